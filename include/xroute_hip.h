@@ -1,0 +1,199 @@
+/*
+ * xroute_hip.h — C ABI of libxroute_hip.so: the MI355X (gfx950) in-process replacement for the
+ * reference's env hot path  Game.reset()/Game.step()  (simulator round trip + build_3Dgrid + metric
+ * deltas + reward).
+ *
+ * The reference has no FFI for this path: the seam is the Python `Game` object and the protobuf
+ * `Message` behind it.  Every entry point below names the reference interface it
+ * replaces.  All paths are relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int32_t status (XR_OK == 0, negative = error);
+ *     xr_last_error() returns a thread-local message for the last failing call on this thread;
+ *   - no exception crosses the ABI;
+ *   - `stream` arguments are a hipStream_t passed as void* (pass torch's current stream);
+ *     functions only enqueue work on it and never synchronise unless documented ("sync");
+ *   - pointers named *_dev are device pointers on the batch's device, *_host are host pointers;
+ *     the caller owns every buffer it passes; the library owns batch state until xr_batch_destroy;
+ *   - calls on one batch must be serialised by the caller; one batch is bound to one HIP device;
+ *   - net ids are 1-based at this boundary exactly as in the reference's env API
+ *     (baseline/baseline_utils.py:20,26,33 shift the wire's 0-based ids by +1; Game.step sends
+ *     action-1, :410).
+ *
+ * Node records (uint32), flat node order f = (x*Y + y)*Z + z  (the memory order of the reference
+ * observation: baseline/build_3Dgrid.py:97-103 reshapes a zeros([X,Y,Z]) tensor without permuting):
+ *   bits  1:0  type  0 BLOCKAGE 1 NORMAL 2 ACCESS     (baseline/openroad_api/proto/net_ordering.proto:5-9)
+ *   bit   2    is_used                                (net_ordering.proto:24)
+ *   bits 16:3  net+1 (0 = none)                       (net_ordering.proto:25)
+ *   bits 30:17 pin+1 (0 = none)                       (net_ordering.proto:26)
+ */
+#ifndef XROUTE_HIP_H
+#define XROUTE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XR_ABI_VERSION 1
+
+/* status codes */
+#define XR_OK            0
+#define XR_ERR_INVALID  (-1)   /* bad argument */
+#define XR_ERR_NOMEM    (-2)   /* host or device allocation failed */
+#define XR_ERR_HIP      (-3)   /* a HIP runtime call failed (message has the HIP error string) */
+#define XR_ERR_STATE    (-4)   /* call order violated (e.g. step before load_regions) */
+#define XR_ERR_RANGE    (-5)   /* size/limit exceeded (dims, net count, LDS capacity ...) */
+#define XR_ERR_PARSE    (-6)   /* malformed protobuf bytes */
+
+/* node record fields */
+#define XR_TYPE_BLOCKAGE 0u
+#define XR_TYPE_NORMAL   1u
+#define XR_TYPE_ACCESS   2u
+#define XR_REC_TYPE(r)   ((r) & 3u)
+#define XR_REC_USED(r)   (((r) >> 2) & 1u)
+#define XR_REC_NET1(r)   (((r) >> 3) & 0x3FFFu)    /* net + 1, 0 = none */
+#define XR_REC_PIN1(r)   (((r) >> 17) & 0x3FFFu)   /* pin + 1, 0 = none */
+#define XR_MAX_NETS      16382
+#define XR_MAX_LAYERS    32
+
+/* owner value of nodes occupied by something that is not a net of this region
+ * (blockages, pre-routed wires: is_used NORMAL nodes in the initial Request) */
+#define XR_OWNER_FOREIGN 0x7FFF
+
+/* per-env status bits (XR_FETCH_STATUS) */
+#define XR_ENV_OK            0
+#define XR_ENV_BAD_ACTION    1   /* action not in the legal set: step was a no-op (the reference does
+                                    not check this client-side, baseline/baseline_utils.py:409-412) */
+#define XR_ENV_UNREACHABLE   2   /* at least one pin could not be reached */
+#define XR_ENV_PATH_TRUNC    4   /* path longer than path_cap: path list truncated, metrics exact */
+#define XR_ENV_WAS_RESET     8   /* auto_reset: this step re-initialised the env instead of routing */
+
+typedef struct xr_batch xr_batch;
+
+/* Router / env parameters.  The simulator knobs mirror the reference's TCL
+ * (ispd/ispd18_test1/run-net-ordering-training.tcl:3 `-drc_cost 8`), the reward weights its
+ * trainers (baseline/DQN/train_DQN.py:98-99, baseline/PPO/train_PPO.py:101-102), max_route_count
+ * its control plane (examples/launch_training.py:28). */
+typedef struct xr_config {
+    int32_t struct_size;      /* = sizeof(xr_config); checked */
+    int32_t device;           /* HIP device ordinal */
+    int32_t n_envs;           /* B: env slots in this batch */
+    int32_t via_cost;         /* XR-Maze v1: cost of one via edge, DBU-equivalent (default 800) */
+    int32_t drc_cost;         /* default 8 */
+    int32_t drc_unit;         /* DBU per drc_cost unit (default 400): entering a node held by
+                                 another net costs drc_cost*drc_unit and counts one violation */
+    int32_t max_route_count;  /* replays of one region before rotating to the next (default 10) */
+    int32_t auto_reset;       /* 1: xr_batch_step re-initialises envs that were done (vector env) */
+    int32_t path_cap;         /* max recorded path nodes per env-step (0 = min(N, 4096)) */
+    int32_t block_threads;    /* route kernel workgroup size, 0 = default */
+    double  w_violation;      /* 500  */
+    double  w_via;            /* 4    */
+    double  w_wirelength;     /* 0.5  */
+} xr_config;
+
+/* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */
+typedef struct xr_region_desc {
+    int32_t dim_x, dim_y, dim_z;
+    const int32_t*  xs_host;        /* [dim_x] track coordinates (Node.point_x), strictly increasing */
+    const int32_t*  ys_host;        /* [dim_y] */
+    const uint8_t*  layer_dir_host; /* [dim_z] 0 = horizontal (x moves), 1 = vertical (y moves) */
+    const uint32_t* nodes_host;     /* [X*Y*Z] packed records */
+    int32_t n_nets;                 /* nets 1..n_nets may appear in records */
+    int32_t metrics0[3];            /* cumulative (violation, wirelength, via) of the initial Request
+                                       (Request.reward_*, net_ordering.proto:36-38) */
+} xr_region_desc;
+
+/* what xr_batch_fetch copies (device -> caller's DEVICE buffer, async on `stream`) */
+#define XR_FETCH_CUM       0   /* int32 [B][3]  cumulative (violation, wirelength, via)  = data[2] */
+#define XR_FETCH_DELTA     1   /* int32 [B][3]  last step's deltas  (Game.step :426-433) */
+#define XR_FETCH_REWARD    2   /* double[B]     -(wv*dvio + wvia*dvia + wwl*dwl)  (train_DQN.py:98-99) */
+#define XR_FETCH_DONE      3   /* uint8 [B]     len(netSet)==0  (Game.step :435-436) */
+#define XR_FETCH_NLEGAL    4   /* int32 [B]     len(netSet) */
+#define XR_FETCH_STATUS    5   /* int32 [B]     XR_ENV_* bits of the last step */
+#define XR_FETCH_LEGAL     6   /* uint64[B][legal_words] bit n-1 set <=> net n in netSet */
+#define XR_FETCH_PATH_LEN  7   /* int32 [B]     nodes claimed by the last step (untruncated count) */
+#define XR_FETCH_PATH      8   /* int32 [B][path_cap] flat node ids in back-trace order */
+#define XR_FETCH_OWNER     9   /* int16 [B][n_max] per-node owner (0 free, net id, XR_OWNER_FOREIGN) */
+#define XR_FETCH_HASH     10   /* uint64[B]     FNV-1a chain over every (path, deltas) since reset_all */
+#define XR_FETCH_REGION   11   /* int32 [B]     region index the env currently plays */
+#define XR_FETCH_STEPS    12   /* int64 [1]     env-steps (real routes, not resets) since create */
+#define XR_FETCH_SWEEPS   13   /* int32 [B]     relaxation sweeps used by the last step */
+
+int32_t     xr_abi_version(void);
+const char* xr_last_error(void);
+void        xr_config_default(xr_config* cfg);
+int32_t     xr_device_count(int32_t* n);
+
+/* ---- batch life cycle ------------------------------------------------------------------- */
+int32_t xr_batch_create(const xr_config* cfg, xr_batch** out);
+int32_t xr_batch_destroy(xr_batch* b);
+
+/* Replaces: receiving the initial Request of each region dump (examples/launch_training.py:57-64
+ * relaunching the simulator on a `workerx*_y*` dir; baseline/baseline_utils.py:459-466).
+ * Uploads the regions and runs the ingest kernel (records -> compact node_net/owner0 state + per-net
+ * access-point lists).  Env e initially plays region e % n_regions.  Synchronises `stream`. */
+int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regions_host, int32_t n_regions,
+                              void* stream);
+
+/* env -> region assignment (host array of n_envs region indices); takes effect at the next reset */
+int32_t xr_batch_assign(xr_batch* b, const int32_t* env_region_host);
+
+/* Sizes the caller needs for its buffers. */
+int32_t xr_batch_sizes(const xr_batch* b, int32_t* n_envs, int32_t* n_regions, int32_t* n_max,
+                       int32_t* k_max, int32_t* legal_words, int32_t* path_cap, int64_t* obs_env_stride);
+
+/* Replaces Game.reset (baseline/baseline_utils.py:441-481) + the control plane's region rotation
+ * (examples/launch_training.py:33-54).  mask_dev: uint8[B] (nonzero = reset this env) or NULL = all.
+ * rotate != 0 applies the 10-replays-then-next-region policy, 0 replays the assigned region. */
+int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, void* stream);
+
+/* Replaces Game.step's simulator round trip (baseline/baseline_utils.py:409-419: send net_index =
+ * action-1, receive the next Request) and its metric bookkeeping (:426-438): routes net
+ * actions_dev[e] (1-based) in env e with the XR-Maze v1 router, claims the path nodes, accumulates
+ * wirelength/via/violation, updates netSet/done/reward. */
+int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
+
+/* BASELINE config "random net-order policy": actions_dev[e] = a uniformly chosen legal net of env e
+ * (1-based; 0 when the env is done), from a counter-based hash of (seed, e, step count). */
+int32_t xr_batch_random_actions(xr_batch* b, int32_t* actions_dev, uint64_t seed, void* stream);
+
+/* Replaces build_3Dgrid on the current state (baseline/build_3Dgrid.py:224-270, called at
+ * baseline/baseline_utils.py:422-423,469-470): fp32 observation [2+7K, Z, Y, X] of envs
+ * [env_lo, env_hi) written at out_dev + (e-env_lo)*env_stride (floats); K = nlegal[e]. */
+int32_t xr_batch_observation(xr_batch* b, float* out_dev, int64_t env_stride, int32_t env_lo,
+                             int32_t env_hi, void* stream);
+
+int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_bytes, void* stream);
+
+/* ---- stateless observation build --------------------------------------------------------- */
+/* Replaces build_3Dgrid(data, routed_nets, bool_inference) for a caller that already holds the
+ * node records (the inference servers baseline/DQN/test_DQN.py:54-62, baseline/PPO/test_PPO.py:
+ * 58-62): nets_dev = the K legal 1-based net ids in ascending order. out_dev: (2+7K)*N floats. */
+int32_t xr_observation_from_records(const uint32_t* nodes_dev, int32_t dim_x, int32_t dim_y,
+                                    int32_t dim_z, const int32_t* nets_dev, int32_t k,
+                                    float* out_dev, void* stream);
+
+/* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
+/* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43).
+ * Pass 1 (fields_host == NULL): fills info_host[8] = {kind (1 request, 2 response, 0 empty),
+ * dim_x, dim_y, dim_z, n_nodes, n_nets, is_done, response.net_index} and metrics_host[3].
+ * Pass 2: fields_host int32[n_nodes][10] = maze xyz, point xyz, type, is_used, net, pin (wire
+ * values, 0-based); nets_host uint32[n_nets]. */
+int32_t xr_proto_decode(const uint8_t* buf_host, size_t len, int64_t* info_host, uint32_t* metrics_host,
+                        int32_t* fields_host, uint32_t* nets_host);
+/* Encodes Message{response{net_index}} exactly as Game.step does (:409-411). Returns bytes written
+ * through *len (buf capacity >= 16). */
+int32_t xr_proto_encode_response(int32_t net_index, uint8_t* buf_host, size_t* len);
+/* Encodes Message{request{...}} (the simulator side; used by tests and the serve-the-protocol path).
+ * Call with buf_host == NULL to get the required size in *len. */
+int32_t xr_proto_encode_request(int32_t dim_x, int32_t dim_y, int32_t dim_z, const int32_t* fields_host,
+                                int32_t n_nodes, const uint32_t* metrics_host, int32_t is_done,
+                                const uint32_t* nets_host, int32_t n_nets, uint8_t* buf_host, size_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XROUTE_HIP_H */
