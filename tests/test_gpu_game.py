@@ -1,0 +1,139 @@
+"""Game drop-in on the GPU: protocol mode replays the reference Game's recorded traces (G3) byte for
+byte; in-process mode equals the oracle env; gym façade and vector env follow the same numbers."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_json, sha
+from xroute_env_amd import proto
+from xroute_env_amd.regions import Region, generate_region
+
+pytestmark = pytest.mark.gpu
+
+
+class ReplayTransport:
+    """Scripted stand-in for the reference's ZMQ sockets (same role as the fake socket the fixture
+    generator used around the reference's Game)."""
+
+    def __init__(self, inbox):
+        self.inbox = list(inbox)
+        self.log = []
+
+    def request_initial(self):
+        self.log.append(["send:REQ", b"initial".hex()])
+
+    def recv(self):
+        return self.inbox.pop(0)
+
+    def send(self, b):
+        self.log.append(["send:REP", bytes(b).hex()])
+
+
+def _trace_inbox(ti, tr):
+    z = np.load(GOLDEN + "/g3_states.npz")
+    dims = tuple(int(v) for v in z[f"t{ti}_dims"])
+    reg = Region(dims, z[f"t{ti}_xs"], z[f"t{ti}_ys"], np.zeros(dims[2], np.uint8), z[f"t{ti}_s0_nodes"], 0)
+    msgs = [bytes.fromhex(h) for h in tr["empties"]]
+    for j, m in enumerate(tr["state_metrics"]):
+        nodes = z[f"t{ti}_s{j}_nodes"]
+        nets = z[f"t{ti}_s{j}_nets"]
+        msgs.append(proto.encode_request(dims, proto.region_wire_fields(reg, nodes), m, len(nets) == 0, nets))
+    return msgs
+
+
+@pytest.mark.parametrize("ti", [0, 1, 2])
+def test_g3_game_trace(ti):
+    from xroute_env_amd.game import Game
+    tr = load_json("g3_game_traces.json")["traces"][ti]
+    inbox = _trace_inbox(ti, tr)
+    assert [hashlib.sha256(m).hexdigest() for m in inbox] == tr["inbox_sha256"]    # our encoder == pb2 bytes
+    tp = ReplayTransport(inbox)
+    game = Game(transport=tp)
+    steps = tr["steps"]
+    obs, tries = game.reset()
+    s0 = steps[0]
+    assert list(obs.shape) == s0["obs_shape"] and sha(obs.numpy()) == s0["obs_sha256"]
+    assert tries == s0["reset_try_time"]
+    assert sorted(game.action_space) == s0["action_space"]
+    assert [game.violation_last_step, game.total_wirelength_last_step, game.via_last_step] == s0["last"]
+    for s in steps[1:]:
+        obs, done, dv, dw, dvia = game.step(s["action"])
+        assert list(obs.shape) == s["obs_shape"] and sha(obs.numpy()) == s["obs_sha256"]
+        assert done == s["done"] and [dv, dw, dvia] == s["delta"]
+        assert sorted(game.legal_action_set) == s["legal"] and sorted(game.routed_nets) == s["routed"]
+    assert tp.log == tr["sends"]
+
+
+def test_game_inprocess_vs_oracle_and_rotation():
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.game import Game, reward_from_deltas
+    regions = [generate_region(7000 + i, dims=(9, 8, 4), k_range=(2, 4)) for i in range(2)]
+    game = Game(regions=regions, max_route_count=2)
+    for episode in range(5):
+        ridx = [0, 0, 1, 1, 0][episode]
+        env = orc.OracleEnv(regions[ridx])
+        obs, tries = game.reset()
+        assert tries == 0 and obs.device.type == "cpu"
+        assert np.array_equal(obs.numpy()[0], env.observation())
+        assert sorted(game.action_space) == env.legal().tolist()
+        done = False
+        while not done:
+            a = max(game.legal_action_set)
+            obs, done, dv, dw, dvia = game.step(a)
+            ref = env.step(a)
+            assert [dv, dw, dvia] == ref["delta"].tolist() and done == ref["done"]
+            assert np.array_equal(obs.numpy()[0], env.observation())
+            assert reward_from_deltas(dv, dw, dvia) == orc.reward(dv, dw, dvia)
+
+
+def test_game_skips_empty_regions():
+    from xroute_env_amd.game import Game
+    from xroute_env_amd.regions import pack_records
+    empty = Region((3, 2, 1), np.arange(3, dtype=np.int32), np.arange(2, dtype=np.int32), np.zeros(1, np.uint8),
+                   pack_records(np.ones(6, int), np.zeros(6, int), -np.ones(6, int), -np.ones(6, int)), 0)
+    full = generate_region(7100, dims=(3, 2, 1), k_range=(1, 1), blockage=(0, 0), prerouted=(0, 0))
+    game = Game(regions=[empty, full], max_route_count=1)
+    obs, tries = game.reset()
+    assert tries == 1 and len(game.action_space) >= 1
+
+
+def test_gym_facade_and_vector_env():
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.envs import OrderingTrainingEnv, StaticRegionEnv, XRouteVectorEnv
+    reg = generate_region(7200, dims=(8, 7, 3), k_range=(3, 3))
+    env = OrderingTrainingEnv([reg], pad_channels=True)
+    ref = orc.OracleEnv(reg)
+    obs, info = env.reset()
+    c0 = obs.shape[0]
+    total = 0.0
+    while True:
+        a = info["legal_actions"][0]
+        obs, rew, term, trunc, info = env.step(a)
+        r = ref.step(a)
+        assert rew == orc.reward(*[int(v) for v in r["delta"]]) and term == r["done"] and not trunc
+        assert obs.shape[0] == c0
+        total += rew
+        if term:
+            break
+    senv = StaticRegionEnv(reg)
+    o1, _ = senv.reset()
+    o2, _ = senv.reset()
+    assert torch.equal(o1, o2)
+
+    regions = [generate_region(7300 + i, dims=(8, 7, 3), k_range=(2, 4)) for i in range(8)]
+    venv = XRouteVectorEnv(regions)
+    ob = orc.OracleBatch(regions)
+    obs, info = venv.reset()
+    acts = torch.empty(8, dtype=torch.int32, device="cuda:0")
+    for it in range(12):
+        venv.random_actions(99, acts)
+        obs, reward, done, info = venv.step(acts)
+        r = ob.step(ob.random_actions(99), threads=1, auto_reset=True)
+        assert np.array_equal(reward.cpu().numpy(), r["reward"])
+        assert done.cpu().numpy().tolist() == r["done"].tolist()
+        o = obs.cpu().numpy()
+        for i, e in enumerate(ob.envs):
+            ro = e.observation()
+            assert np.array_equal(ro.ravel(), o[i, :ro.size])

@@ -1,0 +1,171 @@
+"""GPU parity: xr_batch_step (XR-Maze v1 on the MI355X) == CPU oracle, bit-exact, on the same seeded
+inputs: routed path node lists, metric deltas, done flags, owner grids, legal sets, hash chains."""
+import numpy as np
+import pytest
+import torch
+
+from xroute_env_amd.regions import generate_region, Region, pack_records, ACCESS, NORMAL, BLOCKAGE
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    batch = RegionBatch(regions, device="cuda:0", **kw)
+    envs = [orc.OracleEnv(r, kw.get("via_cost", 800), kw.get("drc_cost", 8), kw.get("drc_unit", 400)) for r in regions]
+    batch.reset()
+    rng = np.random.default_rng(5)
+    total = 0
+    for _ in range(max_steps):
+        legal = batch.legal_sets()
+        for i, env in enumerate(envs):
+            assert sorted(legal[i]) == env.legal().tolist()
+        if not any(legal):
+            break
+        if policy == "min":
+            acts = [min(s) if s else 0 for s in legal]
+        elif policy == "max":
+            acts = [max(s) if s else 0 for s in legal]
+        else:
+            acts = [int(rng.choice(sorted(s))) if s else 0 for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+        delta = batch.fetch("delta").cpu().numpy()
+        cum = batch.fetch("cum").cpu().numpy()
+        done = batch.fetch("done").cpu().numpy()
+        status = batch.fetch("status").cpu().numpy()
+        plen = batch.fetch("path_len").cpu().numpy()
+        path = batch.fetch("path").cpu().numpy()
+        owner = batch.fetch("owner").cpu().numpy()
+        reward = batch.fetch("reward").cpu().numpy()
+        for i, env in enumerate(envs):
+            if not acts[i]:
+                assert status[i] & 1        # XR_ENV_BAD_ACTION on a finished env without auto_reset
+                continue
+            ref = env.step(acts[i])
+            assert status[i] == ref["status"], (i, status[i], ref["status"])
+            assert delta[i].tolist() == ref["delta"].tolist(), (i, acts[i], delta[i], ref["delta"])
+            assert cum[i].tolist() == env.cum().tolist()
+            assert bool(done[i]) == ref["done"]
+            assert plen[i] == ref["path_len"]
+            assert path[i, :plen[i]].tolist() == ref["path"].tolist()
+            assert np.array_equal(owner[i, :env.n], env.owner())
+            assert reward[i] == orc.reward(*[int(v) for v in ref["delta"]])
+            total += 1
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    assert [int(h) for h in hashes] == [e.hash() for e in envs]
+    return total
+
+
+def test_route_parity_ispd_sized():
+    regions = [generate_region(3000 + i) for i in range(24)]
+    n = _run_episode_parity(regions, policy="random")
+    assert n > 200
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 1), (1, 7, 1), (5, 1, 2), (2, 2, 2), (3, 4, 5), (6, 5, 3), (16, 9, 4),
+                                  (7, 31, 9), (33, 8, 2), (12, 12, 12)])
+def test_route_parity_odd_dims(dims):
+    n = dims[0] * dims[1] * dims[2]
+    regions = [generate_region(4000 + 17 * i + n, dims=dims, k_range=(1, 6), net_span=4) for i in range(6)]
+    _run_episode_parity(regions, policy="min")
+
+
+def test_route_parity_policies_and_costs():
+    regions = [generate_region(4500 + i, dims=(14, 17, 6), k_range=(5, 12)) for i in range(8)]
+    _run_episode_parity(regions, policy="max")
+    _run_episode_parity(regions, policy="random", via_cost=1, drc_cost=1, drc_unit=1)
+    _run_episode_parity(regions, policy="random", via_cost=5000, drc_cost=0, drc_unit=400)
+    _run_episode_parity(regions, policy="min", block_threads=64)
+    _run_episode_parity(regions, policy="min", block_threads=1024)
+
+
+def _walled_region():
+    """Two pins separated by a full blockage wall on every layer: unreachable -> violation + flag."""
+    X, Y, Z = 7, 5, 3
+    n = X * Y * Z
+    ntype = np.full(n, NORMAL); used = np.zeros(n, int); net = -np.ones(n, int); pin = -np.ones(n, int)
+    f = lambda x, y, z: (x * Y + y) * Z + z
+    for y in range(Y):
+        for z in range(Z):
+            ntype[f(3, y, z)] = BLOCKAGE; used[f(3, y, z)] = 1
+    for (x, y, p) in [(0, 0, 0), (6, 4, 1), (1, 2, 2)]:
+        ntype[f(x, y, 0)] = ACCESS; net[f(x, y, 0)] = 0; pin[f(x, y, 0)] = p
+    # second net entirely on the left side, crossing net 0's future path region
+    for (x, y, p) in [(0, 4, 0), (2, 0, 1)]:
+        ntype[f(x, y, 1)] = ACCESS; net[f(x, y, 1)] = 1; pin[f(x, y, 1)] = p
+    return Region((X, Y, Z), np.arange(X, dtype=np.int32) * 400, np.arange(Y, dtype=np.int32) * 380,
+                  (np.arange(Z) & 1).astype(np.uint8), pack_records(ntype, used, net, pin), 2,
+                  np.array([2, 100, 3], np.int32))
+
+
+def test_unreachable_pins_and_violations():
+    from xroute_env_amd.batch import RegionBatch
+    reg = _walled_region()
+    _run_episode_parity([reg, reg], policy="min")
+    batch = RegionBatch([reg], device="cuda:0")
+    batch.reset()
+    batch.step(torch.tensor([1], dtype=torch.int32, device="cuda:0"))
+    st = int(batch.fetch("status").cpu()[0])
+    dv = batch.fetch("delta").cpu()[0].tolist()
+    assert st & 2 and dv[0] >= 1              # XR_ENV_UNREACHABLE, one violation per unreachable pin
+
+
+def test_bad_action_is_flagged_noop():
+    from xroute_env_amd.batch import RegionBatch
+    reg = generate_region(4700, dims=(8, 8, 3), k_range=(3, 3))
+    batch = RegionBatch([reg], device="cuda:0")
+    batch.reset()
+    before = batch.fetch("owner").clone()
+    for bad in (0, -3, 99, 4):
+        batch.step(torch.tensor([bad], dtype=torch.int32, device="cuda:0"))
+        assert int(batch.fetch("status").cpu()[0]) == 1
+        assert batch.fetch("delta").cpu()[0].tolist() == [0, 0, 0]
+    assert torch.equal(before, batch.fetch("owner"))
+    batch.step(torch.tensor([2], dtype=torch.int32, device="cuda:0"))
+    assert int(batch.fetch("status").cpu()[0]) & 1 == 0
+    batch.step(torch.tensor([2], dtype=torch.int32, device="cuda:0"))       # already routed
+    assert int(batch.fetch("status").cpu()[0]) == 1
+
+
+def test_large_region_global_scratch_path():
+    """Regions whose distance field does not fit LDS take the HBM-scratch variant of the kernel."""
+    regions = [generate_region(4800 + i, dims=(64, 64, 12), k_range=(3, 4), net_span=20) for i in range(2)]
+    _run_episode_parity(regions, policy="min")
+
+
+def test_auto_reset_rotation_and_random_policy_vs_oracle():
+    """Vector-env mode: random-policy kernel + autoreset, hash chains equal to the oracle batch."""
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(4900 + i, dims=(10, 9, 4), k_range=(2, 5)) for i in range(16)]
+    batch = RegionBatch(regions, n_envs=16, device="cuda:0", auto_reset=True)
+    ob = orc.OracleBatch(regions)
+    batch.reset()
+    acts = torch.empty(16, dtype=torch.int32, device="cuda:0")
+    real = 0
+    for it in range(40):
+        batch.random_actions(777, acts)
+        a_ref = ob.random_actions(777)
+        assert acts.cpu().numpy().tolist() == a_ref.tolist()
+        batch.step(acts)
+        r = ob.step(a_ref, threads=2, auto_reset=True)
+        real += r["real_steps"]
+        assert batch.fetch("delta").cpu().numpy().tolist() == r["delta"].tolist()
+        assert batch.fetch("done").cpu().numpy().tolist() == r["done"].tolist()
+        assert np.array_equal(batch.fetch("reward").cpu().numpy(), r["reward"])
+    assert batch.total_steps() == real
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    assert [int(h) for h in hashes] == [e.hash() for e in ob.envs]
+
+
+def test_region_rotation_policy():
+    """examples/launch_training.py:28-54: the same region max_route_count times, then the next, wrap."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(5000 + i, dims=(4, 4, 2), k_range=(1, 2)) for i in range(3)]
+    batch = RegionBatch(regions, n_envs=1, device="cuda:0", max_route_count=3)
+    seen = []
+    for _ in range(11):
+        batch.reset(rotate=True)
+        seen.append(int(batch.fetch("region").cpu()[0]))
+    assert seen == [0, 0, 0, 1, 1, 1, 2, 2, 2, 0, 0]

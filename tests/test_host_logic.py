@@ -1,0 +1,68 @@
+"""Host-side logic (no GPU): record packing, reference-`data` conversion, netSet logic vs the reference
+fixtures, generator determinism, reward formula."""
+import numpy as np
+import pytest
+
+from tests.helpers import g1_data, g1_records, load_g1, load_json
+from xroute_env_amd.build_3Dgrid import data_to_records, legal_nets
+from xroute_env_amd.regions import (ACCESS, BLOCKAGE, NORMAL, CONFIGS, config_regions, generate_region, pack_records,
+                                    region_from_reference_data, unpack_records)
+
+G1 = load_g1()
+
+
+def test_pack_unpack_roundtrip():
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 3, 1000); u = rng.integers(0, 2, 1000)
+    n = rng.integers(-1, 16382, 1000); p = rng.integers(-1, 16382, 1000)
+    a = unpack_records(pack_records(t, u, n, p))
+    for x, y in zip(a, (t, u, n, p)):
+        assert np.array_equal(x, y)
+    with pytest.raises(ValueError):
+        pack_records([2], [0], [16383], [0])
+
+
+@pytest.mark.parametrize("i", range(len(G1)))
+def test_netset_logic_matches_reference(i):
+    c = G1[i]
+    data = g1_data(c)
+    rec = data_to_records(data)
+    assert np.array_equal(rec, g1_records(c))
+    nets = legal_nets(rec, [int(v) for v in c["routed"]], bool(c["inference"]), data[3])
+    assert nets.tolist() == c["netset"].tolist()
+
+
+def test_region_reference_data_roundtrip():
+    reg = generate_region(42, dims=(6, 5, 4), k_range=(3, 5))
+    data = reg.to_reference_data()
+    back = region_from_reference_data(data, reg.layer_dir)
+    assert back.dims == reg.dims and np.array_equal(back.nodes, reg.nodes)
+    assert np.array_equal(back.xs, reg.xs) and np.array_equal(back.ys, reg.ys)
+    assert np.array_equal(back.metrics0, reg.metrics0) and back.n_nets == reg.n_nets
+
+
+def test_generator_is_deterministic_and_in_spec():
+    a, b = generate_region(1234), generate_region(1234)
+    assert np.array_equal(a.nodes, b.nodes) and np.array_equal(a.ys, b.ys) and a.n_nets == b.n_nets
+    assert a.dims == (24, 40, 9) and a.n_nodes == 8640
+    t, u, n, p = unpack_records(a.nodes)
+    frac_blk = (t == BLOCKAGE).mean()
+    assert 0.09 <= frac_blk <= 0.21
+    assert 4 <= a.n_nets <= 36
+    assert (np.diff(a.xs) == 400).all() and (np.diff(a.ys) > 0).all()
+    assert set(np.unique(np.diff(a.ys))) <= {190, 380, 570, 760, 10, 20, 180, 200, 360, 370, 390, 550, 560}
+    # every net has 1..4 pins, APs only on the two lowest layers
+    z = np.arange(a.n_nodes) % 9
+    assert (z[t == ACCESS] <= 1).all()
+    for k in range(a.n_nets):
+        pins = np.unique(p[(t == ACCESS) & (n == k)])
+        assert 1 <= len(pins) <= 4
+    assert [r.n_nets for r in config_regions(1, 3)] == [10, 10, 10]
+    assert CONFIGS[5]["dims"] == (256, 256, 12)
+
+
+def test_reward_formula_matches_reference_values():
+    from xroute_env_amd.game import reward_from_deltas
+    for t in load_json("g4_reward.json"):
+        r = reward_from_deltas(t["violation"], t["wirelength"], t["via"])
+        assert float(r).hex() == t["reward_hex"]

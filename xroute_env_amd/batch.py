@@ -1,0 +1,200 @@
+"""RegionBatch — Python host layer over the `xr_batch_*` C ABI (include/xroute_hip.h).
+
+A batch holds B env slots on one MI355X.  torch is plumbing only: it allocates the caller-side
+device buffers (actions, observation, fetched results) and supplies the HIP stream; all compute is in
+libxroute_hip.so.  One process per GPU; see xroute_env_amd/dist.py for the sharded launcher.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .regions import Region
+
+
+def _require_gpu(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("xroute_env_amd needs a HIP device (MI355X): torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    return dev
+
+
+def _stream_ptr(dev) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class RegionBatch:
+    """B env slots playing a set of regions.  Mirrors, per env, the reference's Game
+    (baseline/baseline_utils.py:383-481): reset() / step(actions) / observation()."""
+
+    def __init__(self, regions: Sequence[Region], n_envs: Optional[int] = None, device="cuda:0",
+                 auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
+                 max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0):
+        self.device = _require_gpu(device)
+        self.L = _lib.lib()
+        self.regions = list(regions)
+        self.n_envs = int(n_envs if n_envs is not None else len(self.regions))
+        cfg = _lib.default_config()
+        cfg.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        cfg.n_envs = self.n_envs
+        cfg.via_cost, cfg.drc_cost, cfg.drc_unit = via_cost, drc_cost, drc_unit
+        cfg.max_route_count = max_route_count
+        cfg.auto_reset = int(auto_reset)
+        cfg.path_cap = path_cap
+        cfg.block_threads = block_threads
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))
+        with torch.cuda.device(self.device):
+            self._load()
+
+    # ------------------------------------------------------------------------------------------
+    def _load(self):
+        descs = (_lib.XrRegionDesc * len(self.regions))()
+        keep = []
+        for i, r in enumerate(self.regions):
+            xs = np.ascontiguousarray(r.xs, np.int32)
+            ys = np.ascontiguousarray(r.ys, np.int32)
+            ld = np.ascontiguousarray(r.layer_dir, np.uint8)
+            nd = np.ascontiguousarray(r.nodes, np.uint32)
+            if nd.size != r.n_nodes:
+                raise ValueError(f"region {i}: {nd.size} node records for dims {r.dims}")
+            keep += [xs, ys, ld, nd]
+            d = descs[i]
+            d.dim_x, d.dim_y, d.dim_z = (int(v) for v in r.dims)
+            d.xs_host, d.ys_host = xs.ctypes.data, ys.ctypes.data
+            d.layer_dir_host, d.nodes_host = ld.ctypes.data, nd.ctypes.data
+            d.n_nets = int(r.n_nets)
+            for j in range(3):
+                d.metrics0[j] = int(r.metrics0[j])
+        _lib.check(self.L.xr_batch_load_regions(self._h, descs, len(self.regions), _stream_ptr(self.device)))
+        sz = [C.c_int32() for _ in range(6)]
+        stride = C.c_int64()
+        _lib.check(self.L.xr_batch_sizes(self._h, *[C.byref(s) for s in sz], C.byref(stride)))
+        (_, self.n_regions, self.n_max, self.k_max, self.legal_words, self.path_cap) = (s.value for s in sz)
+        self.obs_env_stride = stride.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.L.xr_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def assign(self, env_region: Sequence[int]):
+        a = np.ascontiguousarray(env_region, np.int32)
+        if a.size != self.n_envs:
+            raise ValueError("env_region must have n_envs entries")
+        _lib.check(self.L.xr_batch_assign(self._h, a.ctypes.data))
+
+    def reset(self, mask: Optional[torch.Tensor] = None, rotate: bool = False):
+        """Game.reset for the masked envs (all when mask is None)."""
+        ptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.n_envs:
+                raise ValueError("mask must have n_envs entries")
+            ptr = C.c_void_p(mask.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_reset(self._h, ptr, int(rotate), _stream_ptr(self.device)))
+
+    def step(self, actions: torch.Tensor):
+        """Game.step for every env: actions int32[B] on the device, 1-based net ids."""
+        if actions.device != self.device or actions.dtype != torch.int32 or not actions.is_contiguous() \
+                or actions.numel() != self.n_envs:
+            raise ValueError("actions must be a contiguous int32 tensor of n_envs entries on the batch device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_step(self._h, C.c_void_p(actions.data_ptr()), _stream_ptr(self.device)))
+
+    def random_actions(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_random_actions(self._h, C.c_void_p(out.data_ptr()),
+                                                      C.c_uint64(seed & (2 ** 64 - 1)), _stream_ptr(self.device)))
+        return out
+
+    def alloc_observation(self, n_envs: Optional[int] = None, env_stride: Optional[int] = None) -> torch.Tensor:
+        n = self.n_envs if n_envs is None else n_envs
+        stride = self.obs_env_stride if env_stride is None else env_stride
+        return torch.empty((n, stride), dtype=torch.float32, device=self.device)
+
+    def observation(self, out: Optional[torch.Tensor] = None, env_lo: int = 0, env_hi: Optional[int] = None):
+        """build_3Dgrid of the current state of envs [env_lo, env_hi) into `out` ([n, stride] fp32).
+        Env i's observation is out[i, :(2+7K_i)*N_i] viewed as [2+7K_i, Z, Y, X]."""
+        env_hi = self.n_envs if env_hi is None else env_hi
+        if out is None:
+            out = self.alloc_observation(env_hi - env_lo)
+        if out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 2 \
+                or out.shape[0] < env_hi - env_lo:
+            raise ValueError("out must be a contiguous fp32 [n_envs, stride] tensor on the batch device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_observation(self._h, C.c_void_p(out.data_ptr()), out.shape[1], env_lo, env_hi,
+                                                   _stream_ptr(self.device)))
+        return out
+
+    def env_observation(self, e: int, nlegal: Optional[int] = None) -> torch.Tensor:
+        """Reference-shaped [1, 2+7K, Z, Y, X] observation of one env (device tensor)."""
+        if nlegal is None:
+            nlegal = int(self.fetch("nlegal")[e].item())
+        reg = self.regions[int(self.fetch("region")[e].item())]
+        X, Y, Z = reg.dims
+        buf = self.observation(env_lo=e, env_hi=e + 1)
+        c = 2 + 7 * nlegal
+        return buf[0, : c * reg.n_nodes].view(1, c, Z, Y, X)
+
+    # ------------------------------------------------------------------------------------------
+    _FETCH = {
+        "cum": (_lib.XR_FETCH_CUM, torch.int32, lambda s: (s.n_envs, 3)),
+        "delta": (_lib.XR_FETCH_DELTA, torch.int32, lambda s: (s.n_envs, 3)),
+        "reward": (_lib.XR_FETCH_REWARD, torch.float64, lambda s: (s.n_envs,)),
+        "done": (_lib.XR_FETCH_DONE, torch.uint8, lambda s: (s.n_envs,)),
+        "nlegal": (_lib.XR_FETCH_NLEGAL, torch.int32, lambda s: (s.n_envs,)),
+        "status": (_lib.XR_FETCH_STATUS, torch.int32, lambda s: (s.n_envs,)),
+        "legal": (_lib.XR_FETCH_LEGAL, torch.int64, lambda s: (s.n_envs, s.legal_words)),
+        "path_len": (_lib.XR_FETCH_PATH_LEN, torch.int32, lambda s: (s.n_envs,)),
+        "path": (_lib.XR_FETCH_PATH, torch.int32, lambda s: (s.n_envs, s.path_cap)),
+        "owner": (_lib.XR_FETCH_OWNER, torch.int16, lambda s: (s.n_envs, s.n_max)),
+        "hash": (_lib.XR_FETCH_HASH, torch.int64, lambda s: (s.n_envs,)),
+        "region": (_lib.XR_FETCH_REGION, torch.int32, lambda s: (s.n_envs,)),
+        "steps": (_lib.XR_FETCH_STEPS, torch.int64, lambda s: (1,)),
+        "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
+    }
+
+    def fetch(self, what: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Copy one result array into a device tensor (async on the current stream)."""
+        sel, dtype, shape = self._FETCH[what]
+        if out is None:
+            out = torch.empty(shape(self), dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_fetch(self._h, sel, C.c_void_p(out.data_ptr()),
+                                             out.numel() * out.element_size(), _stream_ptr(self.device)))
+        return out
+
+    def legal_sets(self) -> List[set]:
+        """netSet of every env as Python sets of 1-based ids (host sync)."""
+        words = self.fetch("legal").cpu().numpy().view(np.uint64)
+        out = []
+        for e in range(self.n_envs):
+            s = set()
+            for w in range(self.legal_words):
+                m = int(words[e, w])
+                while m:
+                    b = (m & -m).bit_length() - 1
+                    s.add(w * 64 + b + 1)
+                    m &= m - 1
+            out.append(s)
+        return out
+
+    def total_steps(self) -> int:
+        return int(self.fetch("steps").item())

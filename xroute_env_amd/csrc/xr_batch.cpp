@@ -1,0 +1,480 @@
+// xr_batch.cpp — host side of libxroute_hip.so: the C ABI declared in include/xroute_hip.h.
+// Owns the device state of a batch of env slots and enqueues the gfx950 kernels of xr_kernels.hip.
+// There is NO CPU fallback in this library: without a HIP device every compute entry point fails
+// with XR_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/xroute_hip.h"
+#include "xr_device.h"
+
+extern "C" {
+hipError_t xr_launch_ingest(const uint32_t*, int16_t*, int16_t*, int64_t, hipStream_t);
+hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
+hipError_t xr_route_set_max_lds(size_t);
+hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, size_t, int, hipStream_t);
+hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
+hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
+hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define XR_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(XR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kLdsLimit = 160 * 1024;       // LDS per CU on gfx950
+constexpr size_t kLdsStatic = 2048;            // static __shared__ of the route kernel (AP staging etc.)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct xr_batch {
+    xr_config cfg{};
+    bool loaded = false;
+    int n_regions = 0;
+    int n_max = 0;          // padded max nodes per region (multiple of 8)
+    int n_max_nodes = 0;    // true max N
+    int n_lds = 0;          // padded distance-field words (odd strides), max over regions
+    int tracks_max = 0;
+    int k_max = 0;
+    int legal_words = 1;
+    int path_cap = 0;
+    int x_max = 0, y_max = 0;
+    bool all_n_mult4 = true;
+    bool lds_dist = true;
+    size_t route_lds = 0;
+    int route_threads = 256;
+    // regions
+    DevBuf<XrRegionDev> regions;
+    DevBuf<uint32_t> rg_rec;
+    DevBuf<int16_t> rg_node_net, rg_owner0;
+    DevBuf<int32_t> coords, net_csr, ap_node;
+    DevBuf<int16_t> ap_pin;
+    DevBuf<uint64_t> legal0;
+    // envs
+    DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps;
+    DevBuf<int16_t> owner;
+    DevBuf<uint64_t> legal, hash;
+    DevBuf<double> reward;
+    DevBuf<uint8_t> done, cls_scratch;
+    DevBuf<int64_t> env_steps;
+    DevBuf<unsigned long long> total_steps;
+    DevBuf<uint32_t> dist_scratch;
+    XrBatchDev dev{};
+};
+
+extern "C" {
+
+int32_t xr_abi_version(void) { return XR_ABI_VERSION; }
+const char* xr_last_error(void) { return g_err.c_str(); }
+
+void xr_config_default(xr_config* c) {
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(xr_config);
+    c->device = 0;
+    c->n_envs = 1;
+    c->via_cost = 800;
+    c->drc_cost = 8;           // ispd/ispd18_test1/run-net-ordering-training.tcl:3  -drc_cost 8
+    c->drc_unit = 400;
+    c->max_route_count = 10;   // examples/launch_training.py:28
+    c->auto_reset = 0;
+    c->path_cap = 0;
+    c->block_threads = 0;
+    c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
+    c->w_via = 4.0;
+    c->w_wirelength = 0.5;
+}
+
+int32_t xr_device_count(int32_t* n) {
+    if (!n) return fail(XR_ERR_INVALID, "xr_device_count: null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(XR_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return XR_OK;
+}
+
+int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
+    if (!cfg || !out) return fail(XR_ERR_INVALID, "xr_batch_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(xr_config))
+        return fail(XR_ERR_INVALID, "xr_batch_create: xr_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
+                    sizeof(xr_config));
+    if (cfg->n_envs < 1) return fail(XR_ERR_INVALID, "xr_batch_create: n_envs must be >= 1");
+    if (cfg->via_cost < 1 || cfg->drc_cost < 0 || cfg->drc_unit < 0 || cfg->max_route_count < 1)
+        return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
+    if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
+        return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
+    int ndev = 0;
+    XR_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(XR_ERR_HIP, "xr_batch_create: device %d not present (%d HIP devices)", cfg->device, ndev);
+    XR_HIP(hipSetDevice(cfg->device));
+    xr_batch* b = new (std::nothrow) xr_batch();
+    if (!b) return fail(XR_ERR_NOMEM, "xr_batch_create: out of host memory");
+    b->cfg = *cfg;
+    *out = b;
+    return XR_OK;
+}
+
+int32_t xr_batch_destroy(xr_batch* b) {
+    if (!b) return XR_OK;
+    (void)hipSetDevice(b->cfg.device);
+    delete b;
+    return XR_OK;
+}
+
+int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n_regions, void* stream) {
+    if (!b || !regs || n_regions < 1) return fail(XR_ERR_INVALID, "xr_batch_load_regions: bad argument");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = b->cfg.n_envs;
+
+    std::vector<XrRegionDev> hreg(n_regions);
+    std::vector<uint32_t> hrec;
+    std::vector<int32_t> hcoords, hcsr, hap_node;
+    std::vector<int16_t> hap_pin;
+    int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0;
+    bool mult4 = true;
+    for (int r = 0; r < n_regions; r++) {
+        const xr_region_desc& d = regs[r];
+        if (d.dim_x < 1 || d.dim_y < 1 || d.dim_z < 1 || d.dim_z > XR_MAX_LAYERS)
+            return fail(XR_ERR_RANGE, "region %d: dims %dx%dx%d out of range (z <= %d)", r, d.dim_x, d.dim_y, d.dim_z,
+                        XR_MAX_LAYERS);
+        const int64_t n64 = (int64_t)d.dim_x * d.dim_y * d.dim_z;
+        if (n64 > (int64_t)1 << 30) return fail(XR_ERR_RANGE, "region %d: too many nodes", r);
+        if (!d.xs_host || !d.ys_host || !d.layer_dir_host || !d.nodes_host)
+            return fail(XR_ERR_INVALID, "region %d: null array", r);
+        if (d.n_nets < 0 || d.n_nets > XR_MAX_NETS) return fail(XR_ERR_RANGE, "region %d: n_nets %d", r, d.n_nets);
+        for (int i = 1; i < d.dim_x; i++)
+            if (d.xs_host[i] <= d.xs_host[i - 1]) return fail(XR_ERR_INVALID, "region %d: xs not strictly increasing", r);
+        for (int i = 1; i < d.dim_y; i++)
+            if (d.ys_host[i] <= d.ys_host[i - 1]) return fail(XR_ERR_INVALID, "region %d: ys not strictly increasing", r);
+        const int N = (int)n64;
+        XrRegionDev& R = hreg[r];
+        R.X = d.dim_x; R.Y = d.dim_y; R.Z = d.dim_z; R.N = N;
+        R.n_nets = d.n_nets;
+        R.m0[0] = d.metrics0[0]; R.m0[1] = d.metrics0[1]; R.m0[2] = d.metrics0[2];
+        R.ldir_mask = 0;
+        for (int z = 0; z < d.dim_z; z++)
+            if (d.layer_dir_host[z]) R.ldir_mask |= (1u << z);
+        R.xs_off = (int32_t)hcoords.size();
+        hcoords.insert(hcoords.end(), d.xs_host, d.xs_host + d.dim_x);
+        R.ys_off = (int32_t)hcoords.size();
+        hcoords.insert(hcoords.end(), d.ys_host, d.ys_host + d.dim_y);
+        // node records, padded to a multiple of 8 elements so that int16 planes stay 16-byte aligned
+        R.node_off = (int64_t)hrec.size();
+        hrec.insert(hrec.end(), d.nodes_host, d.nodes_host + N);
+        while (hrec.size() % 8) hrec.push_back(XR_TYPE_NORMAL);
+        // per-net access-point lists (counting sort by 1-based net id; flat order inside a net)
+        R.net_off = (int32_t)hcsr.size();
+        R.ap_off = (int32_t)hap_node.size();
+        std::vector<int32_t> cnt(d.n_nets + 2, 0);
+        for (int f = 0; f < N; f++) {
+            const uint32_t rec = d.nodes_host[f];
+            if (XR_REC_TYPE(rec) == XR_TYPE_ACCESS) {
+                const int net1 = (int)XR_REC_NET1(rec);
+                if (net1 < 1 || net1 > d.n_nets)
+                    return fail(XR_ERR_RANGE, "region %d node %d: ACCESS node with net id %d outside 1..%d", r, f, net1,
+                                d.n_nets);
+                cnt[net1 + 1]++;
+            }
+        }
+        for (int n = 1; n <= d.n_nets + 1; n++) cnt[n] += cnt[n - 1];
+        R.nlegal0 = 0;
+        for (int n = 1; n <= d.n_nets; n++) {
+            const int c = cnt[n + 1] - cnt[n];
+            if (c > XR_MAX_AP_PER_NET)
+                return fail(XR_ERR_RANGE, "region %d net %d: %d access points (max %d)", r, n, c, XR_MAX_AP_PER_NET);
+            R.nlegal0 += (c > 0);
+        }
+        hcsr.insert(hcsr.end(), cnt.begin(), cnt.end());
+        const size_t base = hap_node.size();
+        hap_node.resize(base + cnt[d.n_nets + 1]);
+        hap_pin.resize(base + cnt[d.n_nets + 1]);
+        std::vector<int32_t> cur(cnt.begin(), cnt.end());
+        for (int f = 0; f < N; f++) {
+            const uint32_t rec = d.nodes_host[f];
+            if (XR_REC_TYPE(rec) == XR_TYPE_ACCESS) {
+                const int net1 = (int)XR_REC_NET1(rec);
+                hap_node[base + cur[net1]] = f;
+                hap_pin[base + cur[net1]] = (int16_t)XR_REC_PIN1(rec);
+                cur[net1]++;
+            }
+        }
+        n_max_nodes = std::max(n_max_nodes, N);
+        k_max = std::max(k_max, d.n_nets);
+        x_max = std::max(x_max, d.dim_x);
+        y_max = std::max(y_max, d.dim_y);
+        if (N % 4) mult4 = false;
+        {   // padded field: l = x*SX + y*SY + z, SY = Z|1, SX = (Y*SY)|1 (xr_route_kernel)
+            const int64_t sy = d.dim_z | 1, sx = ((int64_t)d.dim_y * sy) | 1;
+            const int64_t words = (int64_t)d.dim_x * sx;
+            if (words > ((int64_t)1 << 30)) return fail(XR_ERR_RANGE, "region %d: too many nodes", r);
+            n_lds = std::max(n_lds, (int)words);
+            int nv = 0;
+            for (int z = 0; z < d.dim_z; z++) nv += d.layer_dir_host[z] ? 1 : 0;
+            tracks_max = std::max(tracks_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x);
+        }
+    }
+    const int legal_words = std::max(1, (k_max + 63) / 64);
+    std::vector<uint64_t> hlegal0((size_t)n_regions * legal_words, 0);
+    for (int r = 0; r < n_regions; r++) {
+        hreg[r].legal0_off = (int64_t)r * legal_words;
+        const int32_t* csr = hcsr.data() + hreg[r].net_off;
+        for (int n = 1; n <= hreg[r].n_nets; n++)
+            if (csr[n + 1] > csr[n]) hlegal0[(size_t)r * legal_words + ((n - 1) >> 6)] |= 1ULL << ((n - 1) & 63);
+    }
+
+    b->n_regions = n_regions;
+    b->n_max_nodes = n_max_nodes;
+    b->n_max = (n_max_nodes + 7) & ~7;
+    b->n_lds = (n_lds + 7) & ~7;
+    b->tracks_max = tracks_max;
+    b->k_max = k_max;
+    b->legal_words = legal_words;
+    b->x_max = x_max;
+    b->y_max = y_max;
+    b->all_n_mult4 = mult4;
+    b->path_cap = b->cfg.path_cap > 0 ? b->cfg.path_cap : std::min(n_max_nodes, 4096);
+
+    // route kernel placement: distance field + class grid in LDS when they fit
+    const size_t lds_need = (size_t)b->n_lds * 5 + (size_t)(x_max + y_max) * 4;
+    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit;
+    b->route_lds = b->lds_dist ? lds_need : (size_t)(x_max + y_max) * 4;
+    if (b->cfg.block_threads)
+        b->route_threads = b->cfg.block_threads;
+    else
+        b->route_threads = std::min(1024, std::max(128, (tracks_max + 63) & ~63));
+    if (b->lds_dist && b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
+
+    // ---- device allocations ------------------------------------------------------------------
+#define XR_ALLOC(buf, count)                                                                        \
+    do {                                                                                            \
+        hipError_t _e = (buf).alloc(count);                                                         \
+        if (_e != hipSuccess)                                                                       \
+            return fail(XR_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(count) * sizeof(*(buf).p), \
+                        hipGetErrorString(_e));                                                     \
+    } while (0)
+    XR_ALLOC(b->regions, n_regions);
+    XR_ALLOC(b->rg_rec, hrec.size());
+    XR_ALLOC(b->rg_node_net, hrec.size());
+    XR_ALLOC(b->rg_owner0, hrec.size());
+    XR_ALLOC(b->coords, hcoords.size());
+    XR_ALLOC(b->net_csr, hcsr.size());
+    XR_ALLOC(b->ap_node, std::max<size_t>(1, hap_node.size()));
+    XR_ALLOC(b->ap_pin, std::max<size_t>(1, hap_pin.size()));
+    XR_ALLOC(b->legal0, hlegal0.size());
+    XR_ALLOC(b->env_region, B);
+    XR_ALLOC(b->env_replay, B);
+    XR_ALLOC(b->nlegal, B);
+    XR_ALLOC(b->cum, (size_t)B * 3);
+    XR_ALLOC(b->delta, (size_t)B * 3);
+    XR_ALLOC(b->status, B);
+    XR_ALLOC(b->path, (size_t)B * b->path_cap);
+    XR_ALLOC(b->path_len, B);
+    XR_ALLOC(b->sweeps, B);
+    XR_ALLOC(b->owner, (size_t)B * b->n_max);
+    XR_ALLOC(b->legal, (size_t)B * legal_words);
+    XR_ALLOC(b->hash, B);
+    XR_ALLOC(b->reward, B);
+    XR_ALLOC(b->done, B);
+    XR_ALLOC(b->env_steps, B);
+    XR_ALLOC(b->total_steps, 1);
+    if (!b->lds_dist) {
+        XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
+        XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);
+    }
+#undef XR_ALLOC
+
+    XR_HIP(hipMemcpyAsync(b->regions.p, hreg.data(), hreg.size() * sizeof(XrRegionDev), hipMemcpyHostToDevice, st));
+    XR_HIP(hipMemcpyAsync(b->rg_rec.p, hrec.data(), hrec.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    XR_HIP(hipMemcpyAsync(b->coords.p, hcoords.data(), hcoords.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    XR_HIP(hipMemcpyAsync(b->net_csr.p, hcsr.data(), hcsr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!hap_node.empty()) {
+        XR_HIP(hipMemcpyAsync(b->ap_node.p, hap_node.data(), hap_node.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        XR_HIP(hipMemcpyAsync(b->ap_pin.p, hap_pin.data(), hap_pin.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    }
+    XR_HIP(hipMemcpyAsync(b->legal0.p, hlegal0.data(), hlegal0.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    std::vector<int32_t> henv(B);
+    for (int e = 0; e < B; e++) henv[e] = e % n_regions;
+    XR_HIP(hipMemcpyAsync(b->env_region.p, henv.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    XR_HIP(hipMemsetAsync(b->env_replay.p, 0, (size_t)B * sizeof(int32_t), st));
+    XR_HIP(hipMemsetAsync(b->env_steps.p, 0, (size_t)B * sizeof(int64_t), st));
+    XR_HIP(hipMemsetAsync(b->total_steps.p, 0, sizeof(unsigned long long), st));
+    XR_HIP(hipMemsetAsync(b->nlegal.p, 0, (size_t)B * sizeof(int32_t), st));
+    XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
+    XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
+    std::vector<uint64_t> hhash(B, 0xcbf29ce484222325ULL);
+    XR_HIP(hipMemcpyAsync(b->hash.p, hhash.data(), (size_t)B * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+
+    XR_HIP(xr_launch_ingest(b->rg_rec.p, b->rg_node_net.p, b->rg_owner0.p, (int64_t)hrec.size(), st));
+    XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here
+
+    XrBatchDev& d = b->dev;
+    d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
+    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p;
+    d.legal0 = b->legal0.p; d.n_regions = n_regions;
+    d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.legal_words = legal_words; d.path_cap = b->path_cap;
+    d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
+    d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
+    d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
+    d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
+    d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p;
+    d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
+    d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
+    d.w_violation = b->cfg.w_violation; d.w_via = b->cfg.w_via; d.w_wirelength = b->cfg.w_wirelength;
+    b->loaded = true;
+    return XR_OK;
+}
+
+int32_t xr_batch_assign(xr_batch* b, const int32_t* env_region_host) {
+    if (!b || !env_region_host) return fail(XR_ERR_INVALID, "xr_batch_assign: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_assign: load regions first");
+    for (int e = 0; e < b->cfg.n_envs; e++)
+        if (env_region_host[e] < 0 || env_region_host[e] >= b->n_regions)
+            return fail(XR_ERR_RANGE, "xr_batch_assign: env %d -> region %d outside 0..%d", e, env_region_host[e],
+                        b->n_regions - 1);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(hipMemcpy(b->env_region.p, env_region_host, (size_t)b->cfg.n_envs * sizeof(int32_t), hipMemcpyHostToDevice));
+    XR_HIP(hipMemset(b->env_replay.p, 0, (size_t)b->cfg.n_envs * sizeof(int32_t)));
+    return XR_OK;
+}
+
+int32_t xr_batch_sizes(const xr_batch* b, int32_t* n_envs, int32_t* n_regions, int32_t* n_max, int32_t* k_max,
+                       int32_t* legal_words, int32_t* path_cap, int64_t* obs_env_stride) {
+    if (!b) return fail(XR_ERR_INVALID, "xr_batch_sizes: null batch");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_sizes: load regions first");
+    if (n_envs) *n_envs = b->cfg.n_envs;
+    if (n_regions) *n_regions = b->n_regions;
+    if (n_max) *n_max = b->n_max;
+    if (k_max) *k_max = b->k_max;
+    if (legal_words) *legal_words = b->legal_words;
+    if (path_cap) *path_cap = b->path_cap;
+    if (obs_env_stride) *obs_env_stride = (int64_t)(2 + 7 * (int64_t)b->k_max) * (int64_t)b->n_max;
+    return XR_OK;
+}
+
+int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, void* stream) {
+    if (!b) return fail(XR_ERR_INVALID, "xr_batch_reset: null batch");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_reset: load regions first");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(xr_launch_reset(&b->dev, mask_dev, rotate ? 1 : 0, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
+    if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_step: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->route_lds, b->route_threads,
+                           static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_random_actions(xr_batch* b, int32_t* actions_dev, uint64_t seed, void* stream) {
+    if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_random_actions: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_random_actions: load regions first");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(xr_launch_random_actions(&b->dev, actions_dev, seed, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_observation(xr_batch* b, float* out_dev, int64_t env_stride, int32_t env_lo, int32_t env_hi,
+                             void* stream) {
+    if (!b || !out_dev) return fail(XR_ERR_INVALID, "xr_batch_observation: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_observation: load regions first");
+    if (env_lo < 0 || env_hi > b->cfg.n_envs || env_lo > env_hi)
+        return fail(XR_ERR_RANGE, "xr_batch_observation: env range [%d,%d) outside [0,%d)", env_lo, env_hi, b->cfg.n_envs);
+    if (env_stride < (int64_t)2 * b->n_max_nodes)
+        return fail(XR_ERR_RANGE, "xr_batch_observation: env_stride %lld too small", (long long)env_stride);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    const bool vec4 = b->all_n_mult4 && (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    XR_HIP(xr_launch_obs(&b->dev, out_dev, env_stride, env_lo, env_hi, b->n_max_nodes, vec4 ? 1 : 0,
+                         static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_bytes, void* stream) {
+    if (!b || !dst_dev) return fail(XR_ERR_INVALID, "xr_batch_fetch: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_fetch: load regions first");
+    const size_t B = (size_t)b->cfg.n_envs;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+    case XR_FETCH_CUM: src = b->cum.p; bytes = B * 3 * sizeof(int32_t); break;
+    case XR_FETCH_DELTA: src = b->delta.p; bytes = B * 3 * sizeof(int32_t); break;
+    case XR_FETCH_REWARD: src = b->reward.p; bytes = B * sizeof(double); break;
+    case XR_FETCH_DONE: src = b->done.p; bytes = B; break;
+    case XR_FETCH_NLEGAL: src = b->nlegal.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_STATUS: src = b->status.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_LEGAL: src = b->legal.p; bytes = B * b->legal_words * sizeof(uint64_t); break;
+    case XR_FETCH_PATH_LEN: src = b->path_len.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_PATH: src = b->path.p; bytes = B * b->path_cap * sizeof(int32_t); break;
+    case XR_FETCH_OWNER: src = b->owner.p; bytes = B * b->n_max * sizeof(int16_t); break;
+    case XR_FETCH_HASH: src = b->hash.p; bytes = B * sizeof(uint64_t); break;
+    case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
+    case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
+    default: return fail(XR_ERR_INVALID, "xr_batch_fetch: unknown selector %d", what);
+    }
+    if (dst_bytes < bytes)
+        return fail(XR_ERR_RANGE, "xr_batch_fetch(%d): destination holds %zu bytes, need %zu", what, dst_bytes, bytes);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_observation_from_records(const uint32_t* nodes_dev, int32_t X, int32_t Y, int32_t Z, const int32_t* nets_dev,
+                                    int32_t k, float* out_dev, void* stream) {
+    if (!nodes_dev || !out_dev || (k > 0 && !nets_dev)) return fail(XR_ERR_INVALID, "xr_observation_from_records: null argument");
+    if (X < 1 || Y < 1 || Z < 1 || (int64_t)X * Y * Z > ((int64_t)1 << 30) || k < 0 || k > XR_MAX_NETS)
+        return fail(XR_ERR_RANGE, "xr_observation_from_records: dims %dx%dx%d / k %d out of range", X, Y, Z, k);
+    const int N = X * Y * Z;
+    const bool vec4 = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    XR_HIP(xr_launch_obs_records(nodes_dev, X, Y, Z, nets_dev, k, out_dev, vec4 ? 1 : 0, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// xr_device.h — structures shared by the host side (xr_batch.cpp) and the gfx950 kernels
+// (xr_kernels.hip).  Internal: the public boundary is include/xroute_hip.h.
+#pragma once
+#include <stdint.h>
+
+#define XR_INF 0xFFFFFFFFu
+#define XR_CLS_FREE 0
+#define XR_CLS_PEN 1
+#define XR_CLS_BLOCK 2
+#define XR_MAX_AP_PER_NET 256   // access points of one net staged in LDS by the route kernel
+
+// One region (static after xr_batch_load_regions). Node arrays are in the reference observation's
+// flat order f = (x*Y + y)*Z + z.
+struct XrRegionDev {
+    int32_t X, Y, Z, N;
+    int32_t n_nets;        // highest 1-based net id that may appear
+    int32_t nlegal0;       // nets with at least one access point
+    int32_t m0[3];         // cumulative metrics of the initial Request
+    uint32_t ldir_mask;    // bit z set: layer z is vertical (y moves); clear: horizontal (x moves)
+    int32_t xs_off, ys_off;  // into coords[]
+    int32_t net_off;       // into net_csr[]: APs of net n are [csr[n], csr[n+1]) (+ ap_off)
+    int32_t ap_off;        // into ap_node[] / ap_pin[]
+    int64_t node_off;      // into rg_rec / rg_node_net / rg_owner0
+    int64_t legal0_off;    // into legal0[] (uint64 words, legal_words per region)
+};
+
+// Everything a kernel needs, passed by value.
+struct XrBatchDev {
+    // regions (static)
+    const XrRegionDev* regions;
+    const uint32_t* rg_rec;
+    int16_t* rg_node_net;    // -1 blockage / 0 normal / net id of the access point
+    int16_t* rg_owner0;      // initial owner: 0 free, net id (used AP), XR_OWNER_FOREIGN
+    const int32_t* coords;
+    const int32_t* net_csr;
+    const int32_t* ap_node;
+    const int16_t* ap_pin;   // pin + 1
+    const uint64_t* legal0;
+    int32_t n_regions;
+    // envs (mutable)
+    int32_t n_envs;
+    int32_t n_max;           // owner stride per env (elements), multiple of 8
+    int32_t n_lds;           // padded distance-field size (words), max over regions, multiple of 8
+    int32_t legal_words;
+    int32_t path_cap;
+    int32_t* env_region;
+    int32_t* env_replay;
+    int16_t* owner;
+    uint64_t* legal;
+    int32_t* nlegal;
+    int32_t* cum;            // [B][3]
+    int32_t* delta;          // [B][3]
+    double* reward;
+    uint8_t* done;
+    int32_t* status;
+    int32_t* path;           // [B][path_cap]
+    int32_t* path_len;
+    uint64_t* hash;
+    int64_t* env_steps;
+    unsigned long long* total_steps;
+    int32_t* sweeps;
+    uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
+    uint8_t* cls_scratch;
+    // parameters
+    int32_t via_cost, pen_cost, max_route_count, auto_reset;
+    double w_violation, w_via, w_wirelength;
+};

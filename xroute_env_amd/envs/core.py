@@ -1,0 +1,81 @@
+"""Gym-style single-env façade.
+
+The reference reserves the names only: `XRouteEnv.step` is `pass` and the three env classes are
+empty (reference xroute_env/envs/core.py:3-8, ordering_training_env.py:4-5, ...), so the behaviour
+here is the `Game` contract (baseline/baseline_utils.py:383-481) wrapped in the gymnasium calling
+convention.  gymnasium itself is optional: without it a minimal stand-in base class is used.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+try:                                    # gymnasium is not installed in the build image
+    import gymnasium as gym
+    from gymnasium import spaces
+    _HAVE_GYM = True
+except Exception:                       # pragma: no cover - exercised when gymnasium is absent
+    gym = None
+    spaces = None
+    _HAVE_GYM = False
+
+
+class _EnvBase:
+    metadata = {"render_modes": []}
+    observation_space = None
+    action_space = None
+
+    def close(self):
+        pass
+
+
+EnvBase = gym.Env if _HAVE_GYM else _EnvBase
+
+
+class XRouteEnv(EnvBase):
+    """reset(seed, options) -> (obs, info);  step(action) -> (obs, reward, terminated, truncated, info).
+
+    * action: 1-based net id, must be in info["legal_actions"] (the reference's netSet);
+    * obs: fp32 [2+7K, Z, Y, X] in the reference layout (K shrinks as nets are routed); with
+      pad_channels=True it is zero-padded to the episode's initial channel count so that
+      `observation_space` is a fixed Box;
+    * reward = -(500*d_violation + 4*d_via + 0.5*d_wirelength)  (baseline/DQN/train_DQN.py:98-99).
+    """
+
+    def __init__(self, regions: Sequence, device="cuda:0", pad_channels: bool = False, max_route_count: int = 10,
+                 **router_kw):
+        from ..game import Game
+        self.game = Game(regions=list(regions), device=device, max_route_count=max_route_count, **router_kw)
+        self.pad_channels = pad_channels
+        self._c0 = None
+        self.observation_space = None
+        self.action_space = None
+
+    def _spaces(self, obs):
+        if not _HAVE_GYM:
+            return
+        kmax = max(self.game.action_space) if self.game.action_space else 1
+        self.observation_space = spaces.Box(low=0.0, high=float(kmax), shape=tuple(obs.shape), dtype=np.float32)
+        self.action_space = spaces.Discrete(kmax, start=1)
+
+    def _fmt(self, obs):
+        obs = obs[0]
+        if self.pad_channels and obs.shape[0] < self._c0:
+            import torch
+            pad = torch.zeros((self._c0 - obs.shape[0],) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
+            obs = torch.cat([obs, pad], dim=0)
+        return obs
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        obs, tries = self.game.reset()
+        self._c0 = obs.shape[1]
+        out = self._fmt(obs)
+        self._spaces(out)
+        return out, {"legal_actions": sorted(self.game.legal_action_set), "reset_try_time": tries}
+
+    def step(self, action):
+        from ..game import reward_from_deltas
+        obs, done, dv, dw, dvia = self.game.step(int(action))
+        info = {"legal_actions": sorted(self.game.legal_action_set), "violation": dv, "wirelength": dw, "via": dvia}
+        return self._fmt(obs), reward_from_deltas(dv, dw, dvia), bool(done), False, info
