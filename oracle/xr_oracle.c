@@ -414,7 +414,8 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
         int v = best;
         while (e->dist[v] > 0) {
             int pred = -1; uint32_t plen_e = 0; int pvia = 0;
-            uint32_t pen_v = node_pen(e, v, net) ? (uint32_t)e->pen_cost : 0u;
+            const int held = node_pen(e, v, net);     /* a violation even when drc_cost is 0 */
+            uint32_t pen_v = held ? (uint32_t)e->pen_cost : 0u;
             for (int d = 0; d < 6; d++) {
                 uint32_t len; int is_via;
                 int u = graph_nbr(e, v, d, &len, &is_via);
@@ -425,7 +426,7 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
             }
             if (pred < 0) { status |= 0x100; break; }   /* cannot happen on a consistent field */
             /* claim v */
-            if (pen_v) d_vio += 1;
+            if (held) d_vio += 1;
             if (e->owner[v] == 0) e->owner[v] = (int16_t)net;
             e->comp[v] = 1;
             if (plen < path_cap && path) path[plen] = v;
