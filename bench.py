@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched env.step() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the rank's batch of ispd18_test1-sized regions
+(BASELINE config 3, 4096 env slots per GPU, random net-order policy chosen on the device):
+
+    xr_batch_random_actions -> xr_batch_step (grid build + XR-Maze v1 route + metrics/reward,
+    finished envs are re-initialised) -> xr_batch_observation (reference-layout fp32 [2+7K,Z,Y,X] of
+    every env) -> (N > 1) RCCL all_gather of the compact per-env result record.
+
+All inputs are resident in HBM before the timed region.  `value` counts REAL env-steps (a slot
+that spends the step re-initialising a finished episode is not counted) over all ranks / max-rank time.
+The JSON line also carries `roofline` (dominant kernel, HIP-event timed live) and, on rank 0 at N=1,
+`cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
+    ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--no-observation", action="store_true", help="skip xr_batch_observation (NOT the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--seed", type=int, default=2024)
+    return ap.parse_args()
+
+
+def cpu_baseline(regions, seconds, with_obs=True):
+    """Oracle (`port`) on the host cores: same workload, bounded sample."""
+    import numpy as np
+    from oracle import xr_oracle as orc
+    n = min(len(regions), 256)
+    ob = orc.OracleBatch(regions[:n])
+    threads = ob.max_threads()
+    stride = max((2 + 7 * r.n_nets) * r.n_nodes for r in regions[:n])
+    obs = np.empty((n, stride), np.float32) if with_obs else None
+    t0 = time.perf_counter()
+    real = 0
+    it = 0
+    while True:
+        acts = ob.random_actions(99)
+        real += ob.step(acts, threads=threads, auto_reset=True)["real_steps"]
+        if with_obs:
+            ob.observation(obs, stride, threads=threads)
+        it += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or it >= 400:
+            break
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": real / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} envs x {it} batched steps (route + fp32 observation) in {dt:.1f}s, "
+                      f"oracle/xr_oracle.c OpenMP over envs, host cpu '{model}' ({os.cpu_count()} logical)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+
+    B = args.envs
+    regions = config_regions(args.config, B, first_env=rank * B)
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads)
+    batch.reset(rotate=True)
+    acts = torch.empty(B, dtype=torch.int32, device=dev)
+    obs = None if args.no_observation else batch.alloc_observation()
+    # compact per-env result record gathered across ranks: reward f64 | delta 3xi32 | done u8 (padded)
+    rec_local = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    rec_all = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else None
+    reward = torch.empty(B, dtype=torch.float64, device=dev)
+    delta = torch.empty((B, 3), dtype=torch.int32, device=dev)
+    done = torch.empty(B, dtype=torch.uint8, device=dev)
+    nsteps_total = args.warmup + args.steps
+    nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
+    n_nodes = torch.tensor([r.n_nodes for r in regions], dtype=torch.float64, device=dev)
+
+    def one_step(i, ev=None):
+        batch.random_actions(args.seed + rank * 7919 + i, acts)
+        if ev:
+            ev[0].record()
+        batch.step(acts)
+        if ev:
+            ev[1].record()
+        if obs is not None:
+            batch.observation(obs)
+        if ev:
+            ev[2].record()
+        batch.fetch("nlegal", nlegal_log[i])
+        batch.fetch("reward", reward)
+        batch.fetch("delta", delta)
+        batch.fetch("done", done)
+        if world > 1:
+            rec_local[:, 0] = reward
+            rec_local[:, 1:4] = delta.to(torch.float64)
+            dist.all_gather_into_tensor(rec_all, rec_local)      # RCCL over xGMI: the batched-env gather
+
+    for i in range(args.warmup):
+        one_step(i)
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    steps0 = batch.total_steps()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i, events[i])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    real_steps = batch.total_steps() - steps0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    s = torch.tensor([float(real_steps)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    elapsed_max, total_real = float(t.item()), float(s.item())
+
+    # ---- per-kernel live timing (HIP events on the launch stream) and algorithmic bytes -----------
+    route_ms = sum(e[0].elapsed_time(e[1]) for e in events) / max(args.steps, 1)
+    obs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / max(args.steps, 1)
+    k_after = nlegal_log[args.warmup:args.warmup + args.steps].to(torch.float64)          # K written by each obs launch
+    obs_bytes = float(((4.0 * (2.0 + 7.0 * k_after) + 4.0) * n_nodes[None, :]).sum().item()) / max(args.steps, 1)
+    # route launch: every stepped env loads its compact state (node_net i16 + owner i16 = 4 B/node); path writes are noise
+    route_bytes = float((4.0 * n_nodes).sum().item())
+    kernels = []
+    if obs is not None:
+        kernels.append({"kernel": "xr_obs_kernel<4>", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
+                        "achieved": obs_bytes / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else 0.0})
+    kernels.append({"kernel": "xr_route_kernel<true>", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
+                    "achieved": route_bytes / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
+                    "note": "distance field LDS-resident: LDS/latency-bound by construction, HBM bytes are the state load only"})
+    dom = max(kernels, key=lambda k: k["ms"])
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # measured offline with rocprofv3 --pmc (see profiles/README.md)
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom["kernel"])
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(dom["achieved"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes"])}
+
+    out = None
+    if rank == 0:
+        mean_k = float(k_after.mean().item())
+        out = {
+            "metric": "env-steps/sec (batched regions), ispd18_test1-sized regions",
+            "value": round(total_real / elapsed_max, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 distances / i16 state / fp32 observation",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: {B} ispd18_test1-sized regions (24x40x9, K~U[4,36]) per GPU, "
+                                   "full step = random net-order action + XR-Maze v1 route + metrics/reward"
+                                   + ("" if obs is None else " + reference-layout fp32 observation of every env")
+                                   + (", RCCL all_gather of per-env results" if world > 1 else ""),
+                       "envs_per_gpu": B, "global_envs": B * world, "parallelism": f"env-shard x{world}",
+                       "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (args.steps * B * world), 4)},
+            "roofline": roofline,
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=obs is not None)
+            except Exception as ex:          # the oracle is optional for the GPU number itself
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
