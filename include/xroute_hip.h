@@ -121,6 +121,8 @@ typedef struct xr_region_desc {
 #define XR_FETCH_REGION   11   /* int32 [B]     region index the env currently plays */
 #define XR_FETCH_STEPS    12   /* int64 [1]     env-steps (real routes, not resets) since create */
 #define XR_FETCH_SWEEPS   13   /* int32 [B]     relaxation sweeps used by the last step */
+#define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
+                                                 built with -DXR_PHASE_TIMING) */
 
 int32_t     xr_abi_version(void);
 const char* xr_last_error(void);

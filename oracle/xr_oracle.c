@@ -24,6 +24,7 @@
 #define T_ACCESS 2u
 #define OWNER_FOREIGN 0x7FFF
 #define INF32 0xFFFFFFFFu
+#define DIST_CAP 0x30000000u   /* XR-Maze v1: distances >= DIST_CAP do not exist (such a node is unreachable) */
 
 #define ENV_BAD_ACTION 1
 #define ENV_UNREACHABLE 2
@@ -339,7 +340,7 @@ static void dijkstra(xro_env* e, int net) {
             int v = graph_nbr(e, u, d, &len, &is_via);
             if (v < 0 || node_blocked(e, v) || e->comp[v]) continue;
             uint64_t nd = (uint64_t)du + len + (node_pen(e, v, net) ? (uint32_t)e->pen_cost : 0u);
-            if (nd >= INF32) continue;   /* would overflow the spec's uint32 distances */
+            if (nd >= DIST_CAP) continue;   /* spec: such a node is unreachable */
             if ((uint32_t)nd < e->dist[v]) {
                 e->dist[v] = (uint32_t)nd;
                 if (e->heap_n < e->heap_cap) heap_push(e, (uint32_t)nd, v);

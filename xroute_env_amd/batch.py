@@ -169,6 +169,7 @@ class RegionBatch:
         "region": (_lib.XR_FETCH_REGION, torch.int32, lambda s: (s.n_envs,)),
         "steps": (_lib.XR_FETCH_STEPS, torch.int64, lambda s: (1,)),
         "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
+        "phases": (_lib.XR_FETCH_PHASES, torch.int64, lambda s: (s.n_envs, 8)),
     }
 
     def fetch(self, what: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -19,7 +19,7 @@ extern "C" {
 hipError_t xr_launch_ingest(const uint32_t*, int16_t*, int16_t*, int64_t, hipStream_t);
 hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
 hipError_t xr_route_set_max_lds(size_t);
-hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, size_t, int, hipStream_t);
+hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
 hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
@@ -47,7 +47,7 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     } while (0)
 
 constexpr size_t kLdsLimit = 160 * 1024;       // LDS per CU on gfx950
-constexpr size_t kLdsStatic = 2048;            // static __shared__ of the route kernel (AP staging etc.)
+constexpr size_t kLdsStatic = 1280;            // static __shared__ of the route kernel (AP staging etc.)
 
 template <class T>
 struct DevBuf {
@@ -77,6 +77,9 @@ struct xr_batch {
     int n_max_nodes = 0;    // true max N
     int n_lds = 0;          // padded distance-field words (odd strides), max over regions
     int tracks_max = 0;
+    int lines_max = 0;
+    int bits_max = 0;       // tracks + 2 x columns
+    int zch = 0;            // 9 / 12 when all regions have that many layers
     int k_max = 0;
     int legal_words = 1;
     int path_cap = 0;
@@ -99,6 +102,7 @@ struct xr_batch {
     DevBuf<double> reward;
     DevBuf<uint8_t> done, cls_scratch;
     DevBuf<int64_t> env_steps;
+    DevBuf<long long> phase_cycles;
     DevBuf<unsigned long long> total_steps;
     DevBuf<uint32_t> dist_scratch;
     XrBatchDev dev{};
@@ -144,6 +148,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
     if (cfg->n_envs < 1) return fail(XR_ERR_INVALID, "xr_batch_create: n_envs must be >= 1");
     if (cfg->via_cost < 1 || cfg->drc_cost < 0 || cfg->drc_unit < 0 || cfg->max_route_count < 1)
         return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
+    if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
+        return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -175,7 +181,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<uint32_t> hrec;
     std::vector<int32_t> hcoords, hcsr, hap_node;
     std::vector<int16_t> hap_pin;
-    int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0;
+    int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
         const xr_region_desc& d = regs[r];
@@ -256,6 +262,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             int nv = 0;
             for (int z = 0; z < d.dim_z; z++) nv += d.layer_dir_host[z] ? 1 : 0;
             tracks_max = std::max(tracks_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x);
+            lines_max = std::max(lines_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x + d.dim_x * d.dim_y);
+            bits_max = std::max(bits_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x + 2 * d.dim_x * d.dim_y);
+            z_min = std::min(z_min, d.dim_z); z_max = std::max(z_max, d.dim_z);
         }
     }
     const int legal_words = std::max(1, (k_max + 63) / 64);
@@ -272,6 +281,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->n_max = (n_max_nodes + 7) & ~7;
     b->n_lds = (n_lds + 7) & ~7;
     b->tracks_max = tracks_max;
+    b->lines_max = lines_max;
+    b->bits_max = bits_max;
+    b->zch = (z_min == z_max && (z_max == 9 || z_max == 12)) ? z_max : 0;
     b->k_max = k_max;
     b->legal_words = legal_words;
     b->x_max = x_max;
@@ -280,13 +292,21 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->path_cap = b->cfg.path_cap > 0 ? b->cfg.path_cap : std::min(n_max_nodes, 4096);
 
     // route kernel placement: distance field + class grid in LDS when they fit
-    const size_t lds_need = (size_t)b->n_lds * 5 + (size_t)(x_max + y_max) * 4;
-    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit;
-    b->route_lds = b->lds_dist ? lds_need : (size_t)(x_max + y_max) * 4;
+    // field + claim bitmask + edge-length tables + 3 line bitmasks + worklists (u16 line ids)
+    const size_t lw_max = ((size_t)bits_max + 31) / 32 + 1;
+    const size_t el_bytes = (size_t)(x_max + 2 + y_max + 2) * 4;
+    const size_t lds_need = (size_t)b->n_lds * 4 + ((size_t)b->n_lds / 32 + 1) * 4 + el_bytes + 3 * lw_max * 4 +
+                            (size_t)lines_max * 2 + 16;
+    // the worklist kernel keeps one bit per line node in a 64-bit register: X, Y <= 64 (Z <= 32 always)
+    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && lines_max < 65536 && x_max <= 64 && y_max <= 64;
+    b->route_lds = b->lds_dist ? lds_need : el_bytes;
     if (b->cfg.block_threads)
         b->route_threads = b->cfg.block_threads;
     else
-        b->route_threads = std::min(1024, std::max(128, (tracks_max + 63) & ~63));
+        // worklist kernel: ~100-300 dirty lines per iteration on ispd18-sized regions, 4 waves keep 4 workgroups
+        // per CU resident (LDS- and VGPR-wise); large-region kernel: one line per thread up to 1024
+        b->route_threads = b->lds_dist ? std::min(256, std::max(128, (tracks_max + 63) & ~63))
+                                       : std::min(1024, std::max(128, (tracks_max + 63) & ~63));
     if (b->lds_dist && b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
 
     // ---- device allocations ------------------------------------------------------------------
@@ -322,6 +342,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->done, B);
     XR_ALLOC(b->env_steps, B);
     XR_ALLOC(b->total_steps, 1);
+    XR_ALLOC(b->phase_cycles, (size_t)B * 8);
     if (!b->lds_dist) {
         XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);
@@ -343,6 +364,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemsetAsync(b->env_replay.p, 0, (size_t)B * sizeof(int32_t), st));
     XR_HIP(hipMemsetAsync(b->env_steps.p, 0, (size_t)B * sizeof(int64_t), st));
     XR_HIP(hipMemsetAsync(b->total_steps.p, 0, sizeof(unsigned long long), st));
+    XR_HIP(hipMemsetAsync(b->phase_cycles.p, 0, (size_t)B * 8 * sizeof(long long), st));
     XR_HIP(hipMemsetAsync(b->nlegal.p, 0, (size_t)B * sizeof(int32_t), st));
     XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
     XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
@@ -356,12 +378,12 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
     d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
-    d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.legal_words = legal_words; d.path_cap = b->path_cap;
+    d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.lw_max = (int)lw_max; d.lines_max = lines_max; d.x_max = x_max; d.y_max = y_max; d.legal_words = legal_words; d.path_cap = b->path_cap;
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
-    d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p;
+    d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
     d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
     d.w_violation = b->cfg.w_violation; d.w_via = b->cfg.w_via; d.w_wirelength = b->cfg.w_wirelength;
@@ -408,7 +430,7 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
     if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_step: null argument");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
-    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->route_lds, b->route_threads,
+    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
                            static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
@@ -457,6 +479,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;
     default: return fail(XR_ERR_INVALID, "xr_batch_fetch: unknown selector %d", what);
     }
     if (dst_bytes < bytes)

@@ -7,7 +7,7 @@
 #define XR_CLS_FREE 0
 #define XR_CLS_PEN 1
 #define XR_CLS_BLOCK 2
-#define XR_MAX_AP_PER_NET 256   // access points of one net staged in LDS by the route kernel
+#define XR_MAX_AP_PER_NET 128   // access points of one net staged in LDS by the route kernel
 
 // One region (static after xr_batch_load_regions). Node arrays are in the reference observation's
 // flat order f = (x*Y + y)*Z + z.
@@ -41,6 +41,9 @@ struct XrBatchDev {
     int32_t n_envs;
     int32_t n_max;           // owner stride per env (elements), multiple of 8
     int32_t n_lds;           // padded distance-field size (words), max over regions, multiple of 8
+    int32_t lw_max;          // words per line bitmask (tracks + 2 x columns), max over regions
+    int32_t lines_max;       // tracks + columns, max over regions
+    int32_t x_max, y_max;    // largest dims over regions (edge-length tables)
     int32_t legal_words;
     int32_t path_cap;
     int32_t* env_region;
@@ -61,6 +64,7 @@ struct XrBatchDev {
     int32_t* sweeps;
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;
+    long long* phase_cycles; // [B][8] thread-0 cycle counts per kernel phase (only written with -DXR_PHASE_TIMING)
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     double w_violation, w_via, w_wirelength;

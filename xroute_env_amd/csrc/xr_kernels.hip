@@ -110,84 +110,156 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // so any relaxation order that reaches the fixpoint gives the oracle's (Dijkstra's) field; the
 // target choice and the back-trace are deterministic functions of that field.
 //
-// Relaxation = alternating line sweeps ("fast sweeping" on the routing graph):
-//   phase T  thread <-> track (one preferred-direction line of one layer): forward and backward
-//            Gauss-Seidel pass along the whole line, values staged in registers in chunks, so a
-//            distance travels any straight run in ONE pass;
-//   phase V  thread <-> (x,y) column: up and down pass over the via chain.
-// A path with b bends/vias is resolved in ~b iterations instead of ~hops sweeps.  Convergence:
-// __syncthreads_or of "I lowered a distance" over one full T+V iteration.
+// Relaxation = line sweeps ("fast sweeping" on the routing graph).  A *line* is a track (one
+// preferred-direction row of one layer: x-lines on horizontal layers, y-lines on vertical layers) or
+// a column (the via chain of one (x,y)).  One thread takes one line and runs a forward and a backward
+// Gauss-Seidel pass over it, staged through registers 8 nodes at a time; after the two passes the
+// line is internally exact, so a distance travels any straight run in ONE visit.  Track coordinates
+// come through the scalar cache (uniform pointer + uniform index -> s_load), not LDS.
+//
+// Which lines to visit (LDS-resident variant): a dirty-line worklist.  A node lowered by a line
+// pass marks the one other line through that node dirty (atomic OR into an LDS bitmask); every
+// iteration compacts the dirty bitmask into dense worklists (so waves are full) and processes them.
+// A search starts with only the lines through its source nodes dirty, so work follows the wavefront
+// instead of sweeping the whole region.  The large-region variant (field in HBM scratch) sweeps all
+// lines each iteration.
+//
 // Pruning: nothing above `bound` (= best distance of any unconnected target so far) is written; every
 // node with true distance <= the final target distance still gets its exact value (induction along
-// its shortest path), so the target choice and the back-trace are unchanged.
-// Later pins of the same net re-use the field: every value is still an upper bound once the new path
-// nodes are set to 0, so relaxation continues instead of restarting.
+// its shortest path), so the target choice and the back-trace are unchanged.  A line on which a
+// candidate was refused by the bound is remembered (`deferred`) and re-dirtied when the next search of
+// the same net resets the bound.  Later pins re-use the field: every value is still an upper bound
+// once the new path nodes are set to 0, so relaxation continues instead of restarting.
 //
-// LDS layout of the field: index l = x*SX + y*SY + z with SY = Z|1, SX = (Y*SY)|1 (odd strides):
-// lanes of a wave hold consecutive tracks / columns, i.e. consecutive y or consecutive x, so every
-// wave access has an odd word stride and is bank-conflict free.
+// Field word (one u32 per node, nothing else per node):
+//     w = (distance << 2) | (held << 1) | blocked
+//     held = node is held by another net (drc penalty + violation);  blocked nodes have w = 1
+//     0xFFFFFFFC | (held << 1) = unreached.   A node with distance >= XR_DIST_CAP (0x30000000) is
+//     never expanded (spec, mirrored by the oracle), which also makes u32 wrap-around impossible.
+// Field index l = x*SX + y*SY + z with SY = Z|1, SX = (Y*SY)|1 (odd strides): lanes of a wave hold
+// consecutive lines, so wave accesses have odd word strides: bank-conflict free.
 // ------------------------------------------------------------------------------------------------
-#define XR_CH 8          // track chunk held in registers
-#define XR_CLAIM 4u      // cls bit: node claimed by the back-trace in progress
+#ifdef XR_PHASE_TIMING
+#define XR_T0() long long _t = (threadIdx.x == 0) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define XR_LAP(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); _ph[k] += _n - _t; _t = _n; } } while (0)
+#define XR_TDUMP() do { if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) b.phase_cycles[(int64_t)blockIdx.x * 8 + _k] += _ph[_k]; } while (0)
+#else
+#define XR_T0() do {} while (0)
+#define XR_LAP(k) do {} while (0)
+#define XR_TDUMP() do {} while (0)
+#endif
+#define XR_CH 8                       // generic line chunk held in registers
+#define XR_W_USABLE_END 0xC0000000u   // (XR_DIST_CAP << 2): predecessors must be below this
+#define XR_W_UNREACHED 0xFFFFFFFDu    // | held << 1
+#define XR_W_BLOCK 0u                 // blockage (and padded register slots)
 
-__device__ __forceinline__ uint32_t xr_pen_of(uint32_t c, uint32_t pen) { return (c & 3u) == XR_CLS_PEN ? pen : 0u; }
-
-// one Gauss-Seidel pass along a line of L nodes: l(i) = base + i*stride, coordinate c[i]
-template <bool FWD>
-__device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ dist, const uint8_t* __restrict__ cls,
-                                            const int32_t* __restrict__ co, int base, int stride, int L,
-                                            uint32_t pen, uint32_t bound) {
-    int changed = 0;
-    uint32_t prev = XR_INF;
-    int prevc = 0;
-    for (int i0 = 0; i0 < L; i0 += XR_CH) {
-        uint32_t d[XR_CH];
-        uint32_t c[XR_CH];
-        int cc[XR_CH];
+// One Gauss-Seidel pass along a line of L nodes: l(i) = base + i*stride.
+// PLANAR: el4[i] = 4 * distance between node i-1 and node i of the line (LDS table);
+// else constant edge length len4c (via chain).
+// CH nodes are staged in registers per chunk and the NEXT chunk's loads are issued before the current
+// chunk's arithmetic (software pipeline).  The loop-carried dependency per node is three VALU ops
+// (saturating add -> compare -> select); everything else depends only on the loaded words:
+//     add_j  = 4*len + (held ? 4*pen : 0) + flags_j - flags_{j-1}      (blocked node: 0xFFFFFFFF)
+//     cand   = sat_add(w_{j-1}, add_j)                                  (= 4*d_cand + flags_j)
+//     lim_j  = min(w_j, (bound+1) << 2)                                 (blocked node in registers: 0xFFFFFFFF)
+//     w_j    = cand < lim_j ? cand : w_j
+// An unreached or blocked predecessor saturates the add, which can never pass `lim`.  The store is an
+// LDS atomic min of the (possibly unchanged) word: branch-free, and concurrent passes over crossing
+// lines lose no update.  EXACT: L == CH, single chunk, no bounds handling.
+// Returns the set of lowered nodes (bit i); ORs 2 into `flags` when a candidate was refused only
+// because of the bound.
+template <bool FWD, bool PLANAR, int CH, bool EXACT>
+__device__ __forceinline__ unsigned long long xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4,
+                                                            int base, int stride, int L, uint32_t len4c, uint32_t pen4,
+                                                            uint32_t boundw1, int& flags) {
+    unsigned long long lowered = 0;
+    uint32_t prev = 0xFFFFFFFFu;       // "no predecessor": saturates
+    uint32_t pfl = 3u;                 // flag bits of the previous node's word
+    uint32_t refused = 0;
+    uint32_t w[CH], el[CH];
+    auto load = [&](int i0, uint32_t (&ww)[CH], uint32_t (&ee)[CH]) {
+        const bool full = EXACT || (i0 + CH <= L);     // uniform over the wave's lines of one kind
 #pragma unroll
-        for (int j = 0; j < XR_CH; j++) {
+        for (int j = 0; j < CH; j++) {
             const int i = FWD ? (i0 + j) : (L - 1 - i0 - j);
-            const bool in = FWD ? (i < L) : (i >= 0);
-            const int l = base + i * stride;
-            d[j] = in ? dist[l] : XR_INF;
-            c[j] = in ? (uint32_t)cls[l] : (uint32_t)XR_CLS_BLOCK;
-            cc[j] = in ? co[i] : 0;
+            const bool in = full || (FWD ? (i < L) : (i >= 0));
+            ww[j] = in ? field[base + i * stride] : XR_W_BLOCK;
+            ee[j] = PLANAR ? (in ? el4[FWD ? i : i + 1] : 0u) : len4c;
         }
+    };
+    load(0, w, el);
+    for (int i0 = 0; i0 < L; i0 += CH) {
+        uint32_t wnx[CH], enx[CH];
+        const bool more = !EXACT && (i0 + CH < L);
+        if (more) load(i0 + CH, wnx, enx);
+        const bool full = EXACT || (i0 + CH <= L);
+        uint32_t cm = 0;                               // lowered nodes of this chunk, bit j
 #pragma unroll
-        for (int j = 0; j < XR_CH; j++) {
+        for (int j = 0; j < CH; j++) {
             const int i = FWD ? (i0 + j) : (L - 1 - i0 - j);
-            const bool in = FWD ? (i < L) : (i >= 0);
-            if (in) {
-                if ((c[j] & 3u) == XR_CLS_BLOCK) {
-                    prev = XR_INF;
-                } else {
-                    if (prev != XR_INF) {
-                        const uint32_t len = (uint32_t)(FWD ? (cc[j] - prevc) : (prevc - cc[j]));
-                        const uint32_t cand = prev + len + xr_pen_of(c[j], pen);
-                        if (cand < d[j] && cand <= bound) {
-                            d[j] = cand;
-                            dist[base + i * stride] = cand;
-                            changed = 1;
-                        }
-                    }
-                    prev = d[j];
-                }
-                prevc = cc[j];
+            const bool in = full || (FWD ? (i < L) : (i >= 0));
+            // ---- depends only on the loaded word (off the carried chain) ----
+            const uint32_t cw = w[j];
+            const bool blk = (cw == XR_W_BLOCK);
+            const uint32_t cwr = blk ? 0xFFFFFFFFu : cw;
+            const uint32_t fl = cwr & 3u;
+            const uint32_t add = blk ? 0xFFFFFFFFu : (__umul24((cw >> 1) & 1u, pen4) + el[j] + fl - pfl);
+            const uint32_t lim = min(cwr, boundw1);
+            // ---- carried chain: saturating add, compare, select ----
+            const uint32_t cand = __builtin_elementwise_add_sat(prev, add);
+            const bool acc = cand < lim;
+            const uint32_t wn = acc ? cand : cwr;
+            // ---- side results ----
+            refused |= (cand < cwr && !acc && cand < 0xF0000000u) ? 1u : 0u;
+            cm |= acc ? (1u << j) : 0u;
+            if (in) atomicMin(&field[base + i * stride], wn);     // `in` is wave-uniform; blocked: min(0, ~0) = 0
+            prev = wn;
+            pfl = fl;
+        }
+        if (cm) {
+            if (FWD) lowered |= (unsigned long long)cm << i0;
+            else {
+                // bit j of cm is node L-1-i0-j: reverse the CH-bit group, then place it
+                const uint32_t r = __brev(cm) >> (32 - CH);          // bit (CH-1-j) <- bit j
+                const int lo = L - CH - i0;                          // node index of bit 0 after reversal
+                lowered |= lo >= 0 ? ((unsigned long long)r << lo) : ((unsigned long long)r >> (-lo));
             }
         }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) { w[j] = wnx[j]; el[j] = enx[j]; }
+        }
+        if (EXACT) break;
     }
-    return changed;
+    if (refused) flags |= 2;
+    return lowered;
 }
 
-template <bool LDS_DIST>
+// OR a run of up to 64 consecutive bits (ids id0 + i for every set bit i of `bits`) into a bitmask
+__device__ __forceinline__ void xr_or_run(uint32_t* mask, int id0, unsigned long long bits) {
+    if (!bits) return;
+    const int wdx = id0 >> 5, sh = id0 & 31;
+    const unsigned long long sl = bits << sh;
+    const uint32_t m0 = (uint32_t)sl, m1 = (uint32_t)(sl >> 32);
+    const uint32_t m2 = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+    if (m0) atomicOr(&mask[wdx], m0);
+    if (m1) atomicOr(&mask[wdx + 1], m1);
+    if (m2) atomicOr(&mask[wdx + 2], m2);
+}
+
+// ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
+// many layers (single exact chunk).
+template <bool LDS_DIST, int ZCH>
 __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // padded LDS index of each access point
+    __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // padded field index of each access point
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_hl[XR_MAX_LAYERS], s_vl[XR_MAX_LAYERS];
+    __shared__ unsigned short s_ztrk[XR_MAX_LAYERS];  // first track id of layer z
     __shared__ int s_remaining, s_target_i;
     __shared__ uint32_t s_bound;
+    __shared__ int s_cnt[2][3];                        // worklist sizes (H, V, C), double-buffered by parity
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -218,43 +290,103 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         return;
     }
 
-    const int X = R.X, Y = R.Y, Z = R.Z;
+    XR_T0();
+    const int X = R.X, Y = R.Y, Z = R.Z, N = R.N;
     const int SY = Z | 1, SX = (Y * SY) | 1;      // odd strides
+    const int NL = X * SX;                        // padded field size
     const int ncol = X * Y;
+    const uint32_t ldir = R.ldir_mask;
+    const int nv_layers = __popc(ldir & (Z >= 32 ? 0xFFFFFFFFu : ((1u << Z) - 1u)));
+    const int nh_layers = Z - nv_layers;
+    const int tracks_h = nh_layers * Y;            // lines along x, one per (y, horizontal layer)
+    const int tracks_v = nv_layers * X;            // lines along y, one per (x, vertical layer)
+    const int ntracks = tracks_h + tracks_v;
+    // line bitmask layout: [0,ntracks) tracks | [ntracks, +ncol) columns as x*Y+y (written by y-lines and
+    // sources) | [ntracks+ncol, +ncol) columns as y*X+x (written by x-lines): both kinds of line then
+    // report their lowered nodes as ONE run of consecutive bits
+    const int colA0 = ntracks, colB0 = ntracks + ncol;
+    const int nbits = ntracks + 2 * ncol;
+    const int nlw = (nbits + 31) >> 5;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
 
-    // carve: dist u32[n_lds] | cls u8[n_lds] | xs i32[X] | ys i32[Y]
-    uint32_t* dist;
-    uint8_t* cls;
-    int32_t* s_xs;
+    // carve: field u32[n_lds] | claim u32[n_lds/32+1] | el4x u32[x_max+2] | el4y u32[y_max+2]
+    //        (LDS variant only:) dirty0, dirty1, deferred u32[lw_max] | lists u16[lines_max]
+    uint32_t* field;
+    uint32_t* s_claim;
+    uint32_t* s_el4x;
+    uint32_t* s_dirty0 = nullptr;
+    uint32_t* s_dirty1 = nullptr;
+    uint32_t* s_defer = nullptr;
+    unsigned short* s_list = nullptr;
+    const int claim_words = (NL + 31) >> 5;
     if (LDS_DIST) {
-        dist = reinterpret_cast<uint32_t*>(smem);
-        cls = reinterpret_cast<uint8_t*>(smem + (size_t)b.n_lds * 4);
-        s_xs = reinterpret_cast<int32_t*>(smem + (size_t)b.n_lds * 5);   // n_lds % 8 == 0 -> aligned
+        field = reinterpret_cast<uint32_t*>(smem);
+        s_claim = field + b.n_lds;
+        s_el4x = s_claim + (b.n_lds / 32 + 1);
     } else {
-        dist = b.dist_scratch + (int64_t)e * b.n_lds;
-        cls = b.cls_scratch + (int64_t)e * b.n_lds;
-        s_xs = reinterpret_cast<int32_t*>(smem);
+        field = b.dist_scratch + (int64_t)e * b.n_lds;
+        s_claim = reinterpret_cast<uint32_t*>(b.cls_scratch + (int64_t)e * b.n_lds);   // n_lds bytes >= bitmask
+        s_el4x = reinterpret_cast<uint32_t*>(smem);
     }
-    int32_t* s_ys = s_xs + X;
+    uint32_t* s_el4y = s_el4x + (b.x_max + 2);
+    if (LDS_DIST) {
+        s_dirty0 = s_el4y + (b.y_max + 2);
+        s_dirty1 = s_dirty0 + b.lw_max;
+        s_defer = s_dirty1 + b.lw_max;
+        s_list = reinterpret_cast<unsigned short*>(s_defer + b.lw_max);
+    }
+    unsigned short* s_listH = s_list;
+    unsigned short* s_listV = s_list + tracks_h;
+    unsigned short* s_listC = s_list + ntracks;
 
-    // ---- grid build: cost class of every node for THIS net, distance field = INF ------------------
-    for (int col = tid; col < ncol; col += nthr) {
-        const int x = col / Y, y = col - x * Y;
-        const int g0 = col * Z, l0 = x * SX + y * SY;
-        for (int z = 0; z < Z; z++) {
-            const int nn = node_net[g0 + z];
-            const int ow = owner[g0 + z];
-            uint8_t c = XR_CLS_FREE;
-            if (nn == -1) c = XR_CLS_BLOCK;
-            else if ((ow != 0 && ow != a) || (nn > 0 && nn != a)) c = XR_CLS_PEN;
-            cls[l0 + z] = c;
-            dist[l0 + z] = XR_INF;
+    // ---- grid build: field word of every node for THIS net (coalesced 16-byte loads of the state) --
+    {
+        const int nchunk = (N + 7) >> 3;
+        for (int ci = tid; ci < nchunk; ci += nthr) {
+            const int f0 = ci << 3;
+            int pn[4], po[4];          // 8 x int16 each, packed
+            if (f0 + 8 <= N) {
+                const int4 vn = *reinterpret_cast<const int4*>(node_net + f0);
+                const int4 vo = *reinterpret_cast<const int4*>(owner + f0);
+                pn[0] = vn.x; pn[1] = vn.y; pn[2] = vn.z; pn[3] = vn.w;
+                po[0] = vo.x; po[1] = vo.y; po[2] = vo.z; po[3] = vo.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int f = f0 + 2 * j;
+                    const int n0 = (f < N) ? (int)(unsigned short)node_net[f] : 0xFFFF;
+                    const int n1 = (f + 1 < N) ? (int)(unsigned short)node_net[f + 1] : 0xFFFF;
+                    const int o0 = (f < N) ? (int)(unsigned short)owner[f] : 0;
+                    const int o1 = (f + 1 < N) ? (int)(unsigned short)owner[f + 1] : 0;
+                    pn[j] = n0 | (n1 << 16);
+                    po[j] = o0 | (o1 << 16);
+                }
+            }
+            int col = f0 / Z, z = f0 - col * Z;
+            int x = col / Y, y = col - x * Y;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (f0 + j < N) {
+                    const int nn = (int)(short)((j & 1) ? (pn[j >> 1] >> 16) : (pn[j >> 1] & 0xFFFF));
+                    const int ow = (int)(short)((j & 1) ? (po[j >> 1] >> 16) : (po[j >> 1] & 0xFFFF));
+                    uint32_t w;
+                    if (nn == -1) w = XR_W_BLOCK;
+                    else w = XR_W_UNREACHED | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);   // bit 0: real node
+                    field[x * SX + y * SY + z] = w;
+                }
+                if (++z == Z) { z = 0; if (++y == Y) { y = 0; ++x; } }
+            }
         }
     }
-    for (int i = tid; i < X; i += nthr) s_xs[i] = b.coords[R.xs_off + i];
-    for (int i = tid; i < Y; i += nthr) s_ys[i] = b.coords[R.ys_off + i];
+    for (int i = tid; i < claim_words; i += nthr) s_claim[i] = 0;
+    if (LDS_DIST)
+        for (int i = tid; i < nlw; i += nthr) { s_dirty0[i] = 0; s_dirty1[i] = 0; s_defer[i] = 0; }
+    // edge length tables (x4): el4x[i] = 4*(xs[i]-xs[i-1]), 0 at both ends
+    for (int i = tid; i <= X; i += nthr)
+        s_el4x[i] = (i >= 1 && i < X) ? (uint32_t)(b.coords[R.xs_off + i] - b.coords[R.xs_off + i - 1]) << 2 : 0u;
+    for (int i = tid; i <= Y; i += nthr)
+        s_el4y[i] = (i >= 1 && i < Y) ? (uint32_t)(b.coords[R.ys_off + i] - b.coords[R.ys_off + i - 1]) << 2 : 0u;
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
     const int nap = ap_hi - ap_lo;    // 1 <= nap <= XR_MAX_AP_PER_NET (checked at load)
     for (int i = tid; i < nap; i += nthr) {
@@ -264,13 +396,25 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         s_ap_pin[i] = b.ap_pin[R.ap_off + ap_lo + i];
         s_ap_conn[i] = 0;
     }
-    if (tid == 0) {            // layer tables: horizontal layers carry x-tracks, vertical layers y-tracks
+    if (tid == 0) {            // layer tables: horizontal layers carry x-lines, vertical layers y-lines
         int nh = 0, nv = 0;
         for (int z = 0; z < Z; z++) {
-            if ((R.ldir_mask >> z) & 1u) s_vl[nv++] = (unsigned char)z; else s_hl[nh++] = (unsigned char)z;
+            if ((ldir >> z) & 1u) { s_ztrk[z] = (unsigned short)(tracks_h + nv * X); s_vl[nv++] = (unsigned char)z; }
+            else { s_ztrk[z] = (unsigned short)(nh * Y); s_hl[nh++] = (unsigned char)z; }
         }
+        s_cnt[0][0] = s_cnt[0][1] = s_cnt[0][2] = 0;
+        s_cnt[1][0] = s_cnt[1][1] = s_cnt[1][2] = 0;
     }
     __syncthreads();
+
+    // both lines through node l become dirty (used when a node becomes a source)
+    auto mark_node = [&](uint32_t* mask, int l) {
+        const int x = l / SX, r = l - x * SX, y = r / SY, z = r - y * SY;
+        const int tr = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
+        const int cl = colA0 + x * Y + y;
+        atomicOr(&mask[tr >> 5], 1u << (tr & 31));
+        atomicOr(&mask[cl >> 5], 1u << (cl & 31));
+    };
 
     // ---- component = all access points of the lowest pin id -------------------------------------
     if (tid == 0) {
@@ -281,89 +425,172 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
             bool seen = false;
             for (int j = 0; j < i; j++) if (s_ap_pin[j] == s_ap_pin[i]) { seen = true; break; }
             npins += !seen;
-            if (s_ap_pin[i] == first) { s_ap_conn[i] = 1; dist[s_ap_l[i]] = 0; }
+            if (s_ap_pin[i] == first) {
+                s_ap_conn[i] = 1;
+                field[s_ap_l[i]] &= 3u;
+                if (LDS_DIST) mark_node(s_dirty0, s_ap_l[i]);
+            }
         }
         s_remaining = npins - 1;
         s_bound = XR_INF;
     }
     __syncthreads();
+    XR_LAP(0);
 
-    const uint32_t via = (uint32_t)b.via_cost;
-    const uint32_t pen = (uint32_t)b.pen_cost;
-    const int nv_layers = __popc(R.ldir_mask & (Z >= 32 ? 0xFFFFFFFFu : ((1u << Z) - 1u)));
-    const int nh_layers = Z - nv_layers;
-    const int tracks_h = nh_layers * Y;            // lines along x, one per (y, horizontal layer)
-    const int ntracks = tracks_h + nv_layers * X;  // + lines along y, one per (x, vertical layer)
+    const uint32_t via4 = (uint32_t)b.via_cost << 2;
+    const uint32_t pen4 = (uint32_t)b.pen_cost << 2;
     int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, nsweeps = 0;   // thread 0 only
     uint64_t h = (tid == 0) ? b.hash[e] : 0;
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
+    uint32_t* cur = s_dirty0;       // dirty lines to visit this iteration (LDS variant)
+    uint32_t* nxt = s_dirty1;       // dirty lines reported during this iteration
+    int parity = 0;
 
     while (s_remaining > 0) {
+        // new search: the bound was reset, so lines that refused candidates must be looked at again
+        if (LDS_DIST)
+            for (int i = tid; i < nlw; i += nthr) { const uint32_t m = s_defer[i]; if (m) { atomicOr(&cur[i], m); s_defer[i] = 0; } }
         // ---- relax to the (pruned) fixpoint ----------------------------------------------------
-        int any;
-        do {
-            // tighten the bound from the targets' current distances
+        for (;;) {
+            // bound from the targets' current distances
             for (int i = tid; i < nap; i += nthr)
-                if (!s_ap_conn[i]) { const uint32_t dv = dist[s_ap_l[i]]; if (dv != XR_INF) atomicMin(&s_bound, dv); }
-            __syncthreads();
-            const uint32_t bound = s_bound;
+                if (!s_ap_conn[i]) { const uint32_t w = field[s_ap_l[i]]; if (w < XR_W_UNREACHED) atomicMin(&s_bound, w >> 2); }
+            int nH, nV, nC;
+            if (LDS_DIST) {
+                // fold the y*X+x column bits into the x*Y+y ones (one entry per column in the list)
+                for (int wi = (colB0 >> 5) + tid; wi < nlw; wi += nthr) {
+                    uint32_t m = cur[wi];
+                    if (m) {
+                        cur[wi] = 0;
+                        while (m) {
+                            const int id = (wi << 5) + __ffs((int)m) - 1;
+                            m &= m - 1;
+                            if (id >= colB0) {
+                                const int q = id - colB0, y = q / X, x = q - y * X;
+                                const int ca = colA0 + x * Y + y;
+                                atomicOr(&cur[ca >> 5], 1u << (ca & 31));
+                            } else {
+                                atomicOr(&cur[wi], 1u << (id & 31));    // a colA bit sharing the boundary word
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                // compact the dirty bitmask into dense worklists (one list per line kind)
+                const int nlw_a = (colB0 + 31) >> 5;
+                for (int wi = tid; wi < nlw_a; wi += nthr) {
+                    uint32_t m = cur[wi];
+                    const int id0 = wi << 5;
+                    if (id0 + 32 > colB0) {                 // boundary word: keep colB bits for nobody (already folded)
+                        const int keep = colB0 - id0;
+                        m &= keep >= 32 ? 0xFFFFFFFFu : ((1u << keep) - 1u);
+                    }
+                    if (m) {
+                        cur[wi] = 0;
+                        // per kind: reserve a run in the list with one atomic, then fill it
+                        uint32_t mh = 0, mv = 0, mc = 0;
+                        if (id0 + 32 <= tracks_h) mh = m;
+                        else if (id0 >= colA0) mc = m;
+                        else if (id0 >= tracks_h && id0 + 32 <= ntracks) mv = m;
+                        else {
+                            for (uint32_t t = m; t; t &= t - 1) {
+                                const int bit = __ffs((int)t) - 1, id = id0 + bit;
+                                if (id < tracks_h) mh |= 1u << bit; else if (id < ntracks) mv |= 1u << bit; else mc |= 1u << bit;
+                            }
+                        }
+                        if (mh) { int o = atomicAdd(&s_cnt[parity][0], __popc(mh)); for (; mh; mh &= mh - 1) s_listH[o++] = (unsigned short)(id0 + __ffs((int)mh) - 1); }
+                        if (mv) { int o = atomicAdd(&s_cnt[parity][1], __popc(mv)); for (; mv; mv &= mv - 1) s_listV[o++] = (unsigned short)(id0 + __ffs((int)mv) - 1 - tracks_h); }
+                        if (mc) { int o = atomicAdd(&s_cnt[parity][2], __popc(mc)); for (; mc; mc &= mc - 1) s_listC[o++] = (unsigned short)(id0 + __ffs((int)mc) - 1 - colA0); }
+                    }
+                }
+                __syncthreads();
+                nH = s_cnt[parity][0]; nV = s_cnt[parity][1]; nC = s_cnt[parity][2];
+                if (nH + nV + nC == 0) break;              // uniform: nothing left to visit
+                if (tid == 0) { s_cnt[parity ^ 1][0] = 0; s_cnt[parity ^ 1][1] = 0; s_cnt[parity ^ 1][2] = 0; }
+            } else {
+                __syncthreads();
+                nH = tracks_h; nV = tracks_v; nC = ncol;
+            }
+            XR_LAP(1);
+#ifdef XR_PHASE_TIMING
+            if (tid == 0) { _ph[6] += nH + nV + nC; _ph[7] += 1; }
+#endif
+            // candidates must stay <= min(search bound, XR_DIST_CAP - 1): boundw1 = (that + 1) << 2
+            const uint32_t bnd = min(s_bound, (uint32_t)(XR_W_USABLE_END >> 2) - 1u);
+            const uint32_t bound4 = (bnd + 1u) << 2;
             int changed = 0;
-            // phase T: line sweeps
-            for (int t = tid; t < ntracks; t += nthr) {
-                int base, stride, L;
-                const int32_t* co;
-                if (t < tracks_h) {
-                    const int zi = t / Y, y = t - zi * Y;
-                    base = y * SY + s_hl[zi]; stride = SX; L = X; co = s_xs;
+            // each kind starts on a wave boundary: no divergence between line kinds inside a wave
+            const int offV = (nH + 63) & ~63, offC = offV + ((nV + 63) & ~63);
+            const int total = offC + nC;
+            for (int k = tid; k < total; k += nthr) {
+                int fl = 0;
+                int line = -1;                              // canonical line id (for `deferred`)
+                if (k < offV) {
+                    if (k < nH) {
+                        const int t = LDS_DIST ? (int)s_listH[k] : k;
+                        const int zi = t / Y, y = t - zi * Y;
+                        const int base = y * SY + s_hl[zi];
+                        unsigned long long low = xr_line_pass<true, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl);
+                        low |= xr_line_pass<false, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl);
+                        line = t;
+                        changed |= (low != 0);
+                        if (LDS_DIST) xr_or_run(nxt, colB0 + y * X, low);      // columns (x, y) of the lowered x
+                    }
+                } else if (k < offC) {
+                    if (k - offV < nV) {
+                        const int t = LDS_DIST ? (int)s_listV[k - offV] : (k - offV);
+                        const int zi = t / X, x = t - zi * X;
+                        const int base = x * SX + s_vl[zi];
+                        unsigned long long low = xr_line_pass<true, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl);
+                        low |= xr_line_pass<false, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl);
+                        line = tracks_h + t;
+                        changed |= (low != 0);
+                        if (LDS_DIST) xr_or_run(nxt, colA0 + x * Y, low);      // columns (x, y) of the lowered y
+                    }
                 } else {
-                    const int u = t - tracks_h;
-                    const int zi = u / X, x = u - zi * X;
-                    base = x * SX + s_vl[zi]; stride = SY; L = Y; co = s_ys;
-                }
-                changed |= xr_line_pass<true>(dist, cls, co, base, stride, L, pen, bound);
-                changed |= xr_line_pass<false>(dist, cls, co, base, stride, L, pen, bound);
-            }
-            __syncthreads();
-            // phase V: via chains
-            for (int col = tid; col < ncol; col += nthr) {
-                const int x = col / Y, y = col - x * Y;
-                const int l0 = x * SX + y * SY;
-                uint32_t prev = XR_INF;
-                for (int z = 0; z < Z; z++) {
-                    const uint32_t c = cls[l0 + z];
-                    if ((c & 3u) == XR_CLS_BLOCK) { prev = XR_INF; continue; }
-                    uint32_t cur = dist[l0 + z];
-                    if (prev != XR_INF) {
-                        const uint32_t cand = prev + via + xr_pen_of(c, pen);
-                        if (cand < cur && cand <= bound) { cur = cand; dist[l0 + z] = cand; changed = 1; }
+                    const int c = LDS_DIST ? (int)s_listC[k - offC] : (k - offC);
+                    const int x = c / Y, y = c - x * Y;
+                    unsigned long long low;
+                    if (ZCH > 0) {
+                        low = xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl);
+                        low |= xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl);
+                    } else {
+                        low = xr_line_pass<true, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl);
+                        low |= xr_line_pass<false, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl);
                     }
-                    prev = cur;
+                    line = colA0 + c;
+                    changed |= (low != 0);
+                    if (LDS_DIST)                           // lowered node z: its track must be looked at
+                        while (low) {
+                            const int z = __ffsll((long long)low) - 1; low &= low - 1;
+                            const int id = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
+                            atomicOr(&nxt[id >> 5], 1u << (id & 31));
+                        }
                 }
-                prev = XR_INF;
-                for (int z = Z - 1; z >= 0; z--) {
-                    const uint32_t c = cls[l0 + z];
-                    if ((c & 3u) == XR_CLS_BLOCK) { prev = XR_INF; continue; }
-                    uint32_t cur = dist[l0 + z];
-                    if (prev != XR_INF) {
-                        const uint32_t cand = prev + via + xr_pen_of(c, pen);
-                        if (cand < cur && cand <= bound) { cur = cand; dist[l0 + z] = cand; changed = 1; }
-                    }
-                    prev = cur;
-                }
+                if (LDS_DIST && (fl & 2)) atomicOr(&s_defer[line >> 5], 1u << (line & 31));
             }
-            any = __syncthreads_or(changed);
             nsweeps++;
-        } while (any);
+            if (LDS_DIST) {
+                __syncthreads();
+                uint32_t* t = cur; cur = nxt; nxt = t;
+                parity ^= 1;
+                XR_LAP(2);
+            } else {
+                const int any = __syncthreads_or(changed);
+                XR_LAP(2);
+                if (!any) break;
+            }
+        }
 
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
         if (tid < 64) {
             unsigned long long best = ~0ULL;
             for (int i = tid; i < nap; i += 64) {
                 if (s_ap_conn[i]) continue;
-                const uint32_t dv = dist[s_ap_l[i]];
-                if (dv == XR_INF) continue;
+                const uint32_t w = field[s_ap_l[i]];
+                if (w >= XR_W_UNREACHED) continue;
                 // (distance, padded index): padded index order == flat index order
-                const unsigned long long key = ((unsigned long long)dv << 32) | (unsigned)s_ap_l[i];
+                const unsigned long long key = ((unsigned long long)(w >> 2) << 32) | (unsigned)s_ap_l[i];
                 best = key < best ? key : best;
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -389,48 +616,48 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
                 }
             } else {
                 // ---- deterministic back-trace: first predecessor in the order E,S,W,N,U,D.
-                // Lanes 0..5 test one direction each; ballot + ffs picks the first match.
+                // Lanes 0..5 test one direction each; ballot + ffs picks the first match.  The field is
+                // only READ here; claimed nodes are zeroed afterwards (a zero written mid-trace could
+                // fake a predecessor match on the node after it).
                 int v = s_ap_l[best_i];
-                uint32_t dv = dist[v];
-                uint32_t cv = cls[v];
-                while (dv > 0) {
+                uint32_t vw = field[v];
+                while ((vw >> 2) > 0) {
                     const int x = v / SX, r = v - x * SX, y = r / SY, z = r - y * SY;
-                    const uint32_t need = dv - xr_pen_of(cv, pen);   // dist[u] + len must equal this
-                    const bool vert = (R.ldir_mask >> z) & 1u;
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);   // pred distance + edge, x4
+                    const bool vert = (ldir >> z) & 1u;
                     int u = -1;
-                    uint32_t len = 0;
+                    uint32_t len4 = 0;
                     switch (tid) {
-                    case 0: if (!vert && x + 1 < X) { u = v + SX; len = (uint32_t)(s_xs[x + 1] - s_xs[x]); } break;   // E
-                    case 1: if (vert && y > 0)      { u = v - SY; len = (uint32_t)(s_ys[y] - s_ys[y - 1]); } break;   // S
-                    case 2: if (!vert && x > 0)     { u = v - SX; len = (uint32_t)(s_xs[x] - s_xs[x - 1]); } break;   // W
-                    case 3: if (vert && y + 1 < Y)  { u = v + SY; len = (uint32_t)(s_ys[y + 1] - s_ys[y]); } break;   // N
-                    case 4: if (z + 1 < Z)          { u = v + 1; len = via; } break;                                   // U
-                    case 5: if (z > 0)              { u = v - 1; len = via; } break;                                   // D
+                    case 0: if (!vert && x + 1 < X) { u = v + SX; len4 = s_el4x[x + 1]; } break;   // E
+                    case 1: if (vert && y > 0)      { u = v - SY; len4 = s_el4y[y]; } break;       // S
+                    case 2: if (!vert && x > 0)     { u = v - SX; len4 = s_el4x[x]; } break;       // W
+                    case 3: if (vert && y + 1 < Y)  { u = v + SY; len4 = s_el4y[y + 1]; } break;   // N
+                    case 4: if (z + 1 < Z)          { u = v + 1; len4 = via4; } break;             // U
+                    case 5: if (z > 0)              { u = v - 1; len4 = via4; } break;             // D
                     default: break;
                     }
-                    uint32_t du = XR_INF, cu = XR_CLS_BLOCK;
+                    uint32_t uw = XR_W_BLOCK;
                     bool ok = false;
                     if (u >= 0) {
-                        cu = cls[u];
-                        du = dist[u];
-                        ok = ((cu & 3u) != XR_CLS_BLOCK) && du != XR_INF && du + len == need;
+                        uw = field[u];
+                        ok = (uw - 1u) < (XR_W_USABLE_END - 1u) && (uw & ~3u) + len4 == need4;
                     }
                     const unsigned long long m = __ballot(ok);
                     if (m == 0) { if (tid == 0) status |= 0x100; break; }     // inconsistent field: cannot happen
                     const int src = __ffsll((long long)m) - 1;
                     const int pu = __shfl(u, src);
-                    const uint32_t pdu = __shfl(du, src), pcu = __shfl(cu, src), pl = __shfl(len, src);
+                    const uint32_t puw = __shfl(uw, src), pl4 = __shfl(len4, src);
                     if (tid == 0) {                 // claim v
                         const int f = (x * Y + y) * Z + z;
-                        if ((cv & 3u) == XR_CLS_PEN) d_vio += 1;
+                        if (vw & 2u) d_vio += 1;
                         if (owner[f] == 0) owner[f] = (int16_t)a;
-                        cls[v] = (uint8_t)(cv | XR_CLAIM);     // dist[v] = 0 after the trace (the trace reads the field)
+                        s_claim[v >> 5] |= 1u << (v & 31);
                         if (plen < b.path_cap) path[plen] = f;
                         plen++;
                         fnv_mix(h, (uint32_t)f);
-                        if (src >= 4) d_via += 1; else d_wl += (int)pl;
+                        if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
                     }
-                    v = pu; dv = pdu; cv = pcu;
+                    v = pu; vw = puw;
                 }
                 if (tid == 0 && (status & 0x100)) {
                     s_remaining = 0;              // never taken on a consistent field; avoids spinning
@@ -450,24 +677,34 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
             }
         }
         __syncthreads();
+        XR_LAP(3);
         // path nodes and the reached pin's access points become sources of the next search
         {
             const int ti = s_target_i;
             if (ti >= 0) {
                 const short pin = s_ap_pin[ti];
                 for (int i = tid; i < nap; i += nthr)
-                    if (s_ap_pin[i] == pin) { s_ap_conn[i] = 1; dist[s_ap_l[i]] = 0; }
-                for (int col = tid; col < ncol; col += nthr) {
-                    const int x = col / Y, y = col - x * Y;
-                    const int l0 = x * SX + y * SY;
-                    for (int z = 0; z < Z; z++) {
-                        const uint32_t c = cls[l0 + z];
-                        if (c & XR_CLAIM) { cls[l0 + z] = (uint8_t)(c & 3u); dist[l0 + z] = 0; }
+                    if (s_ap_pin[i] == pin) {
+                        s_ap_conn[i] = 1;
+                        field[s_ap_l[i]] &= 3u;
+                        if (LDS_DIST) mark_node(cur, s_ap_l[i]);
+                    }
+                for (int wi = tid; wi < claim_words; wi += nthr) {
+                    uint32_t m = s_claim[wi];
+                    if (m) {
+                        s_claim[wi] = 0;
+                        while (m) {
+                            const int l = (wi << 5) + __ffs((int)m) - 1;
+                            m &= m - 1;
+                            field[l] &= 3u;
+                            if (LDS_DIST) mark_node(cur, l);
+                        }
                     }
                 }
             }
         }
         __syncthreads();
+        XR_LAP(4);
     }
 
     // ---- Game.step bookkeeping (reference baseline/baseline_utils.py:412, :426-438) + reward ------
@@ -492,6 +729,8 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         b.env_steps[e] += 1;
         atomicAdd(b.total_steps, 1ULL);
     }
+    XR_LAP(5);
+    XR_TDUMP();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,16 +928,29 @@ hipError_t xr_launch_reset(const XrBatchDev* b, const uint8_t* mask, int rotate,
 }
 
 hipError_t xr_route_set_max_lds(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 12>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_dist, size_t lds_bytes, int threads,
-                           hipStream_t st) {
-    if (lds_dist)
-        hipLaunchKernelGGL(xr_route_kernel<true>, dim3(b->n_envs), dim3(threads), lds_bytes, st, *b, actions);
-    else
-        hipLaunchKernelGGL(xr_route_kernel<false>, dim3(b->n_envs), dim3(threads), lds_bytes, st, *b, actions);
+// zch: 9 / 12 when every region of the batch has exactly that many layers, else 0
+hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
+                           int threads, hipStream_t st) {
+    const dim3 g(b->n_envs), t(threads);
+    if (lds_dist) {
+        if (zch == 9) hipLaunchKernelGGL((xr_route_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
+        else if (zch == 12) hipLaunchKernelGGL((xr_route_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_route_kernel<true, 0>), g, t, lds_bytes, st, *b, actions);
+    } else {
+        if (zch == 9) hipLaunchKernelGGL((xr_route_kernel<false, 9>), g, t, lds_bytes, st, *b, actions);
+        else if (zch == 12) hipLaunchKernelGGL((xr_route_kernel<false, 12>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_route_kernel<false, 0>), g, t, lds_bytes, st, *b, actions);
+    }
     return hipGetLastError();
 }
 
