@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="run 1 GiB fill/add kernels first (known HBM byte counts for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
@@ -95,7 +97,17 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.pmc_calibrate:          # known traffic for FETCH_SIZE / WRITE_SIZE calibration (tools/pmc_parse.py)
+        ca = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        cb = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            ca.fill_(1.0)
+            torch.add(ca, 1.0, out=cb)
+        torch.cuda.synchronize(dev)
+        del ca, cb
+
     from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.dist import RECORD_WIDTH, gather_records_fixed, pack_records
     from xroute_env_amd.regions import config_regions
 
     B = args.envs
@@ -104,9 +116,9 @@ def main():
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()
-    # compact per-env result record gathered across ranks: reward f64 | delta 3xi32 | done u8 (padded)
-    rec_local = torch.empty((B, 4), dtype=torch.float64, device=dev)
-    rec_all = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else None
+    # compact per-env result record gathered across ranks (xroute_env_amd/dist.py): 6 x f64 per env
+    rec_local = torch.empty((B, RECORD_WIDTH), dtype=torch.float64, device=dev)
+    rec_all = torch.empty((world * B, RECORD_WIDTH), dtype=torch.float64, device=dev) if world > 1 else None
     reward = torch.empty(B, dtype=torch.float64, device=dev)
     delta = torch.empty((B, 3), dtype=torch.int32, device=dev)
     done = torch.empty(B, dtype=torch.uint8, device=dev)
@@ -130,9 +142,8 @@ def main():
         batch.fetch("delta", delta)
         batch.fetch("done", done)
         if world > 1:
-            rec_local[:, 0] = reward
-            rec_local[:, 1:4] = delta.to(torch.float64)
-            dist.all_gather_into_tensor(rec_all, rec_local)      # RCCL over xGMI: the batched-env gather
+            pack_records(reward, delta, done, nlegal_log[i], rec_local)
+            gather_records_fixed(rec_local, rec_all)             # RCCL over xGMI: the batched-env gather
 
     for i in range(args.warmup):
         one_step(i)
@@ -167,9 +178,9 @@ def main():
     route_bytes = float((4.0 * n_nodes).sum().item())
     kernels = []
     if obs is not None:
-        kernels.append({"kernel": "xr_obs_kernel<4>", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
+        kernels.append({"kernel": "xr_obs_kernel", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
                         "achieved": obs_bytes / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else 0.0})
-    kernels.append({"kernel": "xr_route_kernel<true>", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
+    kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
                     "achieved": route_bytes / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
                     "note": "distance field LDS-resident: LDS/latency-bound by construction, HBM bytes are the state load only"})
     dom = max(kernels, key=lambda k: k["ms"])
@@ -178,6 +189,8 @@ def main():
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(dom["kernel"])
+            if isinstance(traffic, dict):
+                traffic = traffic.get("hbm_total_bytes")
         except Exception:
             traffic = None
     roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK_GBPS,

@@ -1,0 +1,94 @@
+"""BASELINE-size run (4096 ispd18_test1-sized regions, config 3) on the GPU: size-independent properties of
+every step, plus the per-env hash chain (paths + deltas of every step) against the oracle run with OpenMP."""
+import numpy as np
+import pytest
+import torch
+
+from xroute_env_amd.regions import config_regions
+
+pytestmark = pytest.mark.gpu
+
+B = 4096
+STEPS = 24
+
+
+@pytest.fixture(scope="module")
+def regions():
+    return config_regions(3, B)
+
+
+def test_fullsize_properties_and_hash_chain(regions):
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    batch = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True)
+    ob = orc.OracleBatch(regions)
+    threads = ob.max_threads()
+    batch.reset()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    nn = np.array([r.n_nodes for r in regions])
+    cum_prev = batch.fetch("cum").cpu().numpy().astype(np.int64)
+    used_prev = (batch.fetch("owner") != 0).sum(dim=1).cpu().numpy()
+    real = 0
+    for it in range(STEPS):
+        batch.random_actions(31337, acts)
+        a_ref = ob.random_actions(31337)
+        assert np.array_equal(acts.cpu().numpy(), a_ref)
+        batch.step(acts)
+        r = ob.step(a_ref, threads=threads, auto_reset=True)
+        real += r["real_steps"]
+        status = batch.fetch("status").cpu().numpy()
+        delta = batch.fetch("delta").cpu().numpy().astype(np.int64)
+        cum = batch.fetch("cum").cpu().numpy().astype(np.int64)
+        done = batch.fetch("done").cpu().numpy()
+        nleg = batch.fetch("nlegal").cpu().numpy()
+        plen = batch.fetch("path_len").cpu().numpy()
+        reward = batch.fetch("reward").cpu().numpy()
+        used = (batch.fetch("owner") != 0).sum(dim=1).cpu().numpy()
+        was_reset = (status & 8) != 0
+        stepped = ~was_reset
+        assert not (status & (1 | 4 | 0x100)).any()                       # no bad action, no truncation, consistent field
+        # GPU == oracle on everything the env returns
+        assert np.array_equal(delta, r["delta"]) and np.array_equal(done, r["done"]) and np.array_equal(reward, r["reward"])
+        # size-independent properties
+        assert np.array_equal(cum[stepped], cum_prev[stepped] + delta[stepped])        # cumulative = running sum of deltas
+        assert np.array_equal(done != 0, nleg == 0)                                      # done <=> netSet empty
+        grew = (used - used_prev)[stepped]          # path nodes already held by another net keep their owner
+        assert (grew <= plen[stepped]).all() and (grew >= plen[stepped] - delta[stepped][:, 0]).all()
+        assert (delta[stepped][:, 1:] >= 0).all() and (delta[stepped][:, 0] >= 0).all()
+        assert np.array_equal(reward, -1.0 * (500.0 * delta[:, 0] + 4.0 * delta[:, 2] + 0.5 * delta[:, 1]))
+        assert (delta[was_reset] == 0).all()
+        cum_prev, used_prev = cum, used
+    assert batch.total_steps() == real
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    ref = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
+    assert np.array_equal(hashes, ref)                                                   # every path node of every step
+
+
+def test_fullsize_observation_properties(regions):
+    """Reference-layout observation of all 4096 envs: structural checks + exact equality on a sample."""
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import unpack_records, BLOCKAGE
+    sub = regions[:512]
+    batch = RegionBatch(sub, n_envs=len(sub), device="cuda:0", auto_reset=True)
+    batch.reset()
+    acts = torch.empty(len(sub), dtype=torch.int32, device="cuda:0")
+    for it in range(3):
+        batch.random_actions(7, acts)
+        batch.step(acts)
+    obs = batch.observation()
+    nleg = batch.fetch("nlegal").cpu().numpy()
+    owner = batch.fetch("owner").cpu().numpy()
+    legal = batch.legal_sets()
+    N = sub[0].n_nodes
+    for i in range(0, len(sub), 37):
+        k = int(nleg[i])
+        o = obs[i, : (2 + 7 * k) * N].view(2 + 7 * k, N).cpu().numpy()
+        t, u, n, p = unpack_records(sub[i].nodes)
+        assert np.array_equal(o[0] != 0, (t == BLOCKAGE) | (owner[i, :N] != 0))          # obstacle plane
+        assert o[1, :k].tolist() == sorted(legal[i]) and (o[1, k:] == 0).all()           # order plane
+        for j in range(k):
+            for c in range(2, 7):
+                assert np.array_equal(o[2 + 7 * j + 1], o[2 + 7 * j + c])                # the six aliased planes
+            assert (o[2 + 7 * j + 1] <= o[2 + 7 * j]).all()
+        assert set(np.unique(o[2:])) <= {0.0, 1.0}
