@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-observation", action="store_true", help="skip xr_batch_observation (NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="two launches (xr_batch_step, xr_batch_observation) instead of the fused xr_batch_step_observe")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -126,15 +128,22 @@ def main():
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
     n_nodes = torch.tensor([r.n_nodes for r in regions], dtype=torch.float64, device=dev)
 
+    fused = (obs is not None) and not args.no_fuse
+
     def one_step(i, ev=None):
         batch.random_actions(args.seed + rank * 7919 + i, acts)
         if ev:
             ev[0].record()
-        batch.step(acts)
-        if ev:
-            ev[1].record()
-        if obs is not None:
-            batch.observation(obs)
+        if fused:
+            batch.step(acts, obs)                 # one launch: route + observation of every env
+            if ev:
+                ev[1].record()
+        else:
+            batch.step(acts)
+            if ev:
+                ev[1].record()
+            if obs is not None:
+                batch.observation(obs)
         if ev:
             ev[2].record()
         batch.fetch("nlegal", nlegal_log[i])
@@ -177,12 +186,19 @@ def main():
     # route launch: every stepped env loads its compact state (node_net i16 + owner i16 = 4 B/node); path writes are noise
     route_bytes = float((4.0 * n_nodes).sum().item())
     kernels = []
-    if obs is not None:
-        kernels.append({"kernel": "xr_obs_kernel", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
-                        "achieved": obs_bytes / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else 0.0})
-    kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
-                    "achieved": route_bytes / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
-                    "note": "distance field LDS-resident: LDS/latency-bound by construction, HBM bytes are the state load only"})
+    if fused:
+        kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": obs_bytes + route_bytes,
+                        "achieved": (obs_bytes + route_bytes) / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
+                        "note": "fused step kernel (xr_batch_step_observe): per env one workgroup routes the net "
+                                "(LDS-resident, latency-bound) and then streams the fp32 observation (HBM-write-bound); "
+                                "bytes = state load + observation"})
+    else:
+        if obs is not None:
+            kernels.append({"kernel": "xr_obs_kernel", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
+                            "achieved": obs_bytes / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else 0.0})
+        kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
+                        "achieved": route_bytes / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
+                        "note": "distance field LDS-resident: LDS/latency-bound by construction, HBM bytes are the state load only"})
     dom = max(kernels, key=lambda k: k["ms"])
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # measured offline with rocprofv3 --pmc (see profiles/README.md)
@@ -216,6 +232,7 @@ def main():
             "config": {"workload": f"BASELINE config {args.config}: {B} ispd18_test1-sized regions (24x40x9, K~U[4,36]) per GPU, "
                                    "full step = random net-order action + XR-Maze v1 route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
+                                   + (" (fused launch)" if fused else "")
                                    + (", RCCL all_gather of per-env results" if world > 1 else ""),
                        "envs_per_gpu": B, "global_envs": B * world, "parallelism": f"env-shard x{world}",
                        "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (args.steps * B * world), 4)},

@@ -158,6 +158,13 @@ int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, voi
  * wirelength/via/violation, updates netSet/done/reward. */
 int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
 
+/* Game.step in ONE launch: xr_batch_step followed, in the same kernel and by the same workgroup, by
+ * xr_batch_observation of every env (baseline/baseline_utils.py:409-423: route, then build_3Dgrid on the new
+ * state).  The observation stream of some workgroups overlaps the routing of others.  out_dev / env_stride as
+ * in xr_batch_observation, for envs [0, n_envs). */
+int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
+                              void* stream);
+
 /* BASELINE config "random net-order policy": actions_dev[e] = a uniformly chosen legal net of env e
  * (1-based; 0 when the env is done), from a counter-based hash of (seed, e, step count). */
 int32_t xr_batch_random_actions(xr_batch* b, int32_t* actions_dev, uint64_t seed, void* stream);

@@ -61,3 +61,48 @@ def test_observation_subrange_and_strides():
         n = (2 + 7 * k) * regions[2 + j].n_nodes
         assert torch.equal(out[j, :n].cpu(), full[2 + j, :n])
         assert (out[j, n:] == -1).all()          # nothing written past the env's own channels
+
+
+def test_step_observe_fused_equals_two_launches():
+    """xr_batch_step_observe == xr_batch_step followed by xr_batch_observation, for every env and step
+    (routing, auto-reset and flagged no-op slots alike)."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(6200 + i, dims=(24, 40, 9), k_range=(1, 6)) for i in range(24)]
+    a = RegionBatch(regions, device="cuda:0", auto_reset=True)
+    b = RegionBatch(regions, device="cuda:0", auto_reset=True)
+    a.reset(); b.reset()
+    acts = torch.empty(len(regions), dtype=torch.int32, device="cuda:0")
+    oa = torch.full((len(regions), a.obs_env_stride), -7.0, device="cuda:0")
+    ob = torch.full((len(regions), a.obs_env_stride), -7.0, device="cuda:0")
+    for it in range(12):
+        a.random_actions(5, acts)
+        if it == 3:
+            acts[0] = 0                       # illegal action: flagged no-op, observation still written
+        a.step(acts, oa)
+        b.step(acts)
+        b.observation(ob)
+        assert torch.equal(a.fetch("nlegal"), b.fetch("nlegal")) and torch.equal(a.fetch("hash"), b.fetch("hash"))
+        k = a.fetch("nlegal").cpu().numpy()
+        for i, r in enumerate(regions):
+            n = (2 + 7 * int(k[i])) * r.n_nodes
+            assert torch.equal(oa[i, :n], ob[i, :n]), (it, i)
+
+
+def test_step_observe_scalar_path_and_odd_dims():
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(6300 + i, dims=(5, 7, 3), k_range=(2, 4)) for i in range(6)]      # N = 105: no float4
+    batch = RegionBatch(regions, device="cuda:0")
+    envs = [orc.OracleEnv(r) for r in regions]
+    batch.reset()
+    obs = batch.alloc_observation()
+    for it in range(4):
+        legal = batch.legal_sets()
+        acts = [min(s) if s else 0 for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"), obs)
+        o = obs.cpu().numpy()
+        for i, env in enumerate(envs):
+            if acts[i]:
+                env.step(acts[i])
+            ro = env.observation()
+            assert np.array_equal(ro.ravel(), o[i, :ro.size])

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxroute_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("XR_LIB", "libxroute_hip.so"))   # XR_LIB: experiment builds
 
 XR_OK = 0
 XR_ERR_INVALID, XR_ERR_NOMEM, XR_ERR_HIP, XR_ERR_STATE, XR_ERR_RANGE, XR_ERR_PARSE = -1, -2, -3, -4, -5, -6
@@ -25,7 +25,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 SYMBOLS = [
     "xr_abi_version", "xr_last_error", "xr_config_default", "xr_device_count",
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
-    "xr_batch_reset", "xr_batch_step", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
+    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 
@@ -79,6 +79,7 @@ def lib():
     L.xr_batch_sizes.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6 + [C.POINTER(C.c_int64)]
     L.xr_batch_reset.argtypes = [vp, vp, C.c_int32, vp]
     L.xr_batch_step.argtypes = [vp, vp, vp]
+    L.xr_batch_step_observe.argtypes = [vp, vp, vp, C.c_int64, vp]
     L.xr_batch_random_actions.argtypes = [vp, vp, C.c_uint64, vp]
     L.xr_batch_observation.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.xr_batch_fetch.argtypes = [vp, C.c_int32, vp, C.c_size_t, vp]

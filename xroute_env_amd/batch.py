@@ -108,13 +108,24 @@ class RegionBatch:
         with torch.cuda.device(self.device):
             _lib.check(self.L.xr_batch_reset(self._h, ptr, int(rotate), _stream_ptr(self.device)))
 
-    def step(self, actions: torch.Tensor):
-        """Game.step for every env: actions int32[B] on the device, 1-based net ids."""
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+        """Game.step for every env: actions int32[B] on the device, 1-based net ids.  With `obs_out`
+        ([n_envs, stride] fp32) the same launch also writes every env's observation of the new state
+        (xr_batch_step_observe)."""
         if actions.device != self.device or actions.dtype != torch.int32 or not actions.is_contiguous() \
                 or actions.numel() != self.n_envs:
             raise ValueError("actions must be a contiguous int32 tensor of n_envs entries on the batch device")
         with torch.cuda.device(self.device):
-            _lib.check(self.L.xr_batch_step(self._h, C.c_void_p(actions.data_ptr()), _stream_ptr(self.device)))
+            if obs_out is None:
+                _lib.check(self.L.xr_batch_step(self._h, C.c_void_p(actions.data_ptr()), _stream_ptr(self.device)))
+            else:
+                if obs_out.device != self.device or obs_out.dtype != torch.float32 or not obs_out.is_contiguous() \
+                        or obs_out.dim() != 2 or obs_out.shape[0] < self.n_envs:
+                    raise ValueError("obs_out must be a contiguous fp32 [n_envs, stride] tensor on the batch device")
+                _lib.check(self.L.xr_batch_step_observe(self._h, C.c_void_p(actions.data_ptr()),
+                                                        C.c_void_p(obs_out.data_ptr()), obs_out.shape[1],
+                                                        _stream_ptr(self.device)))
+        return obs_out
 
     def random_actions(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

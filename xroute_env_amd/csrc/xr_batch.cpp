@@ -300,14 +300,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     // the worklist kernel keeps one bit per line node in a 64-bit register: X, Y <= 64 (Z <= 32 always)
     b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && lines_max < 65536 && x_max <= 64 && y_max <= 64;
     b->route_lds = b->lds_dist ? lds_need : el_bytes;
-    if (b->cfg.block_threads)
-        b->route_threads = b->cfg.block_threads;
-    else
-        // worklist kernel: ~100-300 dirty lines per iteration on ispd18-sized regions, 4 waves keep 4 workgroups
-        // per CU resident (LDS- and VGPR-wise); large-region kernel: one line per thread up to 1024
-        b->route_threads = b->lds_dist ? std::min(256, std::max(128, (tracks_max + 63) & ~63))
-                                       : std::min(1024, std::max(128, (tracks_max + 63) & ~63));
-    if (b->lds_dist && b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
+    // the fused observation epilogue stages the ascending legal-id list in the same LDS
+    const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;
+    b->route_lds = std::max(b->route_lds, ids_bytes);
 
     // ---- device allocations ------------------------------------------------------------------
 #define XR_ALLOC(buf, count)                                                                        \
@@ -384,6 +379,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.phase_cycles = b->phase_cycles.p;
+    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0;
     d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
     d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
     d.w_violation = b->cfg.w_violation; d.w_via = b->cfg.w_via; d.w_wirelength = b->cfg.w_wirelength;
@@ -431,6 +427,22 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
     XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
+                           static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream) {
+    if (!b || !actions_dev || !out_dev) return fail(XR_ERR_INVALID, "xr_batch_step_observe: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step_observe: load regions first");
+    if (env_stride < (int64_t)(2 + 7 * (int64_t)b->k_max) * b->n_max_nodes)
+        return fail(XR_ERR_RANGE, "xr_batch_step_observe: env_stride %lld < (2+7*k_max)*n_max = %lld", (long long)env_stride,
+                    (long long)((2 + 7 * (int64_t)b->k_max) * b->n_max_nodes));
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XrBatchDev d = b->dev;
+    d.obs_out = out_dev;
+    d.obs_stride = env_stride;
+    d.obs_vec4 = (b->all_n_mult4 && (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0)) ? 1 : 0;
+    XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
                            static_cast<hipStream_t>(stream)));
     return XR_OK;
 }

@@ -65,6 +65,10 @@ struct XrBatchDev {
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;
     long long* phase_cycles; // [B][8] thread-0 cycle counts per kernel phase (only written with -DXR_PHASE_TIMING)
+    // fused observation output of the step kernel (null: route only)
+    float* obs_out;
+    int64_t obs_stride;      // floats per env
+    int32_t obs_vec4;        // float4 stores allowed (all N % 4 == 0, aligned planes)
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     double w_violation, w_via, w_wirelength;

@@ -250,8 +250,7 @@ __device__ __forceinline__ void xr_or_run(uint32_t* mask, int id0, unsigned long
 // ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
 // many layers (single exact chunk).
 template <bool LDS_DIST, int ZCH>
-__global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t* __restrict__ actions, char* smem) {
     __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // padded field index of each access point
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
@@ -807,6 +806,12 @@ __device__ __forceinline__ void xr_node_features(const Src& s, int f, int X, int
 }
 
 // VEC = 4: float4 stores (needs N % 4 == 0 and 16-byte aligned planes); VEC = 1: any N.
+#ifndef XR_OBS_PLAIN_STORES      // non-temporal: the observation is written once and read by somebody else
+typedef float xr_f4 __attribute__((ext_vector_type(4)));
+#define XR_ST4(ptr, val) __builtin_nontemporal_store(xr_f4{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<xr_f4*>(ptr))
+#else
+#define XR_ST4(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#endif
 template <class Src, int VEC>
 __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, int N, const int* s_ids, int K,
                                              float* __restrict__ out, int chunk_base) {
@@ -821,13 +826,13 @@ __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, 
     if (VEC == 4) {
         float4 v;
         v.x = obst[0]; v.y = obst[1]; v.z = obst[2]; v.w = obst[3];
-        *reinterpret_cast<float4*>(p) = v;
+        XR_ST4(p, v);
         p += N;
         v.x = (f0 + 0 < K) ? (float)s_ids[f0 + 0] : 0.f;
         v.y = (f0 + 1 < K) ? (float)s_ids[f0 + 1] : 0.f;
         v.z = (f0 + 2 < K) ? (float)s_ids[f0 + 2] : 0.f;
         v.w = (f0 + 3 < K) ? (float)s_ids[f0 + 3] : 0.f;
-        *reinterpret_cast<float4*>(p) = v;
+        XR_ST4(p, v);
         p += N;
         bool anyap = false;
 #pragma unroll
@@ -842,10 +847,10 @@ __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, 
                 ma.x = (adj[0] ? m.x : 0.f); ma.y = (adj[1] ? m.y : 0.f);
                 ma.z = (adj[2] ? m.z : 0.f); ma.w = (adj[3] ? m.w : 0.f);
             }
-            *reinterpret_cast<float4*>(p) = m;
+            XR_ST4(p, m);
             p += N;
 #pragma unroll
-            for (int c = 0; c < 6; c++) { *reinterpret_cast<float4*>(p) = ma; p += N; }
+            for (int c = 0; c < 6; c++) { XR_ST4(p, ma); p += N; }
         }
     } else {
         p[0] = obst[0];
@@ -907,6 +912,34 @@ __global__ void xr_obs_records_kernel(const uint32_t* __restrict__ rec, int X, i
     __syncthreads();
     XrRecSrc src{rec};
     xr_obs_write<XrRecSrc, VEC>(src, X, Y, Z, X * Y * Z, s_ids, K, out, blockIdx.x * blockDim.x * VEC);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The step kernel: route (xr_route_env) and, when the caller asked for it (xr_batch_step_observe), the
+// observation of the new state written by the same workgroup.  Fusing the two lets the HBM-write-bound
+// observation stream of some workgroups overlap the latency-bound routing of others on the same CU.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_DIST, int ZCH>
+__global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    xr_route_env<LDS_DIST, ZCH>(b, actions, smem);
+    if (b.obs_out) {
+        __syncthreads();          // this workgroup's owner / legal / region writes are visible to all its threads
+        const int e = blockIdx.x;
+        const XrRegionDev R = b.regions[b.env_region[e]];
+        int* s_ids = reinterpret_cast<int*>(smem);              // the field is dead: reuse its LDS
+        int* s_pref = s_ids + b.legal_words * 64;
+        const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
+        XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
+        float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
+        if (b.obs_vec4) {
+            for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
+                xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+        } else {
+            for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
+                xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
