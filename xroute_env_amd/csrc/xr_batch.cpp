@@ -105,6 +105,7 @@ struct xr_batch {
     DevBuf<long long> phase_cycles;
     DevBuf<unsigned long long> total_steps;
     DevBuf<uint32_t> dist_scratch;
+    DevBuf<unsigned short> list_scratch;
     XrBatchDev dev{};
 };
 
@@ -181,7 +182,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<uint32_t> hrec;
     std::vector<int32_t> hcoords, hcsr, hap_node;
     std::vector<int16_t> hap_pin;
-    int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0;
+    int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
         const xr_region_desc& d = regs[r];
@@ -265,9 +266,16 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             lines_max = std::max(lines_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x + d.dim_x * d.dim_y);
             bits_max = std::max(bits_max, (d.dim_z - nv) * d.dim_y + nv * d.dim_x + 2 * d.dim_x * d.dim_y);
             z_min = std::min(z_min, d.dim_z); z_max = std::max(z_max, d.dim_z);
+            ncol_max = std::max(ncol_max, d.dim_x * d.dim_y);
         }
     }
     const int legal_words = std::max(1, (k_max + 63) / 64);
+    // the observation kernels stage the ascending legal-id list in LDS (4 bytes per possible net)
+    if ((size_t)legal_words * 64 * 4 + (size_t)(legal_words + 1) * 4 > 60 * 1024)
+        return fail(XR_ERR_RANGE, "k_max %d too large for the observation kernel's LDS id list (max ~15000 nets)", k_max);
+    // the observation kernels stage the ascending legal-id list in LDS (4 bytes per possible net)
+    if ((size_t)legal_words * 64 * 4 + (size_t)(legal_words + 1) * 4 > 60 * 1024)
+        return fail(XR_ERR_RANGE, "k_max %d too large for the observation kernel's LDS id list (max ~15000 nets)", k_max);
     std::vector<uint64_t> hlegal0((size_t)n_regions * legal_words, 0);
     for (int r = 0; r < n_regions; r++) {
         hreg[r].legal0_off = (int64_t)r * legal_words;
@@ -297,12 +305,17 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     const size_t el_bytes = (size_t)(x_max + 2 + y_max + 2) * 4;
     const size_t lds_need = (size_t)b->n_lds * 4 + ((size_t)b->n_lds / 32 + 1) * 4 + el_bytes + 3 * lw_max * 4 +
                             (size_t)lines_max * 2 + 16;
-    // the worklist kernel keeps one bit per line node in a 64-bit register: X, Y <= 64 (Z <= 32 always)
-    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && lines_max < 65536 && x_max <= 64 && y_max <= 64;
-    b->route_lds = b->lds_dist ? lds_need : el_bytes;
+    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit;
+    // worklist entries are 16-bit line ids within their kind: columns X*Y <= 65536, tracks <= 65536
+    if (ncol_max > 65536 || tracks_max > 65536)
+        return fail(XR_ERR_RANGE, "regions with more than 65536 columns or tracks are not supported (got %d / %d)", ncol_max, tracks_max);
+    b->route_lds = b->lds_dist ? lds_need : el_bytes + 3 * lw_max * 4;
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
     const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;
     b->route_lds = std::max(b->route_lds, ids_bytes);
+    if (b->route_lds + kLdsStatic > kLdsLimit)
+        return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
+    if (b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
 
     // ---- device allocations ------------------------------------------------------------------
 #define XR_ALLOC(buf, count)                                                                        \
@@ -341,6 +354,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     if (!b->lds_dist) {
         XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);
+        XR_ALLOC(b->list_scratch, (size_t)B * b->lines_max);
     }
 #undef XR_ALLOC
 
@@ -378,7 +392,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
-    d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.phase_cycles = b->phase_cycles.p;
+    d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0;
     d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
     d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
@@ -504,7 +518,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
 int32_t xr_observation_from_records(const uint32_t* nodes_dev, int32_t X, int32_t Y, int32_t Z, const int32_t* nets_dev,
                                     int32_t k, float* out_dev, void* stream) {
     if (!nodes_dev || !out_dev || (k > 0 && !nets_dev)) return fail(XR_ERR_INVALID, "xr_observation_from_records: null argument");
-    if (X < 1 || Y < 1 || Z < 1 || (int64_t)X * Y * Z > ((int64_t)1 << 30) || k < 0 || k > XR_MAX_NETS)
+    if (X < 1 || Y < 1 || Z < 1 || (int64_t)X * Y * Z > ((int64_t)1 << 30) || k < 0 || k > 15000)
         return fail(XR_ERR_RANGE, "xr_observation_from_records: dims %dx%dx%d / k %d out of range", X, Y, Z, k);
     const int N = X * Y * Z;
     const bool vec4 = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);

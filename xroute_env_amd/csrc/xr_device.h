@@ -64,6 +64,7 @@ struct XrBatchDev {
     int32_t* sweeps;
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;
+    unsigned short* list_scratch;   // [B][lines_max] worklists of the large-region variant
     long long* phase_cycles; // [B][8] thread-0 cycle counts per kernel phase (only written with -DXR_PHASE_TIMING)
     // fused observation output of the step kernel (null: route only)
     float* obs_out;

@@ -166,13 +166,13 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // An unreached or blocked predecessor saturates the add, which can never pass `lim`.  The store is an
 // LDS atomic min of the (possibly unchanged) word: branch-free, and concurrent passes over crossing
 // lines lose no update.  EXACT: L == CH, single chunk, no bounds handling.
-// Returns the set of lowered nodes (bit i); ORs 2 into `flags` when a candidate was refused only
-// because of the bound.
-template <bool FWD, bool PLANAR, int CH, bool EXACT>
-__device__ __forceinline__ unsigned long long xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4,
-                                                            int base, int stride, int L, uint32_t len4c, uint32_t pen4,
-                                                            uint32_t boundw1, int& flags) {
-    unsigned long long lowered = 0;
+// `mark(start, bits)` is called once per chunk with the lowered nodes (bit k <-> node start+k).  Returns 1 when
+// anything was lowered; ORs 2 into `flags` when a candidate was refused only because of the bound.
+template <bool FWD, bool PLANAR, int CH, bool EXACT, class MarkFn>
+__device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4, int base,
+                                            int stride, int L, uint32_t len4c, uint32_t pen4, uint32_t boundw1,
+                                            int& flags, MarkFn mark) {
+    int lowered = 0;
     uint32_t prev = 0xFFFFFFFFu;       // "no predecessor": saturates
     uint32_t pfl = 3u;                 // flag bits of the previous node's word
     uint32_t refused = 0;
@@ -216,13 +216,15 @@ __device__ __forceinline__ unsigned long long xr_line_pass(uint32_t* __restrict_
             prev = wn;
             pfl = fl;
         }
-        if (cm) {
-            if (FWD) lowered |= (unsigned long long)cm << i0;
+        if (cm) {       // report the lowered nodes of this chunk: bit k of `bits` <-> node start + k
+            lowered = 1;
+            if (FWD) mark(i0, cm);
             else {
-                // bit j of cm is node L-1-i0-j: reverse the CH-bit group, then place it
-                const uint32_t r = __brev(cm) >> (32 - CH);          // bit (CH-1-j) <- bit j
-                const int lo = L - CH - i0;                          // node index of bit 0 after reversal
-                lowered |= lo >= 0 ? ((unsigned long long)r << lo) : ((unsigned long long)r >> (-lo));
+                // bit j of cm is node L-1-i0-j: reverse the CH-bit group; bit 0 is then node L-CH-i0 (may be < 0 in
+                // the last partial chunk: those slots are padding and never lowered)
+                const uint32_t r = __brev(cm) >> (32 - CH);
+                const int lo = L - CH - i0;
+                if (lo >= 0) mark(lo, r); else mark(0, r >> (-lo));
             }
         }
         if (more) {
@@ -235,16 +237,13 @@ __device__ __forceinline__ unsigned long long xr_line_pass(uint32_t* __restrict_
     return lowered;
 }
 
-// OR a run of up to 64 consecutive bits (ids id0 + i for every set bit i of `bits`) into a bitmask
-__device__ __forceinline__ void xr_or_run(uint32_t* mask, int id0, unsigned long long bits) {
-    if (!bits) return;
+// OR a run of up to 32 consecutive bits (ids id0 + k for every set bit k of `bits`) into a bitmask
+__device__ __forceinline__ void xr_or_run(uint32_t* mask, int id0, uint32_t bits) {
     const int wdx = id0 >> 5, sh = id0 & 31;
-    const unsigned long long sl = bits << sh;
-    const uint32_t m0 = (uint32_t)sl, m1 = (uint32_t)(sl >> 32);
-    const uint32_t m2 = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+    const uint32_t m0 = bits << sh;
+    const uint32_t m1 = sh ? (bits >> (32 - sh)) : 0u;
     if (m0) atomicOr(&mask[wdx], m0);
     if (m1) atomicOr(&mask[wdx + 1], m1);
-    if (m2) atomicOr(&mask[wdx + 2], m2);
 }
 
 // ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
@@ -309,15 +308,13 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
 
-    // carve: field u32[n_lds] | claim u32[n_lds/32+1] | el4x u32[x_max+2] | el4y u32[y_max+2]
-    //        (LDS variant only:) dirty0, dirty1, deferred u32[lw_max] | lists u16[lines_max]
+    // carve (LDS variant):   field u32[n_lds] | claim u32[n_lds/32+1] | el4x | el4y | dirty0 | dirty1 | deferred
+    //                        u32[lw_max] each | lists u16[lines_max]
+    // (large-region variant): field, claim bitmask and the worklists live in per-env HBM scratch; the edge tables
+    //                        and the three line bitmasks stay in LDS
     uint32_t* field;
     uint32_t* s_claim;
     uint32_t* s_el4x;
-    uint32_t* s_dirty0 = nullptr;
-    uint32_t* s_dirty1 = nullptr;
-    uint32_t* s_defer = nullptr;
-    unsigned short* s_list = nullptr;
     const int claim_words = (NL + 31) >> 5;
     if (LDS_DIST) {
         field = reinterpret_cast<uint32_t*>(smem);
@@ -329,12 +326,11 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
         s_el4x = reinterpret_cast<uint32_t*>(smem);
     }
     uint32_t* s_el4y = s_el4x + (b.x_max + 2);
-    if (LDS_DIST) {
-        s_dirty0 = s_el4y + (b.y_max + 2);
-        s_dirty1 = s_dirty0 + b.lw_max;
-        s_defer = s_dirty1 + b.lw_max;
-        s_list = reinterpret_cast<unsigned short*>(s_defer + b.lw_max);
-    }
+    uint32_t* s_dirty0 = s_el4y + (b.y_max + 2);
+    uint32_t* s_dirty1 = s_dirty0 + b.lw_max;
+    uint32_t* s_defer = s_dirty1 + b.lw_max;
+    unsigned short* s_list = LDS_DIST ? reinterpret_cast<unsigned short*>(s_defer + b.lw_max)
+                                      : b.list_scratch + (int64_t)e * b.lines_max;
     unsigned short* s_listH = s_list;
     unsigned short* s_listV = s_list + tracks_h;
     unsigned short* s_listC = s_list + ntracks;
@@ -379,8 +375,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
         }
     }
     for (int i = tid; i < claim_words; i += nthr) s_claim[i] = 0;
-    if (LDS_DIST)
-        for (int i = tid; i < nlw; i += nthr) { s_dirty0[i] = 0; s_dirty1[i] = 0; s_defer[i] = 0; }
+    for (int i = tid; i < nlw; i += nthr) { s_dirty0[i] = 0; s_dirty1[i] = 0; s_defer[i] = 0; }
     // edge length tables (x4): el4x[i] = 4*(xs[i]-xs[i-1]), 0 at both ends
     for (int i = tid; i <= X; i += nthr)
         s_el4x[i] = (i >= 1 && i < X) ? (uint32_t)(b.coords[R.xs_off + i] - b.coords[R.xs_off + i - 1]) << 2 : 0u;
@@ -427,7 +422,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
             if (s_ap_pin[i] == first) {
                 s_ap_conn[i] = 1;
                 field[s_ap_l[i]] &= 3u;
-                if (LDS_DIST) mark_node(s_dirty0, s_ap_l[i]);
+                mark_node(s_dirty0, s_ap_l[i]);
             }
         }
         s_remaining = npins - 1;
@@ -447,15 +442,14 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
 
     while (s_remaining > 0) {
         // new search: the bound was reset, so lines that refused candidates must be looked at again
-        if (LDS_DIST)
-            for (int i = tid; i < nlw; i += nthr) { const uint32_t m = s_defer[i]; if (m) { atomicOr(&cur[i], m); s_defer[i] = 0; } }
+        for (int i = tid; i < nlw; i += nthr) { const uint32_t m = s_defer[i]; if (m) { atomicOr(&cur[i], m); s_defer[i] = 0; } }
         // ---- relax to the (pruned) fixpoint ----------------------------------------------------
         for (;;) {
             // bound from the targets' current distances
             for (int i = tid; i < nap; i += nthr)
                 if (!s_ap_conn[i]) { const uint32_t w = field[s_ap_l[i]]; if (w < XR_W_UNREACHED) atomicMin(&s_bound, w >> 2); }
             int nH, nV, nC;
-            if (LDS_DIST) {
+            {
                 // fold the y*X+x column bits into the x*Y+y ones (one entry per column in the list)
                 for (int wi = (colB0 >> 5) + tid; wi < nlw; wi += nthr) {
                     uint32_t m = cur[wi];
@@ -506,9 +500,6 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                 nH = s_cnt[parity][0]; nV = s_cnt[parity][1]; nC = s_cnt[parity][2];
                 if (nH + nV + nC == 0) break;              // uniform: nothing left to visit
                 if (tid == 0) { s_cnt[parity ^ 1][0] = 0; s_cnt[parity ^ 1][1] = 0; s_cnt[parity ^ 1][2] = 0; }
-            } else {
-                __syncthreads();
-                nH = tracks_h; nV = tracks_v; nC = ncol;
             }
             XR_LAP(1);
 #ifdef XR_PHASE_TIMING
@@ -517,7 +508,6 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
             // candidates must stay <= min(search bound, XR_DIST_CAP - 1): boundw1 = (that + 1) << 2
             const uint32_t bnd = min(s_bound, (uint32_t)(XR_W_USABLE_END >> 2) - 1u);
             const uint32_t bound4 = (bnd + 1u) << 2;
-            int changed = 0;
             // each kind starts on a wave boundary: no divergence between line kinds inside a wave
             const int offV = (nH + 63) & ~63, offC = offV + ((nV + 63) & ~63);
             const int total = offC + nC;
@@ -526,59 +516,52 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                 int line = -1;                              // canonical line id (for `deferred`)
                 if (k < offV) {
                     if (k < nH) {
-                        const int t = LDS_DIST ? (int)s_listH[k] : k;
+                        const int t = (int)s_listH[k];
                         const int zi = t / Y, y = t - zi * Y;
                         const int base = y * SY + s_hl[zi];
-                        unsigned long long low = xr_line_pass<true, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl);
-                        low |= xr_line_pass<false, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl);
+                        // lowered node x: column (x, y) must be looked at -> a run of bits in the y*X+x block
+                        auto mk = [&](int start, uint32_t bits) { xr_or_run(nxt, colB0 + y * X + start, bits); };
+                        xr_line_pass<true, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<false, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
                         line = t;
-                        changed |= (low != 0);
-                        if (LDS_DIST) xr_or_run(nxt, colB0 + y * X, low);      // columns (x, y) of the lowered x
                     }
                 } else if (k < offC) {
                     if (k - offV < nV) {
-                        const int t = LDS_DIST ? (int)s_listV[k - offV] : (k - offV);
+                        const int t = (int)s_listV[k - offV];
                         const int zi = t / X, x = t - zi * X;
                         const int base = x * SX + s_vl[zi];
-                        unsigned long long low = xr_line_pass<true, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl);
-                        low |= xr_line_pass<false, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl);
+                        auto mk = [&](int start, uint32_t bits) { xr_or_run(nxt, colA0 + x * Y + start, bits); };
+                        xr_line_pass<true, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<false, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl, mk);
                         line = tracks_h + t;
-                        changed |= (low != 0);
-                        if (LDS_DIST) xr_or_run(nxt, colA0 + x * Y, low);      // columns (x, y) of the lowered y
                     }
                 } else {
-                    const int c = LDS_DIST ? (int)s_listC[k - offC] : (k - offC);
+                    const int c = (int)s_listC[k - offC];
                     const int x = c / Y, y = c - x * Y;
-                    unsigned long long low;
-                    if (ZCH > 0) {
-                        low = xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl);
-                        low |= xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl);
-                    } else {
-                        low = xr_line_pass<true, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl);
-                        low |= xr_line_pass<false, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl);
-                    }
-                    line = colA0 + c;
-                    changed |= (low != 0);
-                    if (LDS_DIST)                           // lowered node z: its track must be looked at
-                        while (low) {
-                            const int z = __ffsll((long long)low) - 1; low &= low - 1;
+                    // lowered node z: its track must be looked at
+                    auto mk = [&](int start, uint32_t bits) {
+                        while (bits) {
+                            const int z = start + __ffs((int)bits) - 1; bits &= bits - 1;
                             const int id = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
                             atomicOr(&nxt[id >> 5], 1u << (id & 31));
                         }
+                    };
+                    if (ZCH > 0) {
+                        xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl, mk);
+                    } else {
+                        xr_line_pass<true, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<false, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl, mk);
+                    }
+                    line = colA0 + c;
                 }
-                if (LDS_DIST && (fl & 2)) atomicOr(&s_defer[line >> 5], 1u << (line & 31));
+                if (fl & 2) atomicOr(&s_defer[line >> 5], 1u << (line & 31));
             }
             nsweeps++;
-            if (LDS_DIST) {
-                __syncthreads();
-                uint32_t* t = cur; cur = nxt; nxt = t;
-                parity ^= 1;
-                XR_LAP(2);
-            } else {
-                const int any = __syncthreads_or(changed);
-                XR_LAP(2);
-                if (!any) break;
-            }
+            __syncthreads();        // (workgroup-scope: also orders the HBM-scratch field of the large-region variant)
+            uint32_t* t = cur; cur = nxt; nxt = t;
+            parity ^= 1;
+            XR_LAP(2);
         }
 
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
@@ -686,7 +669,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                     if (s_ap_pin[i] == pin) {
                         s_ap_conn[i] = 1;
                         field[s_ap_l[i]] &= 3u;
-                        if (LDS_DIST) mark_node(cur, s_ap_l[i]);
+                        mark_node(cur, s_ap_l[i]);
                     }
                 for (int wi = tid; wi < claim_words; wi += nthr) {
                     uint32_t m = s_claim[wi];
@@ -696,7 +679,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                             const int l = (wi << 5) + __ffs((int)m) - 1;
                             m &= m - 1;
                             field[l] &= 3u;
-                            if (LDS_DIST) mark_node(cur, l);
+                            mark_node(cur, l);
                         }
                     }
                 }
@@ -961,14 +944,14 @@ hipError_t xr_launch_reset(const XrBatchDev* b, const uint8_t* mask, int rotate,
 }
 
 hipError_t xr_route_set_max_lds(size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_route_kernel<true, 12>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const void* fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, 0>), reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
+                          reinterpret_cast<const void*>(&xr_route_kernel<true, 12>), reinterpret_cast<const void*>(&xr_route_kernel<false, 0>),
+                          reinterpret_cast<const void*>(&xr_route_kernel<false, 9>), reinterpret_cast<const void*>(&xr_route_kernel<false, 12>)};
+    for (int i = 0; i < 6; i++) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // zch: 9 / 12 when every region of the batch has exactly that many layers, else 0
