@@ -11,6 +11,8 @@ What is pinned:
                              scripted fake ZMQ socket
   G4  reward KATs            reference baseline/DQN/train_DQN.py:98-99 (expression evaluated
                              here verbatim on integer triples)
+  G5  agent networks (f1)    reference baseline/baseline_utils.py:231-379, baseline/DQN/DQN.py:27-136,
+                             baseline/PPO/PPO.py:30-122: seeded modules -> state_dict, inputs, outputs
 
 Fixtures are DATA ONLY: inputs and the reference's outputs.  No reference source is copied.
 """
@@ -393,6 +395,64 @@ def gen_g4():
     print(f"G4: {len(out)} triples")
 
 
+
+# ---------------------------------------------------------------------------------------------
+# G5 (row f1): agent networks.  Seeded reference modules -> state_dict + inputs + outputs.
+# ---------------------------------------------------------------------------------------------
+def gen_g5(ref_grid):
+    import torch
+    from xroute_env_amd.regions import generate_region
+    sys.path.insert(0, os.path.join(REF, "baseline", "DQN"))
+    sys.path.insert(0, os.path.join(REF, "baseline", "PPO"))
+    import DQN as ref_dqn          # reference baseline/DQN/DQN.py
+    import PPO as ref_ppo          # reference baseline/PPO/PPO.py
+    out = {}
+    cases = [("a", (24, 40, 9), 3, 71), ("b", (12, 10, 5), 2, 72)]
+    torch.manual_seed(1234)
+    q_net = ref_dqn.RepActor(torch.device("cpu"))
+    torch.manual_seed(4321)
+    ac = ref_ppo.ActorCritic(64, torch.device("cpu"))
+    # make BatchNorm running statistics non-trivial so that eval mode is a real test
+    for m in list(q_net.modules()) + list(ac.modules()):
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+    for name, model in (("dqn", q_net), ("ppo", ac)):
+        for k, v in model.state_dict().items():
+            out[f"{name}_sd_{k}"] = v.detach().numpy().copy()
+    import copy
+    sd0 = {"dqn": copy.deepcopy(q_net.state_dict()), "ppo": copy.deepcopy(ac.state_dict())}
+    agent = ref_dqn.DQN.__new__(ref_dqn.DQN)          # only the methods that evaluate q_net are used
+    agent.q_net = q_net
+    agent.device = torch.device("cpu")
+    for tag, dims, k, seed in cases:
+        reg = generate_region(seed, dims=dims, k_range=(k, k), blockage=(0.05, 0.1))
+        obs = quiet(ref_grid.build_3Dgrid, reg.to_reference_data(), set(), False)[0]
+        out[f"{tag}_obs_i16"] = obs.numpy().astype(np.int16)
+        for mode in ("eval", "train"):
+            # a training-mode forward updates the BatchNorm running statistics: every case starts from the saved state
+            q_net.load_state_dict(sd0["dqn"]); ac.load_state_dict(sd0["ppo"])
+            q_net.train(mode == "train"); ac.train(mode == "train")
+            with torch.no_grad():
+                enc, amap = quiet(agent.representation, obs)
+                pol = quiet(agent.get_policy_from, enc, amap, None, False)[0]          # raw logits (bool_prob=False)
+                out[f"{tag}_{mode}_dqn_state"] = torch.stack(list(enc)).numpy() if not isinstance(enc, torch.Tensor) else enc.numpy()
+                ids = sorted(amap[0].keys())
+                out[f"{tag}_{mode}_dqn_ids"] = np.array(ids, np.int32)
+                out[f"{tag}_{mode}_dqn_netvec"] = torch.stack([amap[0][i] for i in ids]).numpy()
+                d = dict(pol)
+                out[f"{tag}_{mode}_dqn_logits"] = np.array([float(d[i]) for i in ids], np.float32)
+                q_net.load_state_dict(sd0["dqn"])
+                enc2, amap2 = quiet(ac.representation, obs)
+                pol2 = quiet(ac.get_policy_from, enc2, amap2)[0]                       # softmax probabilities
+                d2 = dict(pol2)
+                out[f"{tag}_{mode}_ppo_probs"] = np.array([float(d2[i]) for i in ids], np.float32)
+                out[f"{tag}_{mode}_ppo_value"] = ac.critic(enc2).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_agents.npz"), **out)
+    print(f"G5: {len(cases)} observations x 2 modes x (DQN, PPO)")
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_grid, ref_utils, pb2 = import_reference()
@@ -400,6 +460,7 @@ def main():
     gen_g2(ref_utils, pb2)
     gen_g3(ref_utils, pb2)
     gen_g4()
+    gen_g5(ref_grid)
 
 
 if __name__ == "__main__":
