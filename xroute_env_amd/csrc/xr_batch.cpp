@@ -301,7 +301,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     // route kernel placement: distance field + class grid in LDS when they fit
     // field + claim bitmask + edge-length tables + 3 line bitmasks + worklists (u16 line ids)
-    const size_t lw_max = ((size_t)bits_max + 31) / 32 + 1;
+    const size_t lw_max = ((size_t)lines_max + 31) / 32 + 1;
     const size_t el_bytes = (size_t)(x_max + 2 + y_max + 2) * 4;
     const size_t lds_need = (size_t)b->n_lds * 4 + ((size_t)b->n_lds / 32 + 1) * 4 + el_bytes + 3 * lw_max * 4 +
                             (size_t)lines_max * 2 + 16;

@@ -41,7 +41,7 @@ struct XrBatchDev {
     int32_t n_envs;
     int32_t n_max;           // owner stride per env (elements), multiple of 8
     int32_t n_lds;           // padded distance-field size (words), max over regions, multiple of 8
-    int32_t lw_max;          // words per line bitmask (tracks + 2 x columns), max over regions
+    int32_t lw_max;          // words per line bitmask (tracks + columns), max over regions
     int32_t lines_max;       // tracks + columns, max over regions
     int32_t x_max, y_max;    // largest dims over regions (edge-length tables)
     int32_t legal_words;

@@ -299,11 +299,9 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
     const int tracks_h = nh_layers * Y;            // lines along x, one per (y, horizontal layer)
     const int tracks_v = nv_layers * X;            // lines along y, one per (x, vertical layer)
     const int ntracks = tracks_h + tracks_v;
-    // line bitmask layout: [0,ntracks) tracks | [ntracks, +ncol) columns as x*Y+y (written by y-lines and
-    // sources) | [ntracks+ncol, +ncol) columns as y*X+x (written by x-lines): both kinds of line then
-    // report their lowered nodes as ONE run of consecutive bits
-    const int colA0 = ntracks, colB0 = ntracks + ncol;
-    const int nbits = ntracks + 2 * ncol;
+    // line bitmask layout: [0, ntracks) tracks | [ntracks, ntracks + ncol) columns as x*Y + y
+    const int colA0 = ntracks;
+    const int nbits = ntracks + ncol;
     const int nlw = (nbits + 31) >> 5;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
@@ -450,34 +448,10 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                 if (!s_ap_conn[i]) { const uint32_t w = field[s_ap_l[i]]; if (w < XR_W_UNREACHED) atomicMin(&s_bound, w >> 2); }
             int nH, nV, nC;
             {
-                // fold the y*X+x column bits into the x*Y+y ones (one entry per column in the list)
-                for (int wi = (colB0 >> 5) + tid; wi < nlw; wi += nthr) {
-                    uint32_t m = cur[wi];
-                    if (m) {
-                        cur[wi] = 0;
-                        while (m) {
-                            const int id = (wi << 5) + __ffs((int)m) - 1;
-                            m &= m - 1;
-                            if (id >= colB0) {
-                                const int q = id - colB0, y = q / X, x = q - y * X;
-                                const int ca = colA0 + x * Y + y;
-                                atomicOr(&cur[ca >> 5], 1u << (ca & 31));
-                            } else {
-                                atomicOr(&cur[wi], 1u << (id & 31));    // a colA bit sharing the boundary word
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
                 // compact the dirty bitmask into dense worklists (one list per line kind)
-                const int nlw_a = (colB0 + 31) >> 5;
-                for (int wi = tid; wi < nlw_a; wi += nthr) {
+                for (int wi = tid; wi < nlw; wi += nthr) {
                     uint32_t m = cur[wi];
                     const int id0 = wi << 5;
-                    if (id0 + 32 > colB0) {                 // boundary word: keep colB bits for nobody (already folded)
-                        const int keep = colB0 - id0;
-                        m &= keep >= 32 ? 0xFFFFFFFFu : ((1u << keep) - 1u);
-                    }
                     if (m) {
                         cur[wi] = 0;
                         // per kind: reserve a run in the list with one atomic, then fill it
@@ -519,8 +493,13 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                         const int t = (int)s_listH[k];
                         const int zi = t / Y, y = t - zi * Y;
                         const int base = y * SY + s_hl[zi];
-                        // lowered node x: column (x, y) must be looked at -> a run of bits in the y*X+x block
-                        auto mk = [&](int start, uint32_t bits) { xr_or_run(nxt, colB0 + y * X + start, bits); };
+                        // lowered node x: column (x, y) must be looked at
+                        auto mk = [&](int start, uint32_t bits) {
+                            while (bits) {
+                                const int id = colA0 + (start + __ffs((int)bits) - 1) * Y + y; bits &= bits - 1;
+                                atomicOr(&nxt[id >> 5], 1u << (id & 31));
+                            }
+                        };
                         xr_line_pass<true, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
                         xr_line_pass<false, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
                         line = t;
