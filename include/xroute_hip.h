@@ -89,6 +89,9 @@ typedef struct xr_config {
     int32_t auto_reset;       /* 1: xr_batch_step re-initialises envs that were done (vector env) */
     int32_t path_cap;         /* max recorded path nodes per env-step (0 = min(N, 4096)) */
     int32_t block_threads;    /* route kernel workgroup size, 0 = default */
+    int32_t force_scratch_field; /* 1: keep the distance field in HBM scratch even when it would fit LDS (the
+                                    large-region code path; for tests and A/B measurements) */
+    int32_t reserved0;        /* keeps the doubles 8-byte aligned; must be 0 */
     double  w_violation;      /* 500  */
     double  w_via;            /* 4    */
     double  w_wirelength;     /* 0.5  */

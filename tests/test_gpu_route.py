@@ -169,3 +169,40 @@ def test_region_rotation_policy():
         batch.reset(rotate=True)
         seen.append(int(batch.fetch("region").cpu()[0]))
     assert seen == [0, 0, 0, 1, 1, 1, 2, 2, 2, 0, 0]
+
+
+def _tie_region():
+    """Uniform pitch, no blockage, one net: source pin in the middle of layer 0 (horizontal) and two target pins
+    at exactly the same distance whose order differs between the flat node order (x-major) and a y-major order:
+    the spec's tie rule (lowest FLAT index) decides which pin is connected first."""
+    X, Y, Z = 17, 17, 2
+    n = X * Y * Z
+    ntype = np.full(n, NORMAL); used = np.zeros(n, int); net = -np.ones(n, int); pin = -np.ones(n, int)
+    f = lambda x, y, z: (x * Y + y) * Z + z
+    for (x, y, p) in [(5, 8, 0), (4, 9, 1), (6, 7, 2)]:
+        ntype[f(x, y, 0)] = ACCESS; net[f(x, y, 0)] = 0; pin[f(x, y, 0)] = p
+    return Region((X, Y, Z), np.arange(X, dtype=np.int32) * 400, np.arange(Y, dtype=np.int32) * 400,
+                  (np.arange(Z) & 1).astype(np.uint8), pack_records(ntype, used, net, pin), 1, np.zeros(3, np.int32))
+
+
+@pytest.mark.parametrize("scratch", [False, True])
+def test_equal_distance_targets_tie_goes_to_lowest_flat_index(scratch):
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    reg = _tie_region()
+    ref = orc.OracleEnv(reg).step(1)
+    first_target = int(ref["path"][0])
+    assert first_target == (4 * 17 + 9) * 2          # (x=4, y=9, z=0): lower flat index than (6, 7, 0)
+    batch = RegionBatch([reg], device="cuda:0", force_scratch_field=scratch)
+    batch.reset()
+    batch.step(torch.tensor([1], dtype=torch.int32, device="cuda:0"))
+    plen = int(batch.fetch("path_len").cpu()[0])
+    assert batch.fetch("path").cpu()[0, :plen].tolist() == ref["path"].tolist()
+    assert batch.fetch("delta").cpu()[0].tolist() == ref["delta"].tolist()
+
+
+def test_scratch_field_variant_full_parity_on_ispd_sized_regions():
+    """The large-region code path (field in HBM scratch, layer-major layout) forced on ispd18-sized regions:
+    same bit-exact parity as the LDS-resident path."""
+    regions = [generate_region(5100 + i) for i in range(12)]
+    _run_episode_parity(regions, policy="random", force_scratch_field=True)

@@ -34,7 +34,7 @@ class XrConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_envs", C.c_int32),
                 ("via_cost", C.c_int32), ("drc_cost", C.c_int32), ("drc_unit", C.c_int32),
                 ("max_route_count", C.c_int32), ("auto_reset", C.c_int32), ("path_cap", C.c_int32),
-                ("block_threads", C.c_int32),
+                ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("reserved0", C.c_int32),
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double)]
 
 

@@ -34,7 +34,8 @@ class RegionBatch:
 
     def __init__(self, regions: Sequence[Region], n_envs: Optional[int] = None, device="cuda:0",
                  auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
-                 max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0):
+                 max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
+                 force_scratch_field: bool = False):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -47,6 +48,7 @@ class RegionBatch:
         cfg.auto_reset = int(auto_reset)
         cfg.path_cap = path_cap
         cfg.block_threads = block_threads
+        cfg.force_scratch_field = int(force_scratch_field)
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))

@@ -127,6 +127,8 @@ void xr_config_default(xr_config* c) {
     c->auto_reset = 0;
     c->path_cap = 0;
     c->block_threads = 0;
+    c->force_scratch_field = 0;
+    c->reserved0 = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -305,7 +307,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     const size_t el_bytes = (size_t)(x_max + 2 + y_max + 2) * 4;
     const size_t lds_need = (size_t)b->n_lds * 4 + ((size_t)b->n_lds / 32 + 1) * 4 + el_bytes + 3 * lw_max * 4 +
                             (size_t)lines_max * 2 + 16;
-    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit;
+    b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && !b->cfg.force_scratch_field;
     // worklist entries are 16-bit line ids within their kind: columns X*Y <= 65536, tracks <= 65536
     if (ncol_max > 65536 || tracks_max > 65536)
         return fail(XR_ERR_RANGE, "regions with more than 65536 columns or tracks are not supported (got %d / %d)", ncol_max, tracks_max);

@@ -153,7 +153,7 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 #define XR_W_UNREACHED 0xFFFFFFFDu    // | held << 1
 #define XR_W_BLOCK 0u                 // blockage (and padded register slots)
 
-// One Gauss-Seidel pass along a line of L nodes: l(i) = base + i*stride.
+// One Gauss-Seidel pass along a line of L nodes: node i lives at field[ix(i)].
 // PLANAR: el4[i] = 4 * distance between node i-1 and node i of the line (LDS table);
 // else constant edge length len4c (via chain).
 // CH nodes are staged in registers per chunk and the NEXT chunk's loads are issued before the current
@@ -168,10 +168,10 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // lines lose no update.  EXACT: L == CH, single chunk, no bounds handling.
 // `mark(start, bits)` is called once per chunk with the lowered nodes (bit k <-> node start+k).  Returns 1 when
 // anything was lowered; ORs 2 into `flags` when a candidate was refused only because of the bound.
-template <bool FWD, bool PLANAR, int CH, bool EXACT, class MarkFn>
-__device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4, int base,
-                                            int stride, int L, uint32_t len4c, uint32_t pen4, uint32_t boundw1,
-                                            int& flags, MarkFn mark) {
+template <bool FWD, bool PLANAR, int CH, bool EXACT, class IndexFn, class MarkFn>
+__device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4, IndexFn ix,
+                                            int L, uint32_t len4c, uint32_t pen4, uint32_t boundw1, int& flags,
+                                            MarkFn mark) {
     int lowered = 0;
     uint32_t prev = 0xFFFFFFFFu;       // "no predecessor": saturates
     uint32_t pfl = 3u;                 // flag bits of the previous node's word
@@ -183,7 +183,7 @@ __device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const 
         for (int j = 0; j < CH; j++) {
             const int i = FWD ? (i0 + j) : (L - 1 - i0 - j);
             const bool in = full || (FWD ? (i < L) : (i >= 0));
-            ww[j] = in ? field[base + i * stride] : XR_W_BLOCK;
+            ww[j] = in ? field[ix(i)] : XR_W_BLOCK;
             ee[j] = PLANAR ? (in ? el4[FWD ? i : i + 1] : 0u) : len4c;
         }
     };
@@ -212,7 +212,7 @@ __device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const 
             // ---- side results ----
             refused |= (cand < cwr && !acc && cand < 0xF0000000u) ? 1u : 0u;
             cm |= acc ? (1u << j) : 0u;
-            if (in) atomicMin(&field[base + i * stride], wn);     // `in` is wave-uniform; blocked: min(0, ~0) = 0
+            if (in) atomicMin(&field[ix(i)], wn);     // `in` is wave-uniform; blocked: min(0, ~0) = 0
             prev = wn;
             pfl = fl;
         }
@@ -245,6 +245,38 @@ __device__ __forceinline__ void xr_or_run(uint32_t* mask, int id0, uint32_t bits
     if (m0) atomicOr(&mask[wdx], m0);
     if (m1) atomicOr(&mask[wdx + 1], m1);
 }
+
+// Field layouts.
+//  PACKED_XYZ (used by both kernel variants): l = x*SX + y*SY + z with SY = Z|1, SX = (Y*SY)|1 (odd strides):
+//    lanes of a wave hold consecutive lines, so wave accesses have odd word strides: LDS bank-conflict free.
+//  LAYER_MAJOR (HBM-scratch variant only, compile with -DXR_SCRATCH_LAYER_MAJOR=1):
+//    l = z*X*Y + (layer z vertical ? x*Y + y : y*X + x): every track unit-stride, via columns gather one word per
+//    layer plane.  Measured SLOWER on BASELINE config 5 (256x256x12: 85 vs 67 ms per 64-env launch): the via
+//    columns are more than half of the line visits and become 12 cache lines each.  Kept for A/B runs.
+#ifndef XR_SCRATCH_LAYER_MAJOR
+#define XR_SCRATCH_LAYER_MAJOR 0
+#endif
+template <bool LDS_DIST_>
+struct XrLayout {
+    static constexpr bool LDS_DIST = LDS_DIST_ || !XR_SCRATCH_LAYER_MAJOR;   // true: packed-xyz index math
+    int X, Y, Z, SX, SY, XY;
+    uint32_t ldir;
+    __device__ __forceinline__ XrLayout(int x, int y, int z, uint32_t ld) : X(x), Y(y), Z(z), ldir(ld) {
+        SY = Z | 1; SX = (Y * SY) | 1; XY = X * Y;
+    }
+    __device__ __forceinline__ int size() const { return LDS_DIST ? X * SX : Z * XY; }
+    __device__ __forceinline__ int idx(int x, int y, int z) const {
+        if (LDS_DIST) return x * SX + y * SY + z;
+        return z * XY + (((ldir >> z) & 1u) ? x * Y + y : y * X + x);
+    }
+    __device__ __forceinline__ void decode(int l, int& x, int& y, int& z) const {
+        if (LDS_DIST) { x = l / SX; const int r = l - x * SX; y = r / SY; z = r - y * SY; }
+        else {
+            z = l / XY; const int r = l - z * XY;
+            if ((ldir >> z) & 1u) { x = r / Y; y = r - x * Y; } else { y = r / X; x = r - y * X; }
+        }
+    }
+};
 
 // ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
 // many layers (single exact chunk).
@@ -290,8 +322,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
 
     XR_T0();
     const int X = R.X, Y = R.Y, Z = R.Z, N = R.N;
-    const int SY = Z | 1, SX = (Y * SY) | 1;      // odd strides
-    const int NL = X * SX;                        // padded field size
+    const XrLayout<LDS_DIST> lay(X, Y, Z, R.ldir_mask);
+    const int NL = lay.size();                    // field size in words (padded in the LDS layout)
     const int ncol = X * Y;
     const uint32_t ldir = R.ldir_mask;
     const int nv_layers = __popc(ldir & (Z >= 32 ? 0xFFFFFFFFu : ((1u << Z) - 1u)));
@@ -366,7 +398,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                     uint32_t w;
                     if (nn == -1) w = XR_W_BLOCK;
                     else w = XR_W_UNREACHED | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);   // bit 0: real node
-                    field[x * SX + y * SY + z] = w;
+                    field[lay.idx(x, y, z)] = w;
                 }
                 if (++z == Z) { z = 0; if (++y == Y) { y = 0; ++x; } }
             }
@@ -384,7 +416,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
     for (int i = tid; i < nap; i += nthr) {
         const int f = b.ap_node[R.ap_off + ap_lo + i];
         const int z = f % Z, y = (f / Z) % Y, x = f / (Y * Z);
-        s_ap_l[i] = x * SX + y * SY + z;
+        s_ap_l[i] = lay.idx(x, y, z);
         s_ap_pin[i] = b.ap_pin[R.ap_off + ap_lo + i];
         s_ap_conn[i] = 0;
     }
@@ -401,7 +433,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
 
     // both lines through node l become dirty (used when a node becomes a source)
     auto mark_node = [&](uint32_t* mask, int l) {
-        const int x = l / SX, r = l - x * SX, y = r / SY, z = r - y * SY;
+        int x, y, z;
+        lay.decode(l, x, y, z);
         const int tr = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
         const int cl = colA0 + x * Y + y;
         atomicOr(&mask[tr >> 5], 1u << (tr & 31));
@@ -492,7 +525,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                     if (k < nH) {
                         const int t = (int)s_listH[k];
                         const int zi = t / Y, y = t - zi * Y;
-                        const int base = y * SY + s_hl[zi];
+                        const int base = lay.idx(0, y, s_hl[zi]), stride = lay.LDS_DIST ? lay.SX : 1;
+                        auto ix = [=](int i) { return base + i * stride; };
                         // lowered node x: column (x, y) must be looked at
                         auto mk = [&](int start, uint32_t bits) {
                             while (bits) {
@@ -500,18 +534,19 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                                 atomicOr(&nxt[id >> 5], 1u << (id & 31));
                             }
                         };
-                        xr_line_pass<true, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
-                        xr_line_pass<false, true, XR_CH, false>(field, s_el4x, base, SX, X, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<true, true, XR_CH, false>(field, s_el4x, ix, X, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<false, true, XR_CH, false>(field, s_el4x, ix, X, 0u, pen4, bound4, fl, mk);
                         line = t;
                     }
                 } else if (k < offC) {
                     if (k - offV < nV) {
                         const int t = (int)s_listV[k - offV];
                         const int zi = t / X, x = t - zi * X;
-                        const int base = x * SX + s_vl[zi];
+                        const int base = lay.idx(x, 0, s_vl[zi]), stride = lay.LDS_DIST ? lay.SY : 1;
+                        auto ix = [=](int i) { return base + i * stride; };
                         auto mk = [&](int start, uint32_t bits) { xr_or_run(nxt, colA0 + x * Y + start, bits); };
-                        xr_line_pass<true, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl, mk);
-                        xr_line_pass<false, true, XR_CH, false>(field, s_el4y, base, SY, Y, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<true, true, XR_CH, false>(field, s_el4y, ix, Y, 0u, pen4, bound4, fl, mk);
+                        xr_line_pass<false, true, XR_CH, false>(field, s_el4y, ix, Y, 0u, pen4, bound4, fl, mk);
                         line = tracks_h + t;
                     }
                 } else {
@@ -525,12 +560,16 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                             atomicOr(&nxt[id >> 5], 1u << (id & 31));
                         }
                     };
+                    // via chain: unit stride in the LDS layout; one word per layer plane in the layer-major layout
+                    const bool packed = lay.LDS_DIST;
+                    const int cbase = packed ? lay.idx(x, y, 0) : 0, offh = y * X + x, offv = x * Y + y, xy = lay.XY;
+                    auto ix = [=](int z) { return packed ? cbase + z : z * xy + (((ldir >> z) & 1u) ? offv : offh); };
                     if (ZCH > 0) {
-                        xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl, mk);
-                        xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, x * SX + y * SY, 1, ZCH, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, ix, ZCH, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, ix, ZCH, via4, pen4, bound4, fl, mk);
                     } else {
-                        xr_line_pass<true, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl, mk);
-                        xr_line_pass<false, false, XR_CH, false>(field, nullptr, x * SX + y * SY, 1, Z, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<true, false, XR_CH, false>(field, nullptr, ix, Z, via4, pen4, bound4, fl, mk);
+                        xr_line_pass<false, false, XR_CH, false>(field, nullptr, ix, Z, via4, pen4, bound4, fl, mk);
                     }
                     line = colA0 + c;
                 }
@@ -550,8 +589,11 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                 if (s_ap_conn[i]) continue;
                 const uint32_t w = field[s_ap_l[i]];
                 if (w >= XR_W_UNREACHED) continue;
-                // (distance, padded index): padded index order == flat index order
-                const unsigned long long key = ((unsigned long long)(w >> 2) << 32) | (unsigned)s_ap_l[i];
+                // (distance, flat node index): ties go to the lowest FLAT index f = (x*Y+y)*Z+z, whatever the
+                // field layout is
+                int ax, ay, az;
+                lay.decode(s_ap_l[i], ax, ay, az);
+                const unsigned long long key = ((unsigned long long)(w >> 2) << 32) | (unsigned)((ax * Y + ay) * Z + az);
                 best = key < best ? key : best;
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -560,7 +602,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
             }
             int best_i = -1;
             if (best != ~0ULL) {                  // AP slot holding that node (node ids are unique per net)
-                const int best_l = (int)(best & 0xFFFFFFFFu);
+                const int bf = (int)(best & 0xFFFFFFFFu);
+                const int best_l = lay.idx(bf / (Y * Z), (bf / Z) % Y, bf % Z);
                 for (int i0 = 0; i0 < nap && best_i < 0; i0 += 64) {
                     const int i = i0 + tid;
                     const unsigned long long m = __ballot(i < nap && s_ap_l[i] == best_l);
@@ -583,18 +626,19 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                 int v = s_ap_l[best_i];
                 uint32_t vw = field[v];
                 while ((vw >> 2) > 0) {
-                    const int x = v / SX, r = v - x * SX, y = r / SY, z = r - y * SY;
+                    int x, y, z;
+                    lay.decode(v, x, y, z);
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);   // pred distance + edge, x4
                     const bool vert = (ldir >> z) & 1u;
                     int u = -1;
                     uint32_t len4 = 0;
                     switch (tid) {
-                    case 0: if (!vert && x + 1 < X) { u = v + SX; len4 = s_el4x[x + 1]; } break;   // E
-                    case 1: if (vert && y > 0)      { u = v - SY; len4 = s_el4y[y]; } break;       // S
-                    case 2: if (!vert && x > 0)     { u = v - SX; len4 = s_el4x[x]; } break;       // W
-                    case 3: if (vert && y + 1 < Y)  { u = v + SY; len4 = s_el4y[y + 1]; } break;   // N
-                    case 4: if (z + 1 < Z)          { u = v + 1; len4 = via4; } break;             // U
-                    case 5: if (z > 0)              { u = v - 1; len4 = via4; } break;             // D
+                    case 0: if (!vert && x + 1 < X) { u = lay.idx(x + 1, y, z); len4 = s_el4x[x + 1]; } break;   // E
+                    case 1: if (vert && y > 0)      { u = lay.idx(x, y - 1, z); len4 = s_el4y[y]; } break;       // S
+                    case 2: if (!vert && x > 0)     { u = lay.idx(x - 1, y, z); len4 = s_el4x[x]; } break;       // W
+                    case 3: if (vert && y + 1 < Y)  { u = lay.idx(x, y + 1, z); len4 = s_el4y[y + 1]; } break;   // N
+                    case 4: if (z + 1 < Z)          { u = lay.idx(x, y, z + 1); len4 = via4; } break;           // U
+                    case 5: if (z > 0)              { u = lay.idx(x, y, z - 1); len4 = via4; } break;           // D
                     default: break;
                     }
                     uint32_t uw = XR_W_BLOCK;
@@ -624,7 +668,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
                     s_remaining = 0;              // never taken on a consistent field; avoids spinning
                 } else if (tid == 0) {
                     // terminal node of the component: claimed (and recorded) only if nobody holds it yet
-                    const int x = v / SX, r = v - x * SX, y = r / SY, z = r - y * SY;
+                    int x, y, z;
+                    lay.decode(v, x, y, z);
                     const int f = (x * Y + y) * Z + z;
                     if (owner[f] == 0) {
                         owner[f] = (int16_t)a;
