@@ -16,10 +16,10 @@ _LAZY = {
     "handle_messange": ("proto", "handle_messange"),
     "RegionBatch": ("batch", "RegionBatch"),
     "XRouteVectorEnv": ("envs.vector_env", "XRouteVectorEnv"),
-    "OrderingTrainingEnv": ("envs.ordering_training_env", "OrderingTrainingEnv"),
-    "OrderingEvaluationEnv": ("envs.ordering_evaluation_env", "OrderingEvaluationEnv"),
-    "StaticRegionEnv": ("envs.static_region_env", "StaticRegionEnv"),
-    "XRouteEnv": ("envs.core", "XRouteEnv"),
+    "OrderingTrainingEnv": ("envs.facade", "OrderingTrainingEnv"),
+    "OrderingEvaluationEnv": ("envs.facade", "OrderingEvaluationEnv"),
+    "StaticRegionEnv": ("envs.facade", "StaticRegionEnv"),
+    "XRouteEnv": ("envs.facade", "XRouteEnv"),
     "Region": ("regions", "Region"),
     "generate_region": ("regions", "generate_region"),
     "config_regions": ("regions", "config_regions"),

@@ -1,4 +1,5 @@
-"""Gym-style single-env façade.
+"""Gym-style single-env façade: XRouteEnv and the three named envs the reference reserves
+(OrderingTrainingEnv, OrderingEvaluationEnv, StaticRegionEnv).
 
 The reference reserves the names only: `XRouteEnv.step` is `pass` and the three env classes are
 empty (reference xroute_env/envs/core.py:3-8, ordering_training_env.py:4-5, ...), so the behaviour
@@ -79,3 +80,26 @@ class XRouteEnv(EnvBase):
         obs, done, dv, dw, dvia = self.game.step(int(action))
         info = {"legal_actions": sorted(self.game.legal_action_set), "violation": dv, "wirelength": dw, "via": dvia}
         return self._fmt(obs), reward_from_deltas(dv, dw, dvia), bool(done), False, info
+
+
+class OrderingTrainingEnv(XRouteEnv):
+    """`xroute_env/ordering-training-v0` (reference xroute_env/__init__.py:3-6): net-ordering training
+    on rotating regions — Game semantics, 10 replays per region then the next."""
+
+
+class OrderingEvaluationEnv(XRouteEnv):
+    """Evaluation flavour (reference xroute_env/envs/ordering_evaluation_env.py:4-5 is an empty class;
+    the reference's evaluation servers build observations in inference mode,
+    baseline/DQN/test_DQN.py:62): every region is played once, in order, no replays."""
+
+    def __init__(self, regions, **kw):
+        kw.setdefault("max_route_count", 1)
+        super().__init__(regions, **kw)
+
+
+class StaticRegionEnv(XRouteEnv):
+    """One fixed region replayed forever (reference xroute_env/__init__.py:13-33 sketches
+    `static-{benchmark}-v0` registrations with a `region` kwarg; the class itself is empty)."""
+
+    def __init__(self, region, **kw):
+        super().__init__([region], **kw)
