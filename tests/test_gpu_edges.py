@@ -1,0 +1,136 @@
+"""Edge cases of the domain on the GPU path: mixed region shapes in one batch, hundreds of nets (multi-word legal
+bitmask), maximum layer count, path truncation, load-time limits and argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from xroute_env_amd.regions import ACCESS, NORMAL, Region, generate_region, pack_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _episode_vs_oracle(regions, steps=400, **kw):
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    batch = RegionBatch(regions, device="cuda:0", **kw)
+    envs = [orc.OracleEnv(r) for r in regions]
+    batch.reset()
+    obs = batch.alloc_observation()
+    rng = np.random.default_rng(3)
+    for _ in range(steps):
+        legal = batch.legal_sets()
+        if not any(legal):
+            break
+        acts = [int(rng.choice(sorted(s))) if s else 0 for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"), obs)
+        delta = batch.fetch("delta").cpu().numpy()
+        plen = batch.fetch("path_len").cpu().numpy()
+        path = batch.fetch("path").cpu().numpy()
+        status = batch.fetch("status").cpu().numpy()
+        o = obs.cpu().numpy()
+        for i, env in enumerate(envs):
+            if not acts[i]:
+                continue
+            ref = env.step(acts[i], path_cap=batch.path_cap)
+            assert delta[i].tolist() == ref["delta"].tolist() and status[i] == ref["status"]
+            assert plen[i] == ref["path_len"] and path[i, :min(plen[i], batch.path_cap)].tolist() == ref["path"].tolist()
+            ro = env.observation()
+            assert np.array_equal(ro.ravel(), o[i, :ro.size])
+    assert [int(h) for h in batch.fetch("hash").cpu().numpy().view(np.uint64)] == [e.hash() for e in envs]
+    return batch
+
+
+def test_mixed_region_shapes_in_one_batch():
+    """Different (X, Y, Z) per region in the same batch: per-region strides, generic column pass, scalar and
+    float4 observation paths side by side."""
+    dims = [(24, 40, 9), (5, 7, 3), (12, 12, 12), (9, 4, 2), (1, 6, 1), (16, 16, 5)]
+    regions = [generate_region(9700 + i, dims=d, k_range=(1, 6), net_span=5) for i, d in enumerate(dims)]
+    _episode_vs_oracle(regions)
+
+
+def test_hundreds_of_nets_multiword_legal_mask():
+    reg = generate_region(9710, dims=(40, 40, 4), k_range=(200, 200), pins=(2, 2), aps=(1, 2), net_span=6,
+                          blockage=(0.02, 0.04), prerouted=(0.0, 0.01))
+    assert reg.n_nets > 128                       # > 2 words of the 64-bit legal bitmask
+    b = _episode_vs_oracle([reg, reg], steps=40)
+    assert b.legal_words >= 3
+
+
+def test_maximum_layer_count_and_single_row_regions():
+    regions = [generate_region(9720, dims=(6, 6, 32), k_range=(3, 3), net_span=3),
+               generate_region(9721, dims=(1, 30, 2), k_range=(2, 2), net_span=10),
+               generate_region(9722, dims=(30, 1, 2), k_range=(2, 2), net_span=10)]
+    _episode_vs_oracle(regions)
+
+
+def test_path_truncation_flag_and_exact_metrics():
+    reg = generate_region(9730, dims=(24, 40, 9), k_range=(6, 6))
+    b = _episode_vs_oracle([reg], path_cap=3)          # recorded path truncated, metrics and hash still exact
+    assert b.path_cap == 3
+
+
+def _desc(L, reg):
+    from xroute_env_amd import _lib
+    d = _lib.XrRegionDesc()
+    keep = [np.ascontiguousarray(reg.xs, np.int32), np.ascontiguousarray(reg.ys, np.int32),
+            np.ascontiguousarray(reg.layer_dir, np.uint8), np.ascontiguousarray(reg.nodes, np.uint32)]
+    d.dim_x, d.dim_y, d.dim_z = reg.dims
+    d.xs_host, d.ys_host, d.layer_dir_host, d.nodes_host = (k.ctypes.data for k in keep)
+    d.n_nets = reg.n_nets
+    return d, keep
+
+
+def test_load_time_limits_are_errors_not_crashes():
+    from xroute_env_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.default_config()
+    h = C.c_void_p()
+    assert L.xr_batch_create(C.byref(cfg), C.byref(h)) == 0
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    good = generate_region(9740, dims=(6, 6, 2), k_range=(2, 2))
+
+    def load(reg):
+        d, keep = _desc(L, reg)
+        arr = (_lib.XrRegionDesc * 1)(d)
+        return L.xr_batch_load_regions(h, arr, 1, stream)
+
+    # a net with more access points than the kernel stages
+    n = 20 * 20 * 2
+    ntype = np.full(n, NORMAL); used = np.zeros(n, int); net = -np.ones(n, int); pin = -np.ones(n, int)
+    ntype[:200] = ACCESS; net[:200] = 0; pin[:200] = np.arange(200) % 3
+    many = Region((20, 20, 2), np.arange(20, dtype=np.int32) * 400, np.arange(20, dtype=np.int32) * 380,
+                  np.array([0, 1], np.uint8), pack_records(ntype, used, net, pin), 1)
+    assert load(many) == _lib.XR_ERR_RANGE and b"access points" in L.xr_last_error()
+    # ACCESS node naming a net id beyond n_nets
+    bad = Region(good.dims, good.xs, good.ys, good.layer_dir, good.nodes, 1)
+    assert load(bad) == _lib.XR_ERR_RANGE
+    # coordinates not strictly increasing
+    flat = Region(good.dims, np.zeros(6, np.int32), good.ys, good.layer_dir, good.nodes, good.n_nets)
+    assert load(flat) == _lib.XR_ERR_INVALID and b"strictly increasing" in L.xr_last_error()
+    # too many layers
+    tall = Region((2, 2, 33), np.arange(2, dtype=np.int32), np.arange(2, dtype=np.int32), np.zeros(33, np.uint8),
+                  np.full(2 * 2 * 33, 1, np.uint32), 0)
+    assert load(tall) == _lib.XR_ERR_RANGE
+    # calls before a successful load
+    acts = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    assert L.xr_batch_step(h, C.c_void_p(acts.data_ptr()), stream) == _lib.XR_ERR_STATE
+    assert load(good) == 0
+    assert L.xr_batch_fetch(h, 99, C.c_void_p(acts.data_ptr()), 4, stream) == _lib.XR_ERR_INVALID
+    assert L.xr_batch_fetch(h, _lib.XR_FETCH_CUM, C.c_void_p(acts.data_ptr()), 4, stream) == _lib.XR_ERR_RANGE
+    L.xr_batch_destroy(h)
+
+
+def test_config_limits():
+    from xroute_env_amd import _lib
+    L = _lib.lib()
+    for field, val in (("n_envs", 0), ("via_cost", 0), ("via_cost", 1 << 23), ("block_threads", 100), ("max_route_count", 0)):
+        cfg = _lib.default_config()
+        setattr(cfg, field, val)
+        h = C.c_void_p()
+        assert L.xr_batch_create(C.byref(cfg), C.byref(h)) < 0, field
+    cfg = _lib.default_config()
+    cfg.device = 99
+    h = C.c_void_p()
+    assert L.xr_batch_create(C.byref(cfg), C.byref(h)) == _lib.XR_ERR_HIP
