@@ -114,15 +114,14 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // preferred-direction row of one layer: x-lines on horizontal layers, y-lines on vertical layers) or
 // a column (the via chain of one (x,y)).  One thread takes one line and runs a forward and a backward
 // Gauss-Seidel pass over it, staged through registers 8 nodes at a time; after the two passes the
-// line is internally exact, so a distance travels any straight run in ONE visit.  Track coordinates
-// come through the scalar cache (uniform pointer + uniform index -> s_load), not LDS.
+// line is internally exact, so a distance travels any straight run in ONE visit.  Edge lengths come
+// from two small LDS tables (4*(xs[i]-xs[i-1]), same for ys): a wave's lanes read one address.
 //
-// Which lines to visit (LDS-resident variant): a dirty-line worklist.  A node lowered by a line
-// pass marks the one other line through that node dirty (atomic OR into an LDS bitmask); every
-// iteration compacts the dirty bitmask into dense worklists (so waves are full) and processes them.
-// A search starts with only the lines through its source nodes dirty, so work follows the wavefront
-// instead of sweeping the whole region.  The large-region variant (field in HBM scratch) sweeps all
-// lines each iteration.
+// Which lines to visit: a dirty-line worklist.  A node lowered by a line pass marks the one other line
+// through that node dirty (atomic OR into an LDS bitmask); every iteration compacts the dirty bitmask
+// into dense per-kind worklists (kinds start on wave boundaries, so waves are full and uniform) and
+// processes them.  A search starts with only the lines through its source nodes dirty, so work follows
+// the wavefront instead of sweeping the whole region.
 //
 // Pruning: nothing above `bound` (= best distance of any unconnected target so far) is written; every
 // node with true distance <= the final target distance still gets its exact value (induction along
@@ -132,12 +131,14 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // once the new path nodes are set to 0, so relaxation continues instead of restarting.
 //
 // Field word (one u32 per node, nothing else per node):
-//     w = (distance << 2) | (held << 1) | blocked
-//     held = node is held by another net (drc penalty + violation);  blocked nodes have w = 1
-//     0xFFFFFFFC | (held << 1) = unreached.   A node with distance >= XR_DIST_CAP (0x30000000) is
-//     never expanded (spec, mirrored by the oracle), which also makes u32 wrap-around impossible.
-// Field index l = x*SX + y*SY + z with SY = Z|1, SX = (Y*SY)|1 (odd strides): lanes of a wave hold
-// consecutive lines, so wave accesses have odd word strides: bank-conflict free.
+//     w = (distance << 2) | (held << 1) | 1          for every real node; a blockage is w = 0
+//     held = node is held by another net (drc penalty + violation)
+//     0xFFFFFFFD | (held << 1) = unreached.  Distances >= XR_DIST_CAP (0x30000000) do not exist (spec,
+//     mirrored by the oracle): candidates are capped there, which makes u32 wrap-around impossible.
+//
+// Two placements of the same code (template LDS_DIST): field + claim bitmask + worklists in LDS (regions up to
+// ~38 k field words: 39.3 KB per workgroup at 24x40x9, 4 workgroups per CU), or in per-env HBM scratch with only
+// the line bitmasks and edge tables in LDS (larger regions; correct, not tuned).
 // ------------------------------------------------------------------------------------------------
 #ifdef XR_PHASE_TIMING
 #define XR_T0() long long _t = (threadIdx.x == 0) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
