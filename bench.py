@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--region-pack", default=None,
+                    help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
+                         "synthetic generator; NOT the headline workload")
     ap.add_argument("--no-observation", action="store_true", help="skip xr_batch_observation (NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true",
@@ -113,7 +116,11 @@ def main():
     from xroute_env_amd.regions import config_regions
 
     B = args.envs
-    regions = config_regions(args.config, B, first_env=rank * B)
+    if args.region_pack:
+        from xroute_env_amd.lefdef import load_region_pack
+        regions = load_region_pack(args.region_pack)
+    else:
+        regions = config_regions(args.config, B, first_env=rank * B)
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
@@ -126,7 +133,7 @@ def main():
     done = torch.empty(B, dtype=torch.uint8, device=dev)
     nsteps_total = args.warmup + args.steps
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
-    n_nodes = torch.tensor([r.n_nodes for r in regions], dtype=torch.float64, device=dev)
+    n_nodes = torch.tensor([regions[e % len(regions)].n_nodes for e in range(B)], dtype=torch.float64, device=dev)
 
     fused = (obs is not None) and not args.no_fuse
 
@@ -229,7 +236,10 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 distances / i16 state / fp32 observation",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: {B} ispd18_test1-sized regions (24x40x9, K~U[4,36]) per GPU, "
+            "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)}, "
+                                    if args.region_pack else
+                                    f"BASELINE config {args.config}: {B} ispd18_test1-sized regions (24x40x9, K~U[4,36]) per GPU, ")
+                                   +
                                    "full step = random net-order action + XR-Maze v1 route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
                                    + (" (fused launch)" if fused else "")

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Extract per-GCell regions from a LEF/DEF/guide triple (xroute_env_amd/lefdef.py) into a compact region pack.
+
+    python tools/extract_regions.py --out tests/golden/ispd18_test1_regions.npz --count 256 --stride 17
+
+Default inputs are the reference's ispd18_test1 files (build container only).  The pack is DATA derived from the
+reference's benchmark input files (tracks, placed pin / obstruction shapes, guides), not source."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xroute_env_amd import lefdef
+
+REF = "/root/reference/ispd/ispd18_test1/ispd18_test1.input"
+ap = argparse.ArgumentParser()
+ap.add_argument("--lef", default=REF + ".lef")
+ap.add_argument("--def", dest="deff", default=REF + ".def")
+ap.add_argument("--guide", default=REF + ".guide")
+ap.add_argument("--out", required=True)
+ap.add_argument("--count", type=int, default=256)
+ap.add_argument("--stride", type=int, default=17, help="keep every stride-th non-empty region (spreads over the die)")
+ap.add_argument("--min-nets", type=int, default=2)
+args = ap.parse_args()
+t0 = time.time()
+design = lefdef.load_design(args.lef, args.deff, args.guide)
+ex = lefdef.RegionExtractor(design)
+regs = ex.gcell_regions(min_nets=args.min_nets)
+keep = regs[::args.stride][:args.count]
+lefdef.save_region_pack(args.out, keep)
+print(f"{len(regs)} regions with >= {args.min_nets} nets on the die, kept {len(keep)} -> {args.out} "
+      f"({os.path.getsize(args.out) / 1024:.0f} KiB) in {time.time() - t0:.0f}s; "
+      f"mean K {sum(r.n_nets for r in keep) / len(keep):.1f}, dims of the first: {keep[0].dims}")

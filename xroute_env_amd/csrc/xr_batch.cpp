@@ -86,6 +86,7 @@ struct xr_batch {
     int x_max = 0, y_max = 0;
     bool all_n_mult4 = true;
     bool lds_dist = true;
+    bool stream_ok = false;   // ids + 2 bytes/node of the largest region fit the LDS of the observation stream form
     size_t route_lds = 0;
     int route_threads = 256;
     // regions
@@ -314,7 +315,10 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->route_lds = b->lds_dist ? lds_need : el_bytes + 3 * lw_max * 4;
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
     const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;
-    b->route_lds = std::max(b->route_lds, ids_bytes);
+    // flat-stream observation (any N): ids + a 16-bit feature per node in LDS
+    const size_t stream_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4 + (size_t)b->n_max * 2;
+    b->stream_ok = stream_bytes <= 60 * 1024;
+    b->route_lds = std::max(b->route_lds, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
     if (b->route_lds + kLdsStatic > kLdsLimit)
         return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
     if (b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
@@ -426,7 +430,7 @@ int32_t xr_batch_sizes(const xr_batch* b, int32_t* n_envs, int32_t* n_regions, i
     if (k_max) *k_max = b->k_max;
     if (legal_words) *legal_words = b->legal_words;
     if (path_cap) *path_cap = b->path_cap;
-    if (obs_env_stride) *obs_env_stride = (int64_t)(2 + 7 * (int64_t)b->k_max) * (int64_t)b->n_max;
+    if (obs_env_stride) *obs_env_stride = ((int64_t)(2 + 7 * (int64_t)b->k_max) * (int64_t)b->n_max + 3) & ~(int64_t)3;
     return XR_OK;
 }
 
@@ -457,7 +461,9 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     XrBatchDev d = b->dev;
     d.obs_out = out_dev;
     d.obs_stride = env_stride;
-    d.obs_vec4 = (b->all_n_mult4 && (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0)) ? 1 : 0;
+    // 1: aligned float4 (every N % 4 == 0), 2: shifted float4 (any N), 0: scalar (unaligned caller buffer)
+    const bool aligned = (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
                            static_cast<hipStream_t>(stream)));
     return XR_OK;
@@ -480,8 +486,9 @@ int32_t xr_batch_observation(xr_batch* b, float* out_dev, int64_t env_stride, in
     if (env_stride < (int64_t)2 * b->n_max_nodes)
         return fail(XR_ERR_RANGE, "xr_batch_observation: env_stride %lld too small", (long long)env_stride);
     XR_HIP(hipSetDevice(b->cfg.device));
-    const bool vec4 = b->all_n_mult4 && (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
-    XR_HIP(xr_launch_obs(&b->dev, out_dev, env_stride, env_lo, env_hi, b->n_max_nodes, vec4 ? 1 : 0,
+    const bool aligned = (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    const int vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
+    XR_HIP(xr_launch_obs(&b->dev, out_dev, env_stride, env_lo, env_hi, b->n_max_nodes, vec4,
                          static_cast<hipStream_t>(stream)));
     return XR_OK;
 }

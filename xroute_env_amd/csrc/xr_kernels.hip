@@ -876,6 +876,65 @@ __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, 
     }
 }
 
+// float4 stores for ANY N (design-derived regions rarely have N % 4 == 0): the env's (2+7K)*N floats are ONE
+// contiguous run starting at a 16-byte aligned address, so it is written as a flat stream of aligned float4
+// slots, whatever N is.  The workgroup first reduces every node to a 16-bit feature in LDS
+//     AP net id (14 bits) | has-same-net-axis-neighbour << 14 | obstacle << 15
+// and then every thread walks slots tid, tid+T, ...; the (plane, node) of a slot advances incrementally and a
+// slot that straddles two planes is resolved float by float.
+__device__ __forceinline__ float xr_plane_value(unsigned ft, int plane, int node, const int* s_ids, int K) {
+    if (plane >= 2) {
+        const int pi = plane - 2, i = pi / 7, c = pi - 7 * i;
+        const unsigned id = (unsigned)s_ids[i];
+        return c ? (((ft & 0x7FFFu) == (id | 0x4000u)) ? 1.f : 0.f) : (((ft & 0x3FFFu) == id) ? 1.f : 0.f);
+    }
+    if (plane == 0) return (ft & 0x8000u) ? 1.f : 0.f;
+    return node < K ? (float)s_ids[node] : 0.f;
+}
+
+template <class Src>
+__device__ __forceinline__ void xr_obs_env_stream(const Src& src, int X, int Y, int Z, int N, const int* s_ids, int K,
+                                                  float* __restrict__ out, unsigned short* s_feat) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int f = tid; f < N; f += nthr) {
+        float obst; int apnet; bool adj;
+        xr_node_features(src, f, X, Y, Z, N, obst, apnet, adj);
+        s_feat[f] = (unsigned short)(apnet | (adj ? 0x4000 : 0) | (obst != 0.f ? 0x8000 : 0));
+    }
+    __syncthreads();
+    const long long total = (long long)(2 + 7 * K) * N;          // floats
+    const long long nslot = total >> 2;
+    int plane = (int)((4LL * tid) / N), node = (int)((4LL * tid) - (long long)plane * N);
+    const int dplane = (4 * nthr) / N, dnode = (4 * nthr) - dplane * N;
+    for (long long sidx = tid; sidx < nslot; sidx += nthr) {
+        float v[4];
+        if (node + 3 < N && plane >= 2) {            // common case: four nodes of one net plane
+            const int pi = plane - 2, i = pi / 7, c = pi - 7 * i;
+            const unsigned id = (unsigned)s_ids[i];
+            const unsigned msk = c ? 0x7FFFu : 0x3FFFu, want = c ? (id | 0x4000u) : id;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = ((s_feat[node + j] & msk) == want) ? 1.f : 0.f;
+        } else {
+            int p = plane, f = node;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v[j] = xr_plane_value(s_feat[f], p, f, s_ids, K);
+                if (++f == N) { f = 0; ++p; }
+            }
+        }
+        XR_ST4(out + 4 * sidx, make_float4(v[0], v[1], v[2], v[3]));
+        plane += dplane; node += dnode;
+        if (node >= N) { node -= N; ++plane; }
+    }
+    // the last total % 4 floats
+    const int tail = (int)(total & 3);
+    if (tid < tail) {
+        const long long g = (nslot << 2) + tid;
+        const int p = (int)(g / N), f = (int)(g - (long long)p * N);
+        out[g] = xr_plane_value(s_feat[f], p, f, s_ids, K);
+    }
+}
+
 // legal bitmask -> ascending id list in LDS (== sorted(list(netSet)), build_3Dgrid.py:177)
 __device__ __forceinline__ int xr_legal_ids(const uint64_t* __restrict__ lw, int words, int* s_ids, int* s_pref) {
     const int tid = threadIdx.x;
@@ -911,6 +970,19 @@ __global__ void xr_obs_kernel(XrBatchDev b, float* __restrict__ out, int64_t env
                                   chunk_base);
 }
 
+// stand-alone observation as a flat float4 stream, one workgroup per env (any N; env_stride % 4 == 0, aligned base)
+__global__ void xr_obs_stream_kernel(XrBatchDev b, float* __restrict__ out, int64_t env_stride, int env_lo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_ids = reinterpret_cast<int*>(smem);
+    int* s_pref = s_ids + b.legal_words * 64;
+    unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
+    const int e = env_lo + blockIdx.x;
+    const XrRegionDev R = b.regions[b.env_region[e]];
+    const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
+    XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
+    xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out + (int64_t)blockIdx.x * env_stride, s_feat);
+}
+
 template <int VEC>
 __global__ void xr_obs_records_kernel(const uint32_t* __restrict__ rec, int X, int Y, int Z,
                                       const int32_t* __restrict__ nets, int K, float* __restrict__ out) {
@@ -940,9 +1012,12 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
         XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
         float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
-        if (b.obs_vec4) {
+        if (b.obs_vec4 == 1) {
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
                 xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+        } else if (b.obs_vec4 == 2) {
+            unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
+            xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat);
         } else {
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
                 xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
@@ -1009,9 +1084,12 @@ hipError_t xr_launch_obs(const XrBatchDev* b, float* out, int64_t env_stride, in
     for (int lo = env_lo; lo < env_hi; lo += 32768) {
         const int cnt = (env_hi - lo) < 32768 ? (env_hi - lo) : 32768;
         float* o = out + (int64_t)(lo - env_lo) * env_stride;
-        if (vec4) {
+        if (vec4 == 1) {
             const int chunks = (n_max_nodes + 1023) / 1024;
             hipLaunchKernelGGL(xr_obs_kernel<4>, dim3(chunks, cnt), dim3(256), lds, st, *b, o, env_stride, lo);
+        } else if (vec4 == 2) {
+            const size_t lds2 = (size_t)(b->legal_words * 64 + ((b->legal_words + 1 + 3) & ~3)) * sizeof(int) + (size_t)b->n_max * 2;
+            hipLaunchKernelGGL(xr_obs_stream_kernel, dim3(cnt), dim3(256), lds2, st, *b, o, env_stride, lo);
         } else {
             const int chunks = (n_max_nodes + 255) / 256;
             hipLaunchKernelGGL(xr_obs_kernel<1>, dim3(chunks, cnt), dim3(256), lds, st, *b, o, env_stride, lo);
