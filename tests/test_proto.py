@@ -87,3 +87,17 @@ def test_g3_inbox_bytes_from_our_encoder():
             raw = proto.encode_request(dims, proto.region_wire_fields(reg, z[f"t{ti}_s{j}_nodes"]), m,
                                        len(nets) == 0, nets)
             assert hashlib.sha256(raw).hexdigest() == t["inbox_sha256"][n_empty + j]
+
+
+def test_handle_messange_accepts_a_protobuf_like_object():
+    """The reference's callers pass the parsed pb2 Message (baseline/DQN/test_DQN.py:52-54); anything that can
+    SerializeToString is accepted."""
+    class Msg:
+        def __init__(self, raw):
+            self.raw = raw
+
+        def SerializeToString(self):
+            return self.raw
+    c = G2["cases"][0]
+    s = Sock()
+    assert proto.handle_messange(Msg(bytes.fromhex(c["bytes"])), s) == c["data"]

@@ -105,8 +105,11 @@ def request_to_data(msg: DecodedMessage) -> list:
 
 
 def handle_messange(message, socket):
-    """Drop-in for baseline_utils.handle_messange (:9-43): `message` is raw bytes or a DecodedMessage;
+    """Drop-in for baseline_utils.handle_messange (:9-43): `message` is the raw bytes, a DecodedMessage, or a
+    protobuf Message object (anything with SerializeToString, which is what the reference's callers hold);
     returns the reference's `data` list, or None for a non-request; acknowledges is_done with b'\\0'."""
+    if hasattr(message, "SerializeToString"):        # a protobuf `Message` object, as the reference passes it
+        message = message.SerializeToString()
     if isinstance(message, (bytes, bytearray, memoryview)):
         message = decode_message(bytes(message))
     data = None
