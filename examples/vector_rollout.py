@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Batched rollout: 1024 regions stepped per call on one MI355X with the batched DQN counterpart choosing the nets
+(random-init weights here; load a reference checkpoint with q_net.load_state_dict(torch.load(path)))."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from xroute_env_amd import XRouteVectorEnv, agents
+from xroute_env_amd.regions import config_regions
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+regions = config_regions(3, B)
+venv = XRouteVectorEnv(regions)
+q_net = agents.RepActor().to(venv.device).eval()
+obs, info = venv.reset()
+ret = torch.zeros(B, dtype=torch.float64, device=venv.device)
+for t in range(4):
+    actions = agents.dqn_actions(q_net, obs, info["nlegal"], regions[0].dims)      # int32 [B], 1-based net ids
+    obs, reward, done, info = venv.step(actions)
+    ret += reward
+    print(f"step {t}: mean reward {reward.mean().item():.1f}, done {int(done.sum())}/{B}")
