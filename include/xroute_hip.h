@@ -168,6 +168,21 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
 
+/* Whole-order re-route, the step of the reference's two other env contracts: the A3C env answers the simulator with
+ * a complete net list (baseline/A3C/utils.py:305-307, Response.net_list of net_ordering.proto v2 field 2) and the
+ * MCTS dispatcher re-routes the region from scratch with `routed_nets + unrouted_nets` after every selection
+ * (baseline/xroute/trainer4/dispatcher.py:113-118).  Every env restores its assigned region's initial state and
+ * routes orders_dev[e*stride + 0..] (int32, 1-based net ids, a value <= 0 ends the list; stride >= k_max) in that
+ * order, in one launch.  Afterwards XR_FETCH_CUM holds the final cumulative metrics, XR_FETCH_DELTA / REWARD the
+ * totals over the whole order (cum - initial), XR_FETCH_STATUS the OR over the routed nets, XR_FETCH_PATH_LEN /
+ * SWEEPS the sums, XR_FETCH_DONE whether every net was routed.  Illegal entries (out of range, repeated) are skipped and
+ * flagged XR_ENV_BAD_ACTION.  net_stats_dev: NULL or int32[n_envs][stride][4], row = net id - 1:
+ * {d_violation, d_wirelength, d_via} of that net's route in this order (the simulator's `metrics_delta`, proto v2
+ * field 13) and a counter incremented once per route (`count_map`, field 12); rows of nets not routed are left
+ * untouched, the caller zeroes the buffer when an episode starts. */
+int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t stride, int32_t* net_stats_dev,
+                             void* stream);
+
 /* BASELINE config "random net-order policy": actions_dev[e] = a uniformly chosen legal net of env e
  * (1-based; 0 when the env is done), from a counter-based hash of (seed, e, step count). */
 int32_t xr_batch_random_actions(xr_batch* b, int32_t* actions_dev, uint64_t seed, void* stream);

@@ -20,6 +20,9 @@ _LAZY = {
     "OrderingEvaluationEnv": ("envs.facade", "OrderingEvaluationEnv"),
     "StaticRegionEnv": ("envs.facade", "StaticRegionEnv"),
     "XRouteEnv": ("envs.facade", "XRouteEnv"),
+    "A3CGame": ("envs.order_contracts", "A3CGame"),
+    "Route": ("envs.order_contracts", "Route"),
+    "OrderVectorEnv": ("envs.order_contracts", "OrderVectorEnv"),
     "Region": ("regions", "Region"),
     "generate_region": ("regions", "generate_region"),
     "config_regions": ("regions", "config_regions"),

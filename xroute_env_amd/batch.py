@@ -129,6 +129,24 @@ class RegionBatch:
                                                         _stream_ptr(self.device)))
         return obs_out
 
+    def route_order(self, orders: torch.Tensor, net_stats: Optional[torch.Tensor] = None):
+        """Whole-order re-route (xr_batch_route_order): every env restarts its region and routes
+        orders[e, :] (int32 [B, stride >= k_max], 1-based ids, 0-terminated) in that order, one launch.
+        net_stats: optional int32 [B, stride, 4] (per net: d_vio, d_wl, d_via, route counter)."""
+        if orders.device != self.device or orders.dtype != torch.int32 or not orders.is_contiguous() \
+                or orders.dim() != 2 or orders.shape[0] != self.n_envs:
+            raise ValueError("orders must be a contiguous int32 [n_envs, stride] tensor on the batch device")
+        sp = None
+        if net_stats is not None:
+            if net_stats.device != self.device or net_stats.dtype != torch.int32 or not net_stats.is_contiguous() \
+                    or tuple(net_stats.shape) != (self.n_envs, orders.shape[1], 4):
+                raise ValueError("net_stats must be a contiguous int32 [n_envs, stride, 4] tensor on the batch device")
+            sp = C.c_void_p(net_stats.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_route_order(self._h, C.c_void_p(orders.data_ptr()), int(orders.shape[1]), sp,
+                                                   _stream_ptr(self.device)))
+        return net_stats
+
     def random_actions(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)

@@ -20,6 +20,7 @@ hipError_t xr_launch_ingest(const uint32_t*, int16_t*, int16_t*, int64_t, hipStr
 hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
 hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
+hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
 hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
@@ -466,6 +467,17 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
                            static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t stride, int32_t* net_stats_dev, void* stream) {
+    if (!b || !orders_dev) return fail(XR_ERR_INVALID, "xr_batch_route_order: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_route_order: load regions first");
+    if (stride < b->k_max)
+        return fail(XR_ERR_RANGE, "xr_batch_route_order: stride %d < k_max %d", stride, b->k_max);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(xr_launch_order(&b->dev, orders_dev, stride, net_stats_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds,
+                           b->route_threads, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 

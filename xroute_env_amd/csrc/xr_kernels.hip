@@ -282,7 +282,7 @@ struct XrLayout {
 // ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
 // many layers (single exact chunk).
 template <bool LDS_DIST, int ZCH>
-__device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t* __restrict__ actions, char* smem) {
+__device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, char* smem) {
     __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // padded field index of each access point
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
@@ -309,7 +309,6 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int32_t*
     }
 
     const XrRegionDev R = b.regions[b.env_region[e]];
-    const int a = actions[e];
     bool valid = (a >= 1 && a <= R.n_nets);
     if (valid) valid = (b.legal[(int64_t)e * b.legal_words + ((a - 1) >> 6)] >> ((a - 1) & 63)) & 1ULL;
     if (!valid) {   // the reference never checks this client-side; here: flagged no-op
@@ -1002,7 +1001,7 @@ __global__ void xr_obs_records_kernel(const uint32_t* __restrict__ rec, int X, i
 template <bool LDS_DIST, int ZCH>
 __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    xr_route_env<LDS_DIST, ZCH>(b, actions, smem);
+    xr_route_env<LDS_DIST, ZCH>(b, actions[blockIdx.x], smem);
     if (b.obs_out) {
         __syncthreads();          // this workgroup's owner / legal / region writes are visible to all its threads
         const int e = blockIdx.x;
@@ -1022,6 +1021,55 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
                 xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole-order re-route: the A3C / MCTS simulator contract.  The reference's A3C env answers with a complete
+// net list (baseline/A3C/utils.py:305-307 `message.response.net_list.extend(action_list)`) and its MCTS
+// dispatcher re-routes the region from scratch with `routed_nets + unrouted_nets` after every selection
+// (baseline/xroute/trainer4/dispatcher.py:113-118).  One workgroup restores its env to the region's initial
+// state and routes the listed nets back to back; per-net metric deltas (the simulator's `metrics_delta`,
+// net_ordering.proto v2 field 13) and a per-net route counter (`count_map`, field 12) go to net_stats.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_DIST, int ZCH>
+__global__ void xr_order_kernel(XrBatchDev b, const int32_t* __restrict__ orders, int stride,
+                                int32_t* __restrict__ net_stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    xr_env_reset(b, e, 0, 0);
+    __syncthreads();
+    int st_acc = 0, plen_acc = 0, sweeps_acc = 0;
+    const int32_t* __restrict__ ord = orders + (int64_t)e * stride;
+    for (int k = 0; k < stride; k++) {
+        const int a = ord[k];
+        if (a <= 0) break;                         // list terminator (uniform)
+        if (b.nlegal[e] == 0) break;               // everything routed: the rest of the list is ignored
+        xr_route_env<LDS_DIST, ZCH>(b, a, smem);
+        __syncthreads();
+        if (tid == 0) {
+            const int st = b.status[e];
+            st_acc |= st;
+            if (!(st & XR_ENV_BAD_ACTION)) {
+                plen_acc += b.path_len[e];
+                sweeps_acc += b.sweeps[e];
+                if (net_stats) {
+                    int32_t* s = net_stats + ((int64_t)e * stride + (a - 1)) * 4;
+                    s[0] = b.delta[3 * e + 0]; s[1] = b.delta[3 * e + 1]; s[2] = b.delta[3 * e + 2];
+                    s[3] += 1;
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        const XrRegionDev R = b.regions[b.env_region[e]];
+        const int dv = b.cum[3 * e + 0] - R.m0[0], dw = b.cum[3 * e + 1] - R.m0[1], dvia = b.cum[3 * e + 2] - R.m0[2];
+        b.delta[3 * e + 0] = dv; b.delta[3 * e + 1] = dw; b.delta[3 * e + 2] = dvia;
+        b.reward[e] = -1.0 * (b.w_violation * (double)dv + b.w_via * (double)dvia + b.w_wirelength * (double)dw);
+        b.status[e] = st_acc;
+        b.path_len[e] = plen_acc;
+        b.sweeps[e] = sweeps_acc;
     }
 }
 
@@ -1047,8 +1095,13 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
     const void* fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, 0>), reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
                           reinterpret_cast<const void*>(&xr_route_kernel<true, 12>), reinterpret_cast<const void*>(&xr_route_kernel<false, 0>),
                           reinterpret_cast<const void*>(&xr_route_kernel<false, 9>), reinterpret_cast<const void*>(&xr_route_kernel<false, 12>)};
+    const void* ofns[6] = {reinterpret_cast<const void*>(&xr_order_kernel<true, 0>), reinterpret_cast<const void*>(&xr_order_kernel<true, 9>),
+                           reinterpret_cast<const void*>(&xr_order_kernel<true, 12>), reinterpret_cast<const void*>(&xr_order_kernel<false, 0>),
+                           reinterpret_cast<const void*>(&xr_order_kernel<false, 9>), reinterpret_cast<const void*>(&xr_order_kernel<false, 12>)};
     for (int i = 0; i < 6; i++) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(ofns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1066,6 +1119,21 @@ hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_
         if (zch == 9) hipLaunchKernelGGL((xr_route_kernel<false, 9>), g, t, lds_bytes, st, *b, actions);
         else if (zch == 12) hipLaunchKernelGGL((xr_route_kernel<false, 12>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_route_kernel<false, 0>), g, t, lds_bytes, st, *b, actions);
+    }
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int stride, int32_t* net_stats, int lds_dist, int zch,
+                           size_t lds_bytes, int threads, hipStream_t st) {
+    const dim3 g(b->n_envs), t(threads);
+    if (lds_dist) {
+        if (zch == 9) hipLaunchKernelGGL((xr_order_kernel<true, 9>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else if (zch == 12) hipLaunchKernelGGL((xr_order_kernel<true, 12>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else hipLaunchKernelGGL((xr_order_kernel<true, 0>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+    } else {
+        if (zch == 9) hipLaunchKernelGGL((xr_order_kernel<false, 9>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else if (zch == 12) hipLaunchKernelGGL((xr_order_kernel<false, 12>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else hipLaunchKernelGGL((xr_order_kernel<false, 0>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     }
     return hipGetLastError();
 }
