@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 1
+#define XR_ABI_VERSION 2
 
 /* status codes */
 #define XR_OK            0
@@ -77,6 +77,8 @@ typedef struct xr_batch xr_batch;
  * (ispd/ispd18_test1/run-net-ordering-training.tcl:3 `-drc_cost 8`), the reward weights its
  * trainers (baseline/DQN/train_DQN.py:98-99, baseline/PPO/train_PPO.py:101-102), max_route_count
  * its control plane (examples/launch_training.py:28). */
+#define XR_OBS_FUSED 1
+#define XR_OBS_SPLIT 2
 typedef struct xr_config {
     int32_t struct_size;      /* = sizeof(xr_config); checked */
     int32_t device;           /* HIP device ordinal */
@@ -91,10 +93,13 @@ typedef struct xr_config {
     int32_t block_threads;    /* route kernel workgroup size, 0 = default */
     int32_t force_scratch_field; /* 1: keep the distance field in HBM scratch even when it would fit LDS (the
                                     large-region code path; for tests and A/B measurements) */
-    int32_t reserved0;        /* keeps the doubles 8-byte aligned; must be 0 */
+    int32_t obs_mode;         /* xr_batch_step_observe: 0 = default (= XR_OBS_FUSED, the faster one as measured),
+                                 XR_OBS_FUSED = one launch, XR_OBS_SPLIT = route kernel + concurrent net-plane writer */
     double  w_violation;      /* 500  */
     double  w_via;            /* 4    */
     double  w_wirelength;     /* 0.5  */
+    int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer (0 = default) */
+    int32_t reserved1;        /* must be 0 */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */
@@ -161,10 +166,17 @@ int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, voi
  * wirelength/via/violation, updates netSet/done/reward. */
 int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
 
-/* Game.step in ONE launch: xr_batch_step followed, in the same kernel and by the same workgroup, by
- * xr_batch_observation of every env (baseline/baseline_utils.py:409-423: route, then build_3Dgrid on the new
- * state).  The observation stream of some workgroups overlaps the routing of others.  out_dev / env_stride as
- * in xr_batch_observation, for envs [0, n_envs). */
+/* Game.step with its observation (baseline/baseline_utils.py:409-423: route, then build_3Dgrid on the new state),
+ * out_dev / env_stride as in xr_batch_observation, for envs [0, n_envs).  Two forms, same result:
+ *   XR_OBS_FUSED  one launch: every workgroup routes its env, then streams that env's observation.
+ *   XR_OBS_SPLIT  the 7K net planes of an env do not depend on the routing result (they are functions of the
+ *                 region's static node array and of which nets remain, which follows from the state before the
+ *                 step), so a planning kernel derives every env's post-step net set, a balanced, address-ordered
+ *                 writer kernel streams all net planes on an internal stream, and the route kernel — running
+ *                 concurrently on the caller's stream — writes planes 0..1.  The caller's stream is joined with
+ *                 the internal one before the call returns control of the stream (event wait, no host sync).
+ *                 Needs every region's N % 4 == 0 and a 16-byte aligned out_dev / env_stride % 4 == 0; otherwise
+ *                 the call runs XR_OBS_FUSED. */
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
 
@@ -182,6 +194,11 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
  * untouched, the caller zeroes the buffer when an episode starts. */
 int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t stride, int32_t* net_stats_dev,
                              void* stream);
+
+/* Duration in milliseconds (HIP events on the library's internal stream) of the net-plane writer kernel that the
+ * last xr_batch_step_observe launched in XR_OBS_SPLIT mode; blocks until that kernel has finished.  *mode_out = the
+ * mode that call ran in (XR_OBS_FUSED / XR_OBS_SPLIT); *writer_ms = 0 for XR_OBS_FUSED. */
+int32_t xr_batch_observe_timing(xr_batch* b, int32_t* mode_out, float* writer_ms);
 
 /* BASELINE config "random net-order policy": actions_dev[e] = a uniformly chosen legal net of env e
  * (1-based; 0 when the env is done), from a counter-based hash of (seed, e, step count). */

@@ -63,29 +63,34 @@ def test_observation_subrange_and_strides():
         assert (out[j, n:] == -1).all()          # nothing written past the env's own channels
 
 
-def test_step_observe_fused_equals_two_launches():
+@pytest.mark.parametrize("obs_mode", [1, 2])
+def test_step_observe_fused_equals_two_launches(obs_mode):
     """xr_batch_step_observe == xr_batch_step followed by xr_batch_observation, for every env and step
-    (routing, auto-reset and flagged no-op slots alike)."""
+    (routing, auto-reset with region rotation and flagged no-op slots alike), in both forms: 1 = one fused launch,
+    2 = split (planning kernel + net-plane writer on the internal stream || route kernel writing planes 0..1)."""
     from xroute_env_amd.batch import RegionBatch
-    regions = [generate_region(6200 + i, dims=(24, 40, 9), k_range=(1, 6)) for i in range(24)]
-    a = RegionBatch(regions, device="cuda:0", auto_reset=True)
-    b = RegionBatch(regions, device="cuda:0", auto_reset=True)
+    regions = [generate_region(6200 + i, dims=(24, 40, 9), k_range=(1, 6)) for i in range(29)]
+    a = RegionBatch(regions, n_envs=24, device="cuda:0", auto_reset=True, obs_mode=obs_mode, max_route_count=2)
+    b = RegionBatch(regions, n_envs=24, device="cuda:0", auto_reset=True, max_route_count=2)
     a.reset(); b.reset()
-    acts = torch.empty(len(regions), dtype=torch.int32, device="cuda:0")
-    oa = torch.full((len(regions), a.obs_env_stride), -7.0, device="cuda:0")
-    ob = torch.full((len(regions), a.obs_env_stride), -7.0, device="cuda:0")
-    for it in range(12):
-        a.random_actions(5, acts)
+    acts = torch.empty(24, dtype=torch.int32, device="cuda:0")
+    oa = torch.full((24, a.obs_env_stride), -7.0, device="cuda:0")
+    ob = torch.full((24, a.obs_env_stride), -7.0, device="cuda:0")
+    for it in range(30):
+        a.random_actions(5 + it, acts)
         if it == 3:
             acts[0] = 0                       # illegal action: flagged no-op, observation still written
         a.step(acts, oa)
         b.step(acts)
         b.observation(ob)
+        assert a.observe_timing()[0] == obs_mode
         assert torch.equal(a.fetch("nlegal"), b.fetch("nlegal")) and torch.equal(a.fetch("hash"), b.fetch("hash"))
+        assert torch.equal(a.fetch("region"), b.fetch("region"))
         k = a.fetch("nlegal").cpu().numpy()
-        for i, r in enumerate(regions):
-            n = (2 + 7 * int(k[i])) * r.n_nodes
+        for i in range(24):
+            n = (2 + 7 * int(k[i])) * regions[0].n_nodes
             assert torch.equal(oa[i, :n], ob[i, :n]), (it, i)
+    assert len(set(a.fetch("region").cpu().tolist())) > 1 and int(a.fetch("region").cpu().max()) >= 24     # rotation happened
 
 
 def test_step_observe_scalar_path_and_odd_dims():

@@ -25,7 +25,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 SYMBOLS = [
     "xr_abi_version", "xr_last_error", "xr_config_default", "xr_device_count",
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
-    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_route_order", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
+    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 
@@ -34,8 +34,9 @@ class XrConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_envs", C.c_int32),
                 ("via_cost", C.c_int32), ("drc_cost", C.c_int32), ("drc_unit", C.c_int32),
                 ("max_route_count", C.c_int32), ("auto_reset", C.c_int32), ("path_cap", C.c_int32),
-                ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("reserved0", C.c_int32),
-                ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double)]
+                ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("obs_mode", C.c_int32),
+                ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
+                ("obs_writer_blocks", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class XrRegionDesc(C.Structure):
@@ -92,7 +93,7 @@ def lib():
         fn = getattr(L, name)
         if name not in ("xr_last_error", "xr_config_default"):
             fn.restype = C.c_int32
-    if L.xr_abi_version() != 1:
+    if L.xr_abi_version() != 2:
         raise RuntimeError("libxroute_hip.so ABI version mismatch")
     _LIB = L
     return L

@@ -35,7 +35,7 @@ class RegionBatch:
     def __init__(self, regions: Sequence[Region], n_envs: Optional[int] = None, device="cuda:0",
                  auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
-                 force_scratch_field: bool = False):
+                 force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -49,6 +49,8 @@ class RegionBatch:
         cfg.path_cap = path_cap
         cfg.block_threads = block_threads
         cfg.force_scratch_field = int(force_scratch_field)
+        cfg.obs_mode = int(obs_mode)                    # 0 default, 1 fused single launch, 2 split (route || net-plane writer)
+        cfg.obs_writer_blocks = int(obs_writer_blocks)
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))
@@ -128,6 +130,13 @@ class RegionBatch:
                                                         C.c_void_p(obs_out.data_ptr()), obs_out.shape[1],
                                                         _stream_ptr(self.device)))
         return obs_out
+
+    def observe_timing(self):
+        """(mode, writer_ms) of the last step(actions, obs_out): mode 1 = fused launch, 2 = split (route kernel and
+        net-plane writer running concurrently); writer_ms = HIP-event duration of the writer kernel (0 when fused)."""
+        mode, ms = C.c_int32(0), C.c_float(0.0)
+        _lib.check(self.L.xr_batch_observe_timing(self._h, C.byref(mode), C.byref(ms)))
+        return int(mode.value), float(ms.value)
 
     def route_order(self, orders: torch.Tensor, net_stats: Optional[torch.Tensor] = None):
         """Whole-order re-route (xr_batch_route_order): every env restarts its region and routes

@@ -20,6 +20,8 @@ hipError_t xr_launch_ingest(const uint32_t*, int16_t*, int16_t*, int64_t, hipStr
 hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
 hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
+hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
+hipError_t xr_launch_netplanes(const XrBatchDev*, int, hipStream_t);
 hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
@@ -108,7 +110,20 @@ struct xr_batch {
     DevBuf<unsigned long long> total_steps;
     DevBuf<uint32_t> dist_scratch;
     DevBuf<unsigned short> list_scratch;
+    // split observation
+    DevBuf<int32_t> plan_region, plan_unit_net, plan_off;
+    DevBuf<uint32_t> plan_units;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
+    int last_obs_mode = 0;
     XrBatchDev dev{};
+    ~xr_batch() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_w0) (void)hipEventDestroy(ev_w0);
+        if (ev_w1) (void)hipEventDestroy(ev_w1);
+        if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    }
 };
 
 extern "C" {
@@ -130,7 +145,9 @@ void xr_config_default(xr_config* c) {
     c->path_cap = 0;
     c->block_threads = 0;
     c->force_scratch_field = 0;
-    c->reserved0 = 0;
+    c->obs_mode = 0;
+    c->obs_writer_blocks = 0;
+    c->reserved1 = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -155,6 +172,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
     if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
+    if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_SPLIT || cfg->obs_writer_blocks < 0 || cfg->reserved1 != 0)
+        return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED or XR_OBS_SPLIT; obs_writer_blocks >= 0; reserved1 = 0");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -358,6 +377,10 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->env_steps, B);
     XR_ALLOC(b->total_steps, 1);
     XR_ALLOC(b->phase_cycles, (size_t)B * 8);
+    XR_ALLOC(b->plan_region, B);
+    XR_ALLOC(b->plan_off, (size_t)B + 1);
+    XR_ALLOC(b->plan_units, (size_t)B * std::max(1, k_max));
+    XR_ALLOC(b->plan_unit_net, (size_t)B * std::max(1, k_max));
     if (!b->lds_dist) {
         XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);
@@ -400,7 +423,15 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
-    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0;
+    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0;
+    d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.plan_off = b->plan_off.p;
+    if (!b->aux_stream) {
+        XR_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
+        XR_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        XR_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+        XR_HIP(hipEventCreate(&b->ev_w0));
+        XR_HIP(hipEventCreate(&b->ev_w1));
+    }
     d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
     d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
     d.w_violation = b->cfg.w_violation; d.w_via = b->cfg.w_via; d.w_wirelength = b->cfg.w_wirelength;
@@ -465,8 +496,37 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     // 1: aligned float4 (every N % 4 == 0), 2: shifted float4 (any N), 0: scalar (unaligned caller buffer)
     const bool aligned = (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
-    XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
-                           static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool can_split = d.obs_vec4 == 1 && b->cfg.n_envs <= (1 << 18) && b->k_max < (1 << 14) && b->k_max >= 1;
+    const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT;      // default: fused (measured faster)
+    b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
+    if (!split) {
+        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));
+        return XR_OK;
+    }
+    // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
+    // caller's stream -> join.  Everything is ordered by events; the host never waits.
+    d.obs_head_only = 1;
+    XR_HIP(xr_launch_plan(&d, actions_dev, st));
+    XR_HIP(hipEventRecord(b->ev_fork, st));
+    XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
+    XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));
+    XR_HIP(hipEventRecord(b->ev_w0, b->aux_stream));
+    XR_HIP(xr_launch_netplanes(&d, b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : 512, b->aux_stream));
+    XR_HIP(hipEventRecord(b->ev_w1, b->aux_stream));
+    XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
+    return XR_OK;
+}
+
+int32_t xr_batch_observe_timing(xr_batch* b, int32_t* mode_out, float* writer_ms) {
+    if (!b || !mode_out || !writer_ms) return fail(XR_ERR_INVALID, "xr_batch_observe_timing: null argument");
+    *mode_out = b->last_obs_mode;
+    *writer_ms = 0.f;
+    if (b->last_obs_mode == XR_OBS_SPLIT) {
+        XR_HIP(hipSetDevice(b->cfg.device));
+        XR_HIP(hipEventSynchronize(b->ev_w1));
+        XR_HIP(hipEventElapsedTime(writer_ms, b->ev_w0, b->ev_w1));
+    }
     return XR_OK;
 }
 

@@ -70,6 +70,12 @@ struct XrBatchDev {
     float* obs_out;
     int64_t obs_stride;      // floats per env
     int32_t obs_vec4;        // float4 stores allowed (all N % 4 == 0, aligned planes)
+    int32_t obs_head_only;   // 1: the step kernel writes planes 0..1 only; the net planes come from xr_netplane_kernel
+    // split observation (xr_plan_kernel -> xr_netplane_kernel): the state every env will have AFTER this step
+    int32_t* plan_region;    // [B]
+    uint32_t* plan_units;    // [B*k_max] one entry per (env, remaining net): env << 14 | (rank of the net among the remaining)
+    int32_t* plan_unit_net;  // [B*k_max] 1-based net id of that unit
+    int32_t* plan_off;       // [B+1] exclusive prefix of the remaining-net counts (= first unit of env e)
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     double w_violation, w_via, w_wirelength;

@@ -821,7 +821,8 @@ typedef float xr_f4 __attribute__((ext_vector_type(4)));
 #endif
 template <class Src, int VEC>
 __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, int N, const int* s_ids, int K,
-                                             float* __restrict__ out, int chunk_base) {
+                                             float* __restrict__ out, int chunk_base, int knets = -1) {
+    if (knets < 0) knets = K;            // net plane groups written here (0: planes 0..1 only)
     const int f0 = chunk_base + threadIdx.x * VEC;
     if (f0 >= N) return;
     float obst[VEC];
@@ -845,7 +846,7 @@ __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, 
 #pragma unroll
         for (int j = 0; j < VEC; j++) anyap |= (apnet[j] != 0);
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < knets; i++) {
             float4 m = zero, ma = zero;
             if (anyap) {
                 const int id = s_ids[i];
@@ -864,7 +865,7 @@ __device__ __forceinline__ void xr_obs_write(const Src& s, int X, int Y, int Z, 
         p += N;
         p[0] = (f0 < K) ? (float)s_ids[f0] : 0.f;
         p += N;
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < knets; i++) {
             const float m = (apnet[0] != 0 && apnet[0] == s_ids[i]) ? 1.f : 0.f;
             const float ma = adj[0] ? m : 0.f;
             p[0] = m;
@@ -1001,7 +1002,17 @@ __global__ void xr_obs_records_kernel(const uint32_t* __restrict__ rec, int X, i
 template <bool LDS_DIST, int ZCH>
 __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef XR_TIMELINE
+    // `make timeline`: absolute 100 MHz timestamps of this workgroup (start, routed, written) + where it ran
+    if (threadIdx.x == 0) {
+        b.phase_cycles[(int64_t)blockIdx.x * 8 + 0] = (long long)wall_clock64();
+        b.phase_cycles[(int64_t)blockIdx.x * 8 + 3] = (long long)__smid();
+    }
+#endif
     xr_route_env<LDS_DIST, ZCH>(b, actions[blockIdx.x], smem);
+#ifdef XR_TIMELINE
+    if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 1] = (long long)wall_clock64();
+#endif
     if (b.obs_out) {
         __syncthreads();          // this workgroup's owner / legal / region writes are visible to all its threads
         const int e = blockIdx.x;
@@ -1012,14 +1023,159 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
         float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
         if (b.obs_vec4 == 1) {
+            const int knets = b.obs_head_only ? 0 : K;
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
-                xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+                xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
         } else if (b.obs_vec4 == 2) {
             unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
             xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat);
         } else {
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
                 xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+        }
+    }
+#ifdef XR_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 2] = (long long)wall_clock64();
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// split observation.  7K of the 2+7K planes of an env do not depend on the routing result at all: the planes of
+// net n are functions of the region's static node_net array, and WHICH nets remain after the step follows from
+// the state before it (legal set, action validity, auto-reset + region rotation).  xr_plan_kernel derives that
+// post-step state for every env and lists one unit per (env, remaining net); xr_netplane_kernel then streams the
+// 7 planes of every unit, concurrently with the route kernel (which writes planes 0..1 in its epilogue).
+// Units are equal-sized and visited in address order by the whole grid, so the write stream is balanced and
+// globally sequential (measured: the fastest write pattern on this device, tools/micro/write_bw.hip).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < b.n_envs; base += 1024) {
+        const int e = base + tid;
+        int k = 0, r = 0;
+        const uint64_t* lsrc = nullptr;        // where the post-step legal words come from
+        int clear_bit = -1;
+        if (e < b.n_envs) {
+            const int nl = b.nlegal[e];
+            r = b.env_region[e];
+            if (nl == 0) {
+                if (b.auto_reset) {            // xr_env_reset(rotate = 1), examples/launch_training.py:37-46
+                    if (b.env_replay[e] == b.max_route_count) r = (int)(((int64_t)r + b.n_envs) % b.n_regions);
+                    const XrRegionDev R = b.regions[r];
+                    lsrc = b.legal0 + R.legal0_off;
+                    k = R.nlegal0;
+                }
+            } else {
+                const XrRegionDev R = b.regions[r];
+                const int a = actions[e];
+                lsrc = b.legal + (int64_t)e * b.legal_words;
+                k = nl;
+                if (a >= 1 && a <= R.n_nets && ((lsrc[(a - 1) >> 6] >> ((a - 1) & 63)) & 1ULL)) {
+                    clear_bit = a - 1;
+                    k = nl - 1;
+                }
+            }
+            b.plan_region[e] = r;
+        }
+        // block-wide exclusive scan of k
+        int incl = k;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; w++) woff += s_wsum[w];
+        const int carry = s_carry;
+        const int off = carry + woff + incl - k;
+        if (e < b.n_envs) {
+            b.plan_off[e] = off;
+            int j = 0;
+            for (int w = 0; w < b.legal_words && j < k; w++) {
+                uint64_t m = lsrc[w];
+                if (clear_bit >= 0 && (clear_bit >> 6) == w) m &= ~(1ULL << (clear_bit & 63));
+                while (m) {
+                    const int bit = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                    b.plan_units[off + j] = ((uint32_t)e << 14) | (uint32_t)j;
+                    b.plan_unit_net[off + j] = (w << 6) + bit + 1;
+                    j++;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) b.plan_off[b.n_envs] = s_carry;
+}
+
+#define XR_NP_J 9            // float4 groups per thread per tile: 256 threads * 4 nodes * 9 = 9216 nodes
+__global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
+    const int tid = threadIdx.x;
+    const int total = b.plan_off[b.n_envs];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        const uint32_t ent = b.plan_units[u];
+        const int id = b.plan_unit_net[u];
+        const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
+        const XrRegionDev R = b.regions[b.plan_region[e]];
+        const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
+        const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+        float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride + (int64_t)(2 + 7 * rank) * N;
+        const int ngrp = N >> 2;                                   // N % 4 == 0 in this mode
+        for (int g0 = 0; g0 < ngrp; g0 += 256 * XR_NP_J) {
+            unsigned bits[XR_NP_J];                                // per group: AP mask (bits 0..3), neighbour mask (4..7)
+#pragma unroll
+            for (int j = 0; j < XR_NP_J; j++) {
+                const int g = g0 + j * 256 + tid;
+                unsigned m = 0;
+                if (g < ngrp) {
+                    const int f0 = g << 2;
+                    const int2 v = *reinterpret_cast<const int2*>(nn + f0);     // 4 x int16, 8-byte aligned
+                    const int n0 = (short)(v.x & 0xFFFF), n1 = v.x >> 16, n2 = (short)(v.y & 0xFFFF), n3 = v.y >> 16;
+                    m = (n0 == id ? 1u : 0u) | (n1 == id ? 2u : 0u) | (n2 == id ? 4u : 0u) | (n3 == id ? 8u : 0u);
+                    if (m) {                                           // rare: ~1 % of the nodes are access points
+                        for (int q = 0; q < 4; q++)
+                            if (m & (1u << q)) {
+                                const int f = f0 + q;
+                                const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+                                bool adj = false;
+                                if (x + 1 < X && nn[f + YZ] == id) adj = true;
+                                else if (y > 0 && nn[f - Z] == id) adj = true;
+                                else if (x > 0 && nn[f - YZ] == id) adj = true;
+                                else if (y + 1 < Y && nn[f + Z] == id) adj = true;
+                                else if (z + 1 < Z && nn[f + 1] == id) adj = true;
+                                else if (z > 0 && nn[f - 1] == id) adj = true;
+                                if (adj) m |= 16u << q;
+                            }
+                    }
+                }
+                bits[j] = m;
+            }
+            // plane 0 of the net: AP mask; planes 1..6: the six aliased "has a same-net axis neighbour" planes
+#pragma unroll 1
+            for (int pl = 0; pl < 7; pl++) {
+                float* __restrict__ pp = out + (int64_t)pl * N;
+                const int sh = pl ? 4 : 0;
+#pragma unroll
+                for (int j = 0; j < XR_NP_J; j++) {
+                    const int g = g0 + j * 256 + tid;
+                    if (g < ngrp) {
+                        const unsigned m = bits[j] >> sh;
+                        float4 v;
+                        v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 2u) ? 1.f : 0.f;
+                        v.z = (m & 4u) ? 1.f : 0.f; v.w = (m & 8u) ? 1.f : 0.f;
+                        XR_ST4(pp + ((int64_t)g << 2), v);
+                    }
+                }
+            }
         }
     }
 }
@@ -1135,6 +1291,16 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
         else if (zch == 12) hipLaunchKernelGGL((xr_order_kernel<false, 12>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else hipLaunchKernelGGL((xr_order_kernel<false, 0>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     }
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream_t st) {
+    hipLaunchKernelGGL(xr_plan_kernel, dim3(1), dim3(1024), 0, st, *b, actions);
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_netplanes(const XrBatchDev* b, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(xr_netplane_kernel, dim3(blocks), dim3(256), 0, st, *b);
     return hipGetLastError();
 }
 
