@@ -1,0 +1,65 @@
+"""BASELINE config 5 at its full size (256x256x12 dense-congestion grids, K = 32): the large-region code path (distance
+field, claim bitmask and worklists in per-env HBM scratch) against the CPU oracle, net by net — paths, metrics,
+owners and the hash chain bit for bit — and the whole-order launch on the same regions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xr_oracle as orc
+from xroute_env_amd.regions import config_regions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def regions():
+    return config_regions(5, 2)
+
+
+def test_config5_fullsize_steps_match_oracle(regions):
+    from xroute_env_amd.batch import RegionBatch
+    assert regions[0].dims == (256, 256, 12) and regions[0].n_nets == 32
+    batch = RegionBatch(regions, device="cuda:0")
+    batch.reset()
+    envs = [orc.OracleEnv(r) for r in regions]
+    for env in envs:
+        env.reset()
+    rng = np.random.default_rng(55)
+    for it in range(5):
+        legal = batch.legal_sets()
+        acts = [int(rng.choice(sorted(s))) for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+        delta = batch.fetch("delta").cpu().numpy()
+        plen = batch.fetch("path_len").cpu().numpy()
+        path = batch.fetch("path").cpu().numpy()
+        status = batch.fetch("status").cpu().numpy()
+        owner = batch.fetch("owner").cpu().numpy()
+        hashes = batch.fetch("hash").cpu().numpy()
+        for e, env in enumerate(envs):
+            res = env.step(acts[e], path_cap=batch.path_cap)
+            assert delta[e].tolist() == res["delta"].tolist(), (it, e)
+            assert int(plen[e]) == res["path_len"] and (int(status[e]) & ~8) == res["status"]
+            n = min(res["path_len"], batch.path_cap)
+            assert np.array_equal(path[e, :n], res["path"][:n])
+            assert np.array_equal(owner[e, : regions[e].n_nodes], env.owner())
+            assert int(hashes[e]) & 0xFFFFFFFFFFFFFFFF == env.hash() & 0xFFFFFFFFFFFFFFFF
+    assert int(batch.fetch("sweeps").cpu().min()) > 0
+
+
+def test_config5_fullsize_route_order_matches_oracle(regions):
+    from xroute_env_amd.batch import RegionBatch
+    batch = RegionBatch(regions, device="cuda:0")
+    S = batch.k_max
+    orders = np.zeros((2, S), np.int32)
+    orders[0, :6] = [7, 3, 30, 1, 12, 20]
+    orders[1, :6] = [32, 2, 9, 17, 4, 25]
+    batch.route_order(torch.as_tensor(orders, device="cuda:0"))
+    cum = batch.fetch("cum").cpu().numpy()
+    owner = batch.fetch("owner").cpu().numpy()
+    for e, r in enumerate(regions):
+        env = orc.OracleEnv(r)
+        env.reset()
+        for a in orders[e, :6]:
+            env.step(int(a))
+        assert cum[e].tolist() == env.cum().tolist()
+        assert np.array_equal(owner[e, : r.n_nodes], env.owner())

@@ -322,16 +322,29 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->all_n_mult4 = mult4;
     b->path_cap = b->cfg.path_cap > 0 ? b->cfg.path_cap : std::min(n_max_nodes, 4096);
 
-    // route kernel placement: distance field + class grid in LDS when they fit
-    // field + claim bitmask + edge-length tables + 3 line bitmasks + worklists (u16 line ids)
-    const size_t lw_max = ((size_t)lines_max + 31) / 32 + 1;
+    // route kernel placement: distance field in LDS when it fits.  Worklist items are (line, chunk of 8 nodes) pairs:
+    // x-tracks * ceil(X/8) + y-tracks * ceil(Y/8) + columns * (1 when every region has 9 / 12 layers, else ceil(Z/8))
+    int items_max = 0, kind_max = 0;
+    for (int r = 0; r < n_regions; r++) {
+        const XrRegionDev& R = hreg[r];
+        int nv = 0;
+        for (int z = 0; z < R.Z; z++) nv += (R.ldir_mask >> z) & 1u;
+        const int chH = (R.X + 7) / 8, chV = (R.Y + 7) / 8, chC = b->zch ? 1 : (R.Z + 7) / 8;
+        const int64_t itH = (int64_t)(R.Z - nv) * R.Y * chH, itV = (int64_t)nv * R.X * chV, itC = (int64_t)R.X * R.Y * chC;
+        if (itH > 65536 || itV > 65536 || itC > 65536)
+            return fail(XR_ERR_RANGE, "region %d: more than 65536 worklist items of one kind (%lld / %lld / %lld)", r,
+                        (long long)itH, (long long)itV, (long long)itC);
+        items_max = std::max(items_max, (int)(itH + itV + itC));
+        kind_max = std::max(kind_max, (int)std::max(itH, std::max(itV, itC)));
+    }
+    lines_max = items_max;
+    b->lines_max = items_max;
+    // field + edge-length tables + 3 item bitmasks + worklists (u16 item ids; the claim bitmask aliases them)
+    const size_t lw_max = ((size_t)items_max + 31) / 32 + 1;
     const size_t el_bytes = (size_t)(x_max + 2 + y_max + 2) * 4;
-    const size_t lds_need = (size_t)b->n_lds * 4 + ((size_t)b->n_lds / 32 + 1) * 4 + el_bytes + 3 * lw_max * 4 +
-                            (size_t)lines_max * 2 + 16;
+    const size_t list_bytes = std::max(((size_t)items_max * 2 + 3) & ~(size_t)3, ((size_t)b->n_lds / 32 + 1) * 4);
+    const size_t lds_need = (size_t)b->n_lds * 4 + el_bytes + 3 * lw_max * 4 + list_bytes + 16;
     b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && !b->cfg.force_scratch_field;
-    // worklist entries are 16-bit line ids within their kind: columns X*Y <= 65536, tracks <= 65536
-    if (ncol_max > 65536 || tracks_max > 65536)
-        return fail(XR_ERR_RANGE, "regions with more than 65536 columns or tracks are not supported (got %d / %d)", ncol_max, tracks_max);
     b->route_lds = b->lds_dist ? lds_need : el_bytes + 3 * lw_max * 4;
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
     const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;

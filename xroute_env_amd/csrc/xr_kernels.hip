@@ -154,88 +154,102 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 #define XR_W_UNREACHED 0xFFFFFFFDu    // | held << 1
 #define XR_W_BLOCK 0u                 // blockage (and padded register slots)
 
-// One Gauss-Seidel pass along a line of L nodes: node i lives at field[ix(i)].
+// One Gauss-Seidel pass along (a segment of) a line of L nodes: node i lives at field[ix(i)].
 // PLANAR: el4[i] = 4 * distance between node i-1 and node i of the line (LDS table);
 // else constant edge length len4c (via chain).
-// CH nodes are staged in registers per chunk and the NEXT chunk's loads are issued before the current
-// chunk's arithmetic (software pipeline).  The loop-carried dependency per node is three VALU ops
+// CH nodes are staged in registers per chunk.  The loop-carried dependency per node is three VALU ops
 // (saturating add -> compare -> select); everything else depends only on the loaded words:
 //     add_j  = 4*len + (held ? 4*pen : 0) + flags_j - flags_{j-1}      (blocked node: 0xFFFFFFFF)
 //     cand   = sat_add(w_{j-1}, add_j)                                  (= 4*d_cand + flags_j)
 //     lim_j  = min(w_j, (bound+1) << 2)                                 (blocked node in registers: 0xFFFFFFFF)
 //     w_j    = cand < lim_j ? cand : w_j
-// An unreached or blocked predecessor saturates the add, which can never pass `lim`.  The store is an
-// LDS atomic min of the (possibly unchanged) word: branch-free, and concurrent passes over crossing
-// lines lose no update.  EXACT: L == CH, single chunk, no bounds handling.
-// `mark(start, bits)` is called once per chunk with the lowered nodes (bit k <-> node start+k).  Returns 1 when
-// anything was lowered; ORs 2 into `flags` when a candidate was refused only because of the bound.
-template <bool FWD, bool PLANAR, int CH, bool EXACT, class IndexFn, class MarkFn>
-__device__ __forceinline__ int xr_line_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4, IndexFn ix,
-                                            int L, uint32_t len4c, uint32_t pen4, uint32_t boundw1, int& flags,
-                                            MarkFn mark) {
-    int lowered = 0;
+// An unreached or blocked predecessor saturates the add, which can never pass `lim`.  The store is an atomic min
+// (concurrent passes over crossing lines, or over other chunks of the same line, lose no update).
+// EXACT: L == CH, single chunk, no bounds handling.
+//
+// Worklist items are (line, chunk) pairs, chunk c = nodes [c*CH, (c+1)*CH) of the line.
+// The pass starts at chunk c0 with the node just before it (in the direction of travel) as predecessor, always
+// continues into the next chunk after the start chunk (the node that made the chunk dirty may be its boundary node)
+// and afterwards only while the boundary node of the chunk it just finished was lowered by this pass — an unchanged
+// boundary node cannot improve anything beyond it that its own lowering event (which queued its own item) has not
+// already covered.  The fixpoint is the one the full-line pass reaches; only the visiting order differs.
+// `mark(start, bits)`: lowered nodes of one chunk, bit k <-> node start + k (natural order in both directions).
+// `defer(c)`: a candidate was refused in chunk c only because of the bound.
+// COND_STORE (field in HBM scratch): only lowered nodes are stored — an L2 atomic per node is what bounds the
+// large-region variant; in LDS the unconditional min is cheaper than the branch.
+template <bool FWD, bool PLANAR, int CH, bool EXACT, bool COND_STORE, class IndexFn, class MarkFn, class DeferFn>
+__device__ __forceinline__ void xr_seg_pass(uint32_t* __restrict__ field, const uint32_t* __restrict__ el4, IndexFn ix,
+                                            int L, uint32_t len4c, uint32_t pen4, uint32_t boundw1, int c0,
+                                            MarkFn mark, DeferFn defer) {
     uint32_t prev = 0xFFFFFFFFu;       // "no predecessor": saturates
-    uint32_t pfl = 3u;                 // flag bits of the previous node's word
-    uint32_t refused = 0;
+    uint32_t pfl = 3u;
+    if (!EXACT) {
+        const int ip = FWD ? c0 * CH - 1 : (c0 + 1) * CH;
+        if (FWD ? (ip >= 0) : (ip < L)) {
+            const uint32_t pw = field[ix(ip)];
+            if (pw != XR_W_BLOCK) { prev = pw; pfl = pw & 3u; }
+        }
+    }
     uint32_t w[CH], el[CH];
-    auto load = [&](int i0, uint32_t (&ww)[CH], uint32_t (&ee)[CH]) {
-        const bool full = EXACT || (i0 + CH <= L);     // uniform over the wave's lines of one kind
+    // slot j of a chunk is node c*CH + j in both directions; the chain walks j upwards (FWD) or downwards
+    auto load = [&](int c, uint32_t (&ww)[CH], uint32_t (&ee)[CH]) {
+        const int i0 = c * CH;
+        const bool full = EXACT || (i0 + CH <= L);
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-            const int i = FWD ? (i0 + j) : (L - 1 - i0 - j);
-            const bool in = full || (FWD ? (i < L) : (i >= 0));
+            const int i = i0 + j;
+            const bool in = full || (i < L);
             ww[j] = in ? field[ix(i)] : XR_W_BLOCK;
             ee[j] = PLANAR ? (in ? el4[FWD ? i : i + 1] : 0u) : len4c;
         }
     };
-    load(0, w, el);
-    for (int i0 = 0; i0 < L; i0 += CH) {
+    const int nch = EXACT ? 1 : (L + CH - 1) / CH;
+    int c = EXACT ? 0 : c0;
+    load(c, w, el);
+    for (;;) {
         uint32_t wnx[CH], enx[CH];
-        const bool more = !EXACT && (i0 + CH < L);
-        if (more) load(i0 + CH, wnx, enx);
+        const int cn = FWD ? c + 1 : c - 1;
+        const bool more = !EXACT && (FWD ? (cn < nch) : (cn >= 0));
+        // LDS: the next chunk's loads are issued before this chunk's arithmetic (software pipeline).  HBM scratch:
+        // the kernel is bound by L2 transactions, not latency, so the next chunk is only loaded when it is visited
+        if (more && !COND_STORE) load(cn, wnx, enx);
+        const int i0 = c * CH;
         const bool full = EXACT || (i0 + CH <= L);
-        uint32_t cm = 0;                               // lowered nodes of this chunk, bit j
+        uint32_t cm = 0, refused = 0;
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int i = FWD ? (i0 + j) : (L - 1 - i0 - j);
-            const bool in = full || (FWD ? (i < L) : (i >= 0));
-            // ---- depends only on the loaded word (off the carried chain) ----
+        for (int jj = 0; jj < CH; jj++) {
+            const int j = FWD ? jj : CH - 1 - jj;
+            const int i = i0 + j;
+            const bool in = full || (i < L);
             const uint32_t cw = w[j];
             const bool blk = (cw == XR_W_BLOCK);
             const uint32_t cwr = blk ? 0xFFFFFFFFu : cw;
             const uint32_t fl = cwr & 3u;
             const uint32_t add = blk ? 0xFFFFFFFFu : (__umul24((cw >> 1) & 1u, pen4) + el[j] + fl - pfl);
             const uint32_t lim = min(cwr, boundw1);
-            // ---- carried chain: saturating add, compare, select ----
             const uint32_t cand = __builtin_elementwise_add_sat(prev, add);
             const bool acc = cand < lim;
             const uint32_t wn = acc ? cand : cwr;
-            // ---- side results ----
             refused |= (cand < cwr && !acc && cand < 0xF0000000u) ? 1u : 0u;
             cm |= acc ? (1u << j) : 0u;
-            if (in) atomicMin(&field[ix(i)], wn);     // `in` is wave-uniform; blocked: min(0, ~0) = 0
+            if (COND_STORE ? acc : in) atomicMin(&field[ix(i)], wn);      // (acc implies a real node)
             prev = wn;
             pfl = fl;
         }
-        if (cm) {       // report the lowered nodes of this chunk: bit k of `bits` <-> node start + k
-            lowered = 1;
-            if (FWD) mark(i0, cm);
-            else {
-                // bit j of cm is node L-1-i0-j: reverse the CH-bit group; bit 0 is then node L-CH-i0 (may be < 0 in
-                // the last partial chunk: those slots are padding and never lowered)
-                const uint32_t r = __brev(cm) >> (32 - CH);
-                const int lo = L - CH - i0;
-                if (lo >= 0) mark(lo, r); else mark(0, r >> (-lo));
-            }
-        }
-        if (more) {
+        if (cm) mark(i0, cm);
+        if (refused) defer(c);
+        if (!more) break;
+        // boundary node of this chunk in the direction of travel: slot CH-1 (FWD) / slot 0 (BWD); a partial last chunk
+        // only occurs as the final chunk of a forward pass, where `more` is already false
+        const bool boundary_lowered = (cm >> (FWD ? CH - 1 : 0)) & 1u;
+        if (c != c0 && !boundary_lowered) break;
+        c = cn;
+        if (COND_STORE) load(c, w, el);
+        else {
 #pragma unroll
             for (int j = 0; j < CH; j++) { w[j] = wnx[j]; el[j] = enx[j]; }
         }
-        if (EXACT) break;
     }
-    if (refused) flags |= 2;
-    return lowered;
 }
 
 // OR a run of up to 32 consecutive bits (ids id0 + k for every set bit k of `bits`) into a bitmask
@@ -283,7 +297,7 @@ struct XrLayout {
 // many layers (single exact chunk).
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, char* smem) {
-    __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // padded field index of each access point
+    __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // field index of each access point
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_hl[XR_MAX_LAYERS], s_vl[XR_MAX_LAYERS];
@@ -331,25 +345,31 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
     const int tracks_h = nh_layers * Y;            // lines along x, one per (y, horizontal layer)
     const int tracks_v = nv_layers * X;            // lines along y, one per (x, vertical layer)
     const int ntracks = tracks_h + tracks_v;
-    // line bitmask layout: [0, ntracks) tracks | [ntracks, ntracks + ncol) columns as x*Y + y
-    const int colA0 = ntracks;
-    const int nbits = ntracks + ncol;
+    // worklist items are (line, chunk of XR_CH nodes) pairs.  Item bitmask layout:
+    //   [0, itH) x-tracks * chH | [itV0, itC0) y-tracks * chV | [itC0, nbits) columns (x*Y + y) * chC
+    const int chH = (X + XR_CH - 1) / XR_CH, chV = (Y + XR_CH - 1) / XR_CH;
+    const int chC = (ZCH > 0) ? 1 : (Z + XR_CH - 1) / XR_CH;
+    const int itH = tracks_h * chH, itV = tracks_v * chV, itC = ncol * chC;
+    const int itV0 = itH, itC0 = itH + itV;
+    const int nbits = itC0 + itC;
     const int nlw = (nbits + 31) >> 5;
+    (void)ntracks;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
 
-    // carve (LDS variant):   field u32[n_lds] | claim u32[n_lds/32+1] | el4x | el4y | dirty0 | dirty1 | deferred
-    //                        u32[lw_max] each | lists u16[lines_max]
+    // carve (LDS variant):   field u32[n_lds] | el4x | el4y | dirty0 | dirty1 | deferred u32[lw_max] each |
+    //                        lists u16[lines_max], aliased by the claim bitmask u32[n_lds/32+1] (the lists are dead
+    //                        while a path is traced, the claim bitmask is dead while lines are relaxed)
     // (large-region variant): field, claim bitmask and the worklists live in per-env HBM scratch; the edge tables
-    //                        and the three line bitmasks stay in LDS
+    //                        and the three item bitmasks stay in LDS
     uint32_t* field;
     uint32_t* s_claim;
     uint32_t* s_el4x;
     const int claim_words = (NL + 31) >> 5;
     if (LDS_DIST) {
         field = reinterpret_cast<uint32_t*>(smem);
-        s_claim = field + b.n_lds;
-        s_el4x = s_claim + (b.n_lds / 32 + 1);
+        s_claim = nullptr;                       // set below (aliases the lists)
+        s_el4x = field + b.n_lds;
     } else {
         field = b.dist_scratch + (int64_t)e * b.n_lds;
         s_claim = reinterpret_cast<uint32_t*>(b.cls_scratch + (int64_t)e * b.n_lds);   // n_lds bytes >= bitmask
@@ -361,9 +381,10 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
     uint32_t* s_defer = s_dirty1 + b.lw_max;
     unsigned short* s_list = LDS_DIST ? reinterpret_cast<unsigned short*>(s_defer + b.lw_max)
                                       : b.list_scratch + (int64_t)e * b.lines_max;
+    if (LDS_DIST) s_claim = reinterpret_cast<uint32_t*>(s_list);
     unsigned short* s_listH = s_list;
-    unsigned short* s_listV = s_list + tracks_h;
-    unsigned short* s_listC = s_list + ntracks;
+    unsigned short* s_listV = s_list + itV0;
+    unsigned short* s_listC = s_list + itC0;
 
     // ---- grid build: field word of every node for THIS net (coalesced 16-byte loads of the state) --
     {
@@ -404,7 +425,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
             }
         }
     }
-    for (int i = tid; i < claim_words; i += nthr) s_claim[i] = 0;
+    if (!LDS_DIST) for (int i = tid; i < claim_words; i += nthr) s_claim[i] = 0;
     for (int i = tid; i < nlw; i += nthr) { s_dirty0[i] = 0; s_dirty1[i] = 0; s_defer[i] = 0; }
     // edge length tables (x4): el4x[i] = 4*(xs[i]-xs[i-1]), 0 at both ends
     for (int i = tid; i <= X; i += nthr)
@@ -435,8 +456,10 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
     auto mark_node = [&](uint32_t* mask, int l) {
         int x, y, z;
         lay.decode(l, x, y, z);
-        const int tr = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
-        const int cl = colA0 + x * Y + y;
+        const bool vert = (ldir >> z) & 1u;
+        // s_ztrk[z]: first track id of layer z (x-tracks 0.., y-tracks tracks_h..)
+        const int tr = vert ? itV0 + (s_ztrk[z] - tracks_h + x) * chV + y / XR_CH : (s_ztrk[z] + y) * chH + x / XR_CH;
+        const int cl = itC0 + (x * Y + y) * chC + (ZCH > 0 ? 0 : z / XR_CH);
         atomicOr(&mask[tr >> 5], 1u << (tr & 31));
         atomicOr(&mask[cl >> 5], 1u << (cl & 31));
     };
@@ -489,18 +512,18 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
                         cur[wi] = 0;
                         // per kind: reserve a run in the list with one atomic, then fill it
                         uint32_t mh = 0, mv = 0, mc = 0;
-                        if (id0 + 32 <= tracks_h) mh = m;
-                        else if (id0 >= colA0) mc = m;
-                        else if (id0 >= tracks_h && id0 + 32 <= ntracks) mv = m;
+                        if (id0 + 32 <= itH) mh = m;
+                        else if (id0 >= itC0) mc = m;
+                        else if (id0 >= itV0 && id0 + 32 <= itC0) mv = m;
                         else {
                             for (uint32_t t = m; t; t &= t - 1) {
                                 const int bit = __ffs((int)t) - 1, id = id0 + bit;
-                                if (id < tracks_h) mh |= 1u << bit; else if (id < ntracks) mv |= 1u << bit; else mc |= 1u << bit;
+                                if (id < itH) mh |= 1u << bit; else if (id < itC0) mv |= 1u << bit; else mc |= 1u << bit;
                             }
                         }
                         if (mh) { int o = atomicAdd(&s_cnt[parity][0], __popc(mh)); for (; mh; mh &= mh - 1) s_listH[o++] = (unsigned short)(id0 + __ffs((int)mh) - 1); }
-                        if (mv) { int o = atomicAdd(&s_cnt[parity][1], __popc(mv)); for (; mv; mv &= mv - 1) s_listV[o++] = (unsigned short)(id0 + __ffs((int)mv) - 1 - tracks_h); }
-                        if (mc) { int o = atomicAdd(&s_cnt[parity][2], __popc(mc)); for (; mc; mc &= mc - 1) s_listC[o++] = (unsigned short)(id0 + __ffs((int)mc) - 1 - colA0); }
+                        if (mv) { int o = atomicAdd(&s_cnt[parity][1], __popc(mv)); for (; mv; mv &= mv - 1) s_listV[o++] = (unsigned short)(id0 + __ffs((int)mv) - 1 - itV0); }
+                        if (mc) { int o = atomicAdd(&s_cnt[parity][2], __popc(mc)); for (; mc; mc &= mc - 1) s_listC[o++] = (unsigned short)(id0 + __ffs((int)mc) - 1 - itC0); }
                     }
                 }
                 __syncthreads();
@@ -519,61 +542,71 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
             const int offV = (nH + 63) & ~63, offC = offV + ((nV + 63) & ~63);
             const int total = offC + nC;
             for (int k = tid; k < total; k += nthr) {
-                int fl = 0;
-                int line = -1;                              // canonical line id (for `deferred`)
                 if (k < offV) {
                     if (k < nH) {
-                        const int t = (int)s_listH[k];
+                        const int it = (int)s_listH[k];
+                        const int t = it / chH, c0 = it - t * chH;
                         const int zi = t / Y, y = t - zi * Y;
                         const int base = lay.idx(0, y, s_hl[zi]), stride = lay.LDS_DIST ? lay.SX : 1;
                         auto ix = [=](int i) { return base + i * stride; };
-                        // lowered node x: column (x, y) must be looked at
+                        // lowered node x: column (x, y) must be looked at (the chunk of the column holding this layer)
+                        const int zc = (ZCH > 0) ? 0 : (int)s_hl[zi] / XR_CH;
                         auto mk = [&](int start, uint32_t bits) {
                             while (bits) {
-                                const int id = colA0 + (start + __ffs((int)bits) - 1) * Y + y; bits &= bits - 1;
+                                const int id = itC0 + ((start + __ffs((int)bits) - 1) * Y + y) * chC + zc; bits &= bits - 1;
                                 atomicOr(&nxt[id >> 5], 1u << (id & 31));
                             }
                         };
-                        xr_line_pass<true, true, XR_CH, false>(field, s_el4x, ix, X, 0u, pen4, bound4, fl, mk);
-                        xr_line_pass<false, true, XR_CH, false>(field, s_el4x, ix, X, 0u, pen4, bound4, fl, mk);
-                        line = t;
+                        auto df = [&](int c) { const int id = t * chH + c; atomicOr(&s_defer[id >> 5], 1u << (id & 31)); };
+                        xr_seg_pass<true, true, XR_CH, false, !LDS_DIST>(field, s_el4x, ix, X, 0u, pen4, bound4, c0, mk, df);
+                        xr_seg_pass<false, true, XR_CH, false, !LDS_DIST>(field, s_el4x, ix, X, 0u, pen4, bound4, c0, mk, df);
                     }
                 } else if (k < offC) {
                     if (k - offV < nV) {
-                        const int t = (int)s_listV[k - offV];
+                        const int it = (int)s_listV[k - offV];
+                        const int t = it / chV, c0 = it - t * chV;
                         const int zi = t / X, x = t - zi * X;
                         const int base = lay.idx(x, 0, s_vl[zi]), stride = lay.LDS_DIST ? lay.SY : 1;
                         auto ix = [=](int i) { return base + i * stride; };
-                        auto mk = [&](int start, uint32_t bits) { xr_or_run(nxt, colA0 + x * Y + start, bits); };
-                        xr_line_pass<true, true, XR_CH, false>(field, s_el4y, ix, Y, 0u, pen4, bound4, fl, mk);
-                        xr_line_pass<false, true, XR_CH, false>(field, s_el4y, ix, Y, 0u, pen4, bound4, fl, mk);
-                        line = tracks_h + t;
+                        const int zc = (ZCH > 0) ? 0 : (int)s_vl[zi] / XR_CH;
+                        auto mk = [&](int start, uint32_t bits) {
+                            if (chC == 1) xr_or_run(nxt, itC0 + x * Y + start, bits);
+                            else while (bits) {
+                                const int id = itC0 + (x * Y + start + __ffs((int)bits) - 1) * chC + zc; bits &= bits - 1;
+                                atomicOr(&nxt[id >> 5], 1u << (id & 31));
+                            }
+                        };
+                        auto df = [&](int c) { const int id = itV0 + t * chV + c; atomicOr(&s_defer[id >> 5], 1u << (id & 31)); };
+                        xr_seg_pass<true, true, XR_CH, false, !LDS_DIST>(field, s_el4y, ix, Y, 0u, pen4, bound4, c0, mk, df);
+                        xr_seg_pass<false, true, XR_CH, false, !LDS_DIST>(field, s_el4y, ix, Y, 0u, pen4, bound4, c0, mk, df);
                     }
                 } else {
-                    const int c = (int)s_listC[k - offC];
+                    const int it = (int)s_listC[k - offC];
+                    const int c = it / chC, c0 = it - c * chC;
                     const int x = c / Y, y = c - x * Y;
-                    // lowered node z: its track must be looked at
+                    // lowered node z: the chunk of its track that holds this column must be looked at
                     auto mk = [&](int start, uint32_t bits) {
                         while (bits) {
                             const int z = start + __ffs((int)bits) - 1; bits &= bits - 1;
-                            const int id = s_ztrk[z] + (((ldir >> z) & 1u) ? x : y);
+                            const bool vert = (ldir >> z) & 1u;
+                            const int id = vert ? itV0 + (s_ztrk[z] - tracks_h + x) * chV + y / XR_CH
+                                                : (s_ztrk[z] + y) * chH + x / XR_CH;
                             atomicOr(&nxt[id >> 5], 1u << (id & 31));
                         }
                     };
-                    // via chain: unit stride in the LDS layout; one word per layer plane in the layer-major layout
+                    auto df = [&](int cc) { const int id = itC0 + c * chC + cc; atomicOr(&s_defer[id >> 5], 1u << (id & 31)); };
+                    // via chain: unit stride in the packed layout; one word per layer plane in the layer-major layout
                     const bool packed = lay.LDS_DIST;
                     const int cbase = packed ? lay.idx(x, y, 0) : 0, offh = y * X + x, offv = x * Y + y, xy = lay.XY;
                     auto ix = [=](int z) { return packed ? cbase + z : z * xy + (((ldir >> z) & 1u) ? offv : offh); };
                     if (ZCH > 0) {
-                        xr_line_pass<true, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, ix, ZCH, via4, pen4, bound4, fl, mk);
-                        xr_line_pass<false, false, (ZCH > 0 ? ZCH : 1), true>(field, nullptr, ix, ZCH, via4, pen4, bound4, fl, mk);
+                        xr_seg_pass<true, false, (ZCH > 0 ? ZCH : 1), true, !LDS_DIST>(field, nullptr, ix, ZCH, via4, pen4, bound4, 0, mk, df);
+                        xr_seg_pass<false, false, (ZCH > 0 ? ZCH : 1), true, !LDS_DIST>(field, nullptr, ix, ZCH, via4, pen4, bound4, 0, mk, df);
                     } else {
-                        xr_line_pass<true, false, XR_CH, false>(field, nullptr, ix, Z, via4, pen4, bound4, fl, mk);
-                        xr_line_pass<false, false, XR_CH, false>(field, nullptr, ix, Z, via4, pen4, bound4, fl, mk);
+                        xr_seg_pass<true, false, XR_CH, false, !LDS_DIST>(field, nullptr, ix, Z, via4, pen4, bound4, c0, mk, df);
+                        xr_seg_pass<false, false, XR_CH, false, !LDS_DIST>(field, nullptr, ix, Z, via4, pen4, bound4, c0, mk, df);
                     }
-                    line = colA0 + c;
                 }
-                if (fl & 2) atomicOr(&s_defer[line >> 5], 1u << (line & 31));
             }
             nsweeps++;
             __syncthreads();        // (workgroup-scope: also orders the HBM-scratch field of the large-region variant)
@@ -584,6 +617,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
 
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
         if (tid < 64) {
+            if (LDS_DIST) for (int i = tid; i < claim_words; i += 64) s_claim[i] = 0;   // aliases the (dead) worklists
             unsigned long long best = ~0ULL;
             for (int i = tid; i < nap; i += 64) {
                 if (s_ap_conn[i]) continue;
