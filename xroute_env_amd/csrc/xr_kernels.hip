@@ -168,11 +168,10 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // EXACT: L == CH, single chunk, no bounds handling.
 //
 // Worklist items are (line, chunk) pairs, chunk c = nodes [c*CH, (c+1)*CH) of the line.
-// The pass starts at chunk c0 with the node just before it (in the direction of travel) as predecessor, always
-// continues into the next chunk after the start chunk (the node that made the chunk dirty may be its boundary node)
-// and afterwards only while the boundary node of the chunk it just finished was lowered by this pass — an unchanged
-// boundary node cannot improve anything beyond it that its own lowering event (which queued its own item) has not
-// already covered.  The fixpoint is the one the full-line pass reaches; only the visiting order differs.
+// The pass starts at chunk c0 with the node just before it (in the direction of travel) as predecessor and enters the
+// next chunk only if that chunk's first node is lowered by the boundary node of the chunk just finished: a node that
+// is not lowered passes nothing new on (whatever lowered it earlier queued its own item).  The fixpoint is the one
+// the full-line pass reaches; only the visiting order differs.
 // `mark(start, bits)`: lowered nodes of one chunk, bit k <-> node start + k (natural order in both directions).
 // `defer(c)`: a candidate was refused in chunk c only because of the bound.
 // COND_STORE (field in HBM scratch): only lowered nodes are stored — an L2 atomic per node is what bounds the
@@ -239,10 +238,21 @@ __device__ __forceinline__ void xr_seg_pass(uint32_t* __restrict__ field, const 
         if (cm) mark(i0, cm);
         if (refused) defer(c);
         if (!more) break;
-        // boundary node of this chunk in the direction of travel: slot CH-1 (FWD) / slot 0 (BWD); a partial last chunk
-        // only occurs as the final chunk of a forward pass, where `more` is already false
-        const bool boundary_lowered = (cm >> (FWD ? CH - 1 : 0)) & 1u;
-        if (c != c0 && !boundary_lowered) break;
+        // continue into the next chunk only if its first node (in the direction of travel) is lowered by the boundary
+        // node of this one; if it is not, nothing beyond it can change either
+        {
+            const int jn = FWD ? 0 : CH - 1;
+            const int in = cn * CH + jn;                   // always a real node
+            const uint32_t nw = COND_STORE ? field[ix(in)] : wnx[jn];
+            if (nw == XR_W_BLOCK) break;
+            const uint32_t nel = PLANAR ? (COND_STORE ? el4[FWD ? in : in + 1] : enx[jn]) : len4c;
+            const uint32_t nadd = __umul24((nw >> 1) & 1u, pen4) + nel + (nw & 3u) - pfl;
+            const uint32_t ncand = __builtin_elementwise_add_sat(prev, nadd);
+            if (!(ncand < min(nw, boundw1))) {
+                if (ncand < nw && ncand < 0xF0000000u) defer(cn);      // refused only because of the bound
+                break;
+            }
+        }
         c = cn;
         if (COND_STORE) load(c, w, el);
         else {
