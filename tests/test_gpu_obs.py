@@ -111,3 +111,33 @@ def test_step_observe_scalar_path_and_odd_dims():
                 env.step(acts[i])
             ro = env.observation()
             assert np.array_equal(ro.ravel(), o[i, :ro.size])
+
+
+def test_split_observation_many_envs_and_two_legal_words():
+    """XR_OBS_SPLIT against XR_OBS_FUSED over 2500 env slots (the planning kernel's prefix scan spans three 1024-env
+    blocks), K up to 80 (two 64-bit legal words per env), auto-reset with rotation — byte-equal observations."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(6400 + i, dims=(16, 16, 4), k_range=(1, 80) if i % 3 else (66, 80), net_span=6,
+                               pins=(2, 2), aps=(1, 1)) for i in range(37)]
+    B = 2500
+    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=2, max_route_count=1, obs_writer_blocks=96)
+    b = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=1, max_route_count=1)
+    assert a.legal_words == 2
+    a.reset(); b.reset()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    oa = torch.full((B, a.obs_env_stride), -3.0, device="cuda:0")
+    ob = torch.full((B, a.obs_env_stride), -3.0, device="cuda:0")
+    N = regions[0].n_nodes
+    for it in range(90):
+        a.random_actions(77 + it, acts)
+        if it % 7 == 0:
+            acts[::5] = 999                       # out-of-range actions: flagged no-ops
+        a.step(acts, oa)
+        b.step(acts, ob)
+        if it % 10 == 9 or it < 3:
+            assert a.observe_timing()[0] == 2 and b.observe_timing()[0] == 1
+            k = a.fetch("nlegal")
+            assert torch.equal(k, b.fetch("nlegal")) and torch.equal(a.fetch("region"), b.fetch("region"))
+            valid = (torch.arange(a.obs_env_stride, device="cuda:0")[None, :] < ((2 + 7 * k.long()) * N)[:, None])
+            assert torch.equal(torch.where(valid, oa, 0), torch.where(valid, ob, 0)), it
+    assert int(a.fetch("region").max()) >= 30            # slots rotated through the region list
