@@ -71,6 +71,17 @@ def test_route_parity_odd_dims(dims):
     _run_episode_parity(regions, policy="min")
 
 
+@pytest.mark.parametrize("scratch", [False, True])
+@pytest.mark.parametrize("dims", [(8, 17, 10), (17, 8, 16), (9, 16, 17), (25, 24, 8), (40, 41, 13)])
+def test_route_parity_chunk_boundaries(dims, scratch):
+    """Line lengths around the 8-node chunk size of the segment sweeps (8, 9, 16, 17, 24, 25, 40, 41 nodes; generic
+    via columns of 1, 2 and 3 chunks), dense blockage, field in LDS and in HBM scratch."""
+    n = dims[0] * dims[1] * dims[2]
+    regions = [generate_region(4200 + 13 * i + n, dims=dims, k_range=(3, 9), net_span=8, blockage=(0.2, 0.35))
+               for i in range(5)]
+    assert _run_episode_parity(regions, policy="random", force_scratch_field=scratch) >= 15
+
+
 def test_route_parity_policies_and_costs():
     regions = [generate_region(4500 + i, dims=(14, 17, 6), k_range=(5, 12)) for i in range(8)]
     _run_episode_parity(regions, policy="max")
