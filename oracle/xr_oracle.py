@@ -119,7 +119,10 @@ class OracleEnv:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().xro_env_destroy(self.h)
+            try:
+                lib().xro_env_destroy(self.h)
+            except Exception:          # interpreter shutdown: module globals may already be gone
+                pass
             self.h = None
 
     def reset(self):
