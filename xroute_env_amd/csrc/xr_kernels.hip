@@ -1161,6 +1161,11 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
     if (tid == 0) b.plan_off[b.n_envs] = s_carry;
 }
 
+#ifdef XR_NP_PLAIN
+#define XR_NP_ST4(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#else
+#define XR_NP_ST4(ptr, val) XR_ST4(ptr, val)
+#endif
 #define XR_NP_J 9            // float4 groups per thread per tile: 256 threads * 4 nodes * 9 = 9216 nodes
 __global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
     const int tid = threadIdx.x;
@@ -1204,6 +1209,10 @@ __global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
                 bits[j] = m;
             }
             // plane 0 of the net: AP mask; planes 1..6: the six aliased "has a same-net axis neighbour" planes
+#ifndef XR_NP_ORDER
+#define XR_NP_ORDER 1
+#endif
+#if XR_NP_ORDER == 0       // plane-major: the workgroup writes the unit as one sequential run
 #pragma unroll 1
             for (int pl = 0; pl < 7; pl++) {
                 float* __restrict__ pp = out + (int64_t)pl * N;
@@ -1216,10 +1225,26 @@ __global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
                         float4 v;
                         v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 2u) ? 1.f : 0.f;
                         v.z = (m & 4u) ? 1.f : 0.f; v.w = (m & 8u) ? 1.f : 0.f;
-                        XR_ST4(pp + ((int64_t)g << 2), v);
+                        XR_NP_ST4(pp + ((int64_t)g << 2), v);
                     }
                 }
             }
+#else                      // rotation: 4 KB of each of the 7 planes in turn (the step kernel's own order)
+#pragma unroll
+            for (int j = 0; j < XR_NP_J; j++) {
+                const int g = g0 + j * 256 + tid;
+                if (g < ngrp) {
+                    float* __restrict__ pp = out + ((int64_t)g << 2);
+                    const unsigned m0 = bits[j], m1 = bits[j] >> 4;
+                    float4 v0, v1;
+                    v0.x = (m0 & 1u) ? 1.f : 0.f; v0.y = (m0 & 2u) ? 1.f : 0.f; v0.z = (m0 & 4u) ? 1.f : 0.f; v0.w = (m0 & 8u) ? 1.f : 0.f;
+                    v1.x = (m1 & 1u) ? 1.f : 0.f; v1.y = (m1 & 2u) ? 1.f : 0.f; v1.z = (m1 & 4u) ? 1.f : 0.f; v1.w = (m1 & 8u) ? 1.f : 0.f;
+                    XR_NP_ST4(pp, v0);
+#pragma unroll
+                    for (int pl = 1; pl < 7; pl++) XR_NP_ST4(pp + (int64_t)pl * N, v1);
+                }
+            }
+#endif
         }
     }
 }
