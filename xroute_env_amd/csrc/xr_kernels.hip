@@ -5,7 +5,10 @@
 //   xr_route_kernel       Game.step: grid build -> XR-Maze v1 maze route -> claim path -> metrics
 //                         one workgroup per env; distance field resident in LDS (<= ~32k nodes)
 //                         or in a per-env HBM scratch (larger regions)
+//                         + (xr_batch_step_observe) the observation of the new state by the same workgroup
+//   xr_order_kernel       whole-order re-route (A3C / MCTS contracts): reset + route a list of nets, one launch
 //   xr_obs_kernel         build_3Dgrid: compact state -> fp32 [2+7K, Z, Y, X] observation, streaming
+//   xr_plan_kernel, xr_netplane_kernel   the split form of the step's observation (XR_OBS_SPLIT)
 //   xr_random_action_kernel
 //
 // Integer / index work throughout: no MFMA.  What matters here is coalescing (every sweep is
@@ -110,22 +113,23 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // so any relaxation order that reaches the fixpoint gives the oracle's (Dijkstra's) field; the
 // target choice and the back-trace are deterministic functions of that field.
 //
-// Relaxation = line sweeps ("fast sweeping" on the routing graph).  A *line* is a track (one
+// Relaxation = line-segment sweeps ("fast sweeping" on the routing graph).  A *line* is a track (one
 // preferred-direction row of one layer: x-lines on horizontal layers, y-lines on vertical layers) or
-// a column (the via chain of one (x,y)).  One thread takes one line and runs a forward and a backward
-// Gauss-Seidel pass over it, staged through registers 8 nodes at a time; after the two passes the
-// line is internally exact, so a distance travels any straight run in ONE visit.  Edge lengths come
-// from two small LDS tables (4*(xs[i]-xs[i-1]), same for ys): a wave's lanes read one address.
+// a column (the via chain of one (x,y)); a worklist *item* is a (line, chunk of XR_CH nodes) pair.  One thread
+// takes one item and runs a forward and a backward Gauss-Seidel pass that start at that chunk, staged through
+// registers 8 nodes at a time, and run on along the line for as long as nodes keep getting lowered (xr_seg_pass),
+// so a distance still travels any straight run in ONE visit.  Edge lengths come from two small LDS tables
+// (4*(xs[i]-xs[i-1]), same for ys): a wave's lanes read one address.
 //
-// Which lines to visit: a dirty-line worklist.  A node lowered by a line pass marks the one other line
-// through that node dirty (atomic OR into an LDS bitmask); every iteration compacts the dirty bitmask
-// into dense per-kind worklists (kinds start on wave boundaries, so waves are full and uniform) and
-// processes them.  A search starts with only the lines through its source nodes dirty, so work follows
-// the wavefront instead of sweeping the whole region.
+// Which items to visit: a worklist.  A node lowered by a pass marks the item of the one other line through that
+// node dirty (atomic OR into an LDS bitmask); every iteration compacts the dirty bitmask into dense per-kind
+// worklists (kinds start on wave boundaries, so waves are full and uniform) and processes them.  A search starts
+// with only the items through its source nodes dirty, so work follows the wavefront instead of sweeping the
+// whole region, and a visit costs what the affected segment costs, not what the line costs.
 //
 // Pruning: nothing above `bound` (= best distance of any unconnected target so far) is written; every
 // node with true distance <= the final target distance still gets its exact value (induction along
-// its shortest path), so the target choice and the back-trace are unchanged.  A line on which a
+// its shortest path), so the target choice and the back-trace are unchanged.  An item in which a
 // candidate was refused by the bound is remembered (`deferred`) and re-dirtied when the next search of
 // the same net resets the bound.  Later pins re-use the field: every value is still an upper bound
 // once the new path nodes are set to 0, so relaxation continues instead of restarting.
@@ -136,9 +140,9 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 //     0xFFFFFFFD | (held << 1) = unreached.  Distances >= XR_DIST_CAP (0x30000000) do not exist (spec,
 //     mirrored by the oracle): candidates are capped there, which makes u32 wrap-around impossible.
 //
-// Two placements of the same code (template LDS_DIST): field + claim bitmask + worklists in LDS (regions up to
-// ~38 k field words: 39.3 KB per workgroup at 24x40x9, 4 workgroups per CU), or in per-env HBM scratch with only
-// the line bitmasks and edge tables in LDS (larger regions; correct, not tuned).
+// Two placements of the same code (template LDS_DIST): field + worklists (aliased by the claim bitmask) in LDS
+// (regions up to ~38 k field words: 39.9 KB per workgroup at 24x40x9, 4 workgroups per CU), or in per-env HBM scratch
+// with only the item bitmasks and edge tables in LDS (larger regions: stores only lowered nodes, loads chunks on demand).
 // ------------------------------------------------------------------------------------------------
 #ifdef XR_PHASE_TIMING
 #define XR_T0() long long _t = (threadIdx.x == 0) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
