@@ -195,6 +195,12 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
 int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t stride, int32_t* net_stats_dev,
                              void* stream);
 
+/* Placement of the step kernel for the loaded regions: resident workgroups per CU as the HIP runtime computes it
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor) and LDS bytes per workgroup (dynamic + static).  ispd18_test1-sized
+ * regions are laid out for 4 workgroups per CU (4 x 39.9 KB of the 160 KB); a build that loses that is slower by a
+ * quarter, so the tests check it. */
+int32_t xr_batch_route_occupancy(xr_batch* b, int32_t* workgroups_per_cu, int64_t* lds_bytes_per_workgroup);
+
 /* Duration in milliseconds (HIP events on the library's internal stream) of the net-plane writer kernel that the
  * last xr_batch_step_observe launched in XR_OBS_SPLIT mode; blocks until that kernel has finished.  *mode_out = the
  * mode that call ran in (XR_OBS_FUSED / XR_OBS_SPLIT); *writer_ms = 0 for XR_OBS_FUSED. */

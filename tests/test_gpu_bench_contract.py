@@ -35,3 +35,14 @@ def test_bench_json_contract(extra):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
     # value is consistent with the reported step time: real env-steps <= slots
     assert d["value"] <= 256 * 1 / (d["ms_per_step"] * 1e-3) * 1.001
+
+
+@pytest.mark.gpu
+def test_step_kernel_keeps_four_workgroups_per_cu_on_ispd_sized_regions():
+    """The LDS budget of the step kernel at 24x40x9 is laid out for 4 workgroups per CU; 3 would cost a
+    quarter of the throughput without failing any parity test."""
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+    batch = RegionBatch(config_regions(3, 8), device="cuda:0")
+    wgs, lds = batch.route_occupancy()
+    assert wgs == 4 and lds <= 160 * 1024 // 4, (wgs, lds)

@@ -25,7 +25,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 SYMBOLS = [
     "xr_abi_version", "xr_last_error", "xr_config_default", "xr_device_count",
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
-    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
+    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 

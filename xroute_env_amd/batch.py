@@ -131,6 +131,12 @@ class RegionBatch:
                                                         _stream_ptr(self.device)))
         return obs_out
 
+    def route_occupancy(self):
+        """(resident workgroups per CU, LDS bytes per workgroup) of the step kernel for the loaded regions."""
+        n, lds = C.c_int32(0), C.c_int64(0)
+        _lib.check(self.L.xr_batch_route_occupancy(self._h, C.byref(n), C.byref(lds)))
+        return int(n.value), int(lds.value)
+
     def observe_timing(self):
         """(mode, writer_ms) of the last step(actions, obs_out): mode 1 = fused launch, 2 = split (route kernel and
         net-plane writer running concurrently); writer_ms = HIP-event duration of the writer kernel (0 when fused)."""

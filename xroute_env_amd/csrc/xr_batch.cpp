@@ -20,6 +20,7 @@ hipError_t xr_launch_ingest(const uint32_t*, int16_t*, int16_t*, int64_t, hipStr
 hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
 hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
+hipError_t xr_route_occupancy(int, int, size_t, int, int*, size_t*);
 hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
 hipError_t xr_launch_netplanes(const XrBatchDev*, int, hipStream_t);
 hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
@@ -528,6 +529,18 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     XR_HIP(xr_launch_netplanes(&d, b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : 512, b->aux_stream));
     XR_HIP(hipEventRecord(b->ev_w1, b->aux_stream));
     XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
+    return XR_OK;
+}
+
+int32_t xr_batch_route_occupancy(xr_batch* b, int32_t* workgroups_per_cu, int64_t* lds_bytes_per_workgroup) {
+    if (!b || !workgroups_per_cu || !lds_bytes_per_workgroup) return fail(XR_ERR_INVALID, "xr_batch_route_occupancy: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_route_occupancy: load regions first");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    int n = 0;
+    size_t stat = 0;
+    XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &n, &stat));
+    *workgroups_per_cu = n;
+    *lds_bytes_per_workgroup = (int64_t)(b->route_lds + stat);
     return XR_OK;
 }
 

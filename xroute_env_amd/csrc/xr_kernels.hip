@@ -16,6 +16,7 @@
 // field, and wave64-wide relaxation.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "xr_device.h"
 #include "../../include/xroute_hip.h"
@@ -311,7 +312,9 @@ struct XrLayout {
 // many layers (single exact chunk).
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, char* smem) {
-    __shared__ int s_ap_l[XR_MAX_AP_PER_NET];          // field index of each access point
+    // field index of each access point: 16 bits are enough for any field that fits LDS (<= 40 k words)
+    using ApIndex = typename std::conditional<LDS_DIST, unsigned short, int>::type;
+    __shared__ ApIndex s_ap_l[XR_MAX_AP_PER_NET];
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_hl[XR_MAX_LAYERS], s_vl[XR_MAX_LAYERS];
@@ -451,7 +454,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
     for (int i = tid; i < nap; i += nthr) {
         const int f = b.ap_node[R.ap_off + ap_lo + i];
         const int z = f % Z, y = (f / Z) % Y, x = f / (Y * Z);
-        s_ap_l[i] = lay.idx(x, y, z);
+        s_ap_l[i] = (ApIndex)lay.idx(x, y, z);
         s_ap_pin[i] = b.ap_pin[R.ap_off + ap_lo + i];
         s_ap_conn[i] = 0;
     }
@@ -654,7 +657,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
                 const int best_l = lay.idx(bf / (Y * Z), (bf / Z) % Y, bf % Z);
                 for (int i0 = 0; i0 < nap && best_i < 0; i0 += 64) {
                     const int i = i0 + tid;
-                    const unsigned long long m = __ballot(i < nap && s_ap_l[i] == best_l);
+                    const unsigned long long m = __ballot(i < nap && (int)s_ap_l[i] == best_l);
                     if (m) best_i = i0 + __ffsll((long long)m) - 1;
                 }
             }
@@ -1365,6 +1368,21 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
         else hipLaunchKernelGGL((xr_order_kernel<false, 0>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     }
     return hipGetLastError();
+}
+
+// resident workgroups per CU of the step kernel as the runtime would place it, and its static LDS
+hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threads, int* wg_per_cu, size_t* static_lds) {
+    const void* fn = lds_dist ? (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 9>)
+                                 : zch == 12 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 12>)
+                                             : reinterpret_cast<const void*>(&xr_route_kernel<true, 0>))
+                              : (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<false, 9>)
+                                 : zch == 12 ? reinterpret_cast<const void*>(&xr_route_kernel<false, 12>)
+                                             : reinterpret_cast<const void*>(&xr_route_kernel<false, 0>));
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, fn);
+    if (e != hipSuccess) return e;
+    *static_lds = attr.sharedSizeBytes;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, fn, threads, lds_bytes);
 }
 
 hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream_t st) {
