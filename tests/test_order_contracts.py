@@ -7,6 +7,7 @@ the CPU oracle.  GPU part: xr_batch_route_order against the oracle stepped net b
 on the GPU against the same classes on the oracle.
 """
 import json
+from struct import error as struct_error
 
 import numpy as np
 import pytest
@@ -327,3 +328,46 @@ def test_gpu_contracts_equal_oracle_contracts():
         fg, rg, dg, lg = gv.step(acts.to("cuda:0")); fo, ro, do, lo = ov.step(acts)
         assert torch.equal(fg.cpu(), fo) and torch.equal(rg.cpu(), ro) and torch.equal(dg.cpu(), do) and torch.equal(lg.cpu(), lo)
     assert bool(do.all())
+
+
+# ------------------------------------------------------------------------------------------------ wire fuzz
+def test_proto_ext_random_roundtrip_and_garbage():
+    rng = np.random.default_rng(17)
+    for it in range(60):
+        n = int(rng.integers(0, 6))
+        fields = np.zeros((n, 10), np.int32)
+        fields[:, 0:6] = rng.integers(-3, 300000, (n, 6))
+        fields[:, 6] = rng.integers(0, 3, n); fields[:, 7] = rng.integers(0, 2, n)
+        fields[:, 8] = rng.integers(-1, 40, n); fields[:, 9] = rng.integers(-1, 9, n)
+        nets = rng.integers(0, 50, int(rng.integers(0, 5))).astype(np.uint32)
+        v1 = proto.encode_request((3, 4, 5), fields, (0, 0, 0), bool(it % 2), nets)
+        kw = dict(openroad=[int(v) for v in rng.integers(-5, 90000, int(rng.integers(0, 4)))],
+                  xroute=[int(v) for v in rng.integers(-5, 90000, int(rng.integers(0, 4)))],
+                  count_map='{"0": 2}' if it % 3 == 0 else "", metrics_delta='{"1": [0, 7, 1]}' if it % 4 == 0 else "",
+                  routed_nets=[int(v) for v in rng.integers(0, 70000, int(rng.integers(0, 4)))],
+                  region_coords=[int(v) for v in rng.integers(-10 ** 6, 10 ** 6, int(rng.integers(0, 5)))],
+                  node_properties=[[float(np.float32(v)) for v in rng.random(11)] for _ in range(int(rng.integers(0, 4)))],
+                  edge_connections=[[int(a), int(b)] for a, b in rng.integers(0, 30, (int(rng.integers(0, 4)), 2))],
+                  signed_rewards=[int(v) for v in rng.integers(-70000, 70000, 3)])
+        raw = proto_ext.append_request_extras(v1, **kw)
+        ex = proto_ext.decode_extras(raw)
+        assert ex.is_request and ex.openroad == kw["openroad"] and ex.xroute == kw["xroute"]
+        assert ex.count_map == kw["count_map"] and ex.metrics_delta == kw["metrics_delta"]
+        assert ex.routed_nets == kw["routed_nets"] and ex.region_coords == kw["region_coords"]
+        assert ex.node_properties == kw["node_properties"] and ex.edge_connections == kw["edge_connections"]
+        assert ex.rewards_signed == kw["signed_rewards"]
+        msg = proto.decode_message(raw)                      # the C decoder skips what it does not know
+        assert msg.fields.tolist() == fields.tolist() and msg.nets.tolist() == nets.tolist()
+        # truncations and bit flips never crash or hang: they raise or decode to something
+        for cut in (1, 2, len(raw) // 2):
+            try:
+                proto_ext.decode_extras(raw[:-cut])
+            except ValueError:
+                pass
+        bad = bytearray(raw)
+        for k in rng.integers(0, len(raw), 3):
+            bad[int(k)] ^= 0xFF
+        try:
+            proto_ext.decode_extras(bytes(bad))
+        except (ValueError, UnicodeDecodeError, struct_error):
+            pass
