@@ -18,6 +18,7 @@ ap.add_argument("--envs", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--env-chunk", type=int, default=128)
 ap.add_argument("--net-chunk", type=int, default=512)
+ap.add_argument("--no-cache", action="store_true", help="run the net tower for every (env, net) at every step")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -30,11 +31,17 @@ batch.observation(obs)
 dims = regions[0].dims
 
 
+cache = None if args.no_cache else agents.NetVectorCache(len(regions), batch.k_max, dev)
+
+
 def act():
     nl = batch.fetch("nlegal")
+    kw = dict(env_chunk=args.env_chunk, net_chunk=args.net_chunk)
+    if cache is not None:
+        kw.update(cache=cache, region=batch.fetch("region"))
     if args.agent == "dqn":
-        return agents.dqn_actions(model, obs, nl, dims, env_chunk=args.env_chunk, net_chunk=args.net_chunk)
-    return agents.ppo_actions(model, obs, nl, dims, env_chunk=args.env_chunk, net_chunk=args.net_chunk)[0]
+        return agents.dqn_actions(model, obs, nl, dims, **kw)
+    return agents.ppo_actions(model, obs, nl, dims, **kw)[0]
 
 
 a = act(); batch.step(a, obs)                       # warm-up (MIOpen kernel selection)
@@ -48,7 +55,8 @@ for it in range(args.steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 real = batch.total_steps() - s0
-print(json.dumps({"agent": args.agent, "envs": args.envs, "steps": args.steps,
+print(json.dumps({"agent": args.agent, "envs": args.envs, "steps": args.steps, "net_vector_cache": cache is not None,
+                  "net_grids_through_the_tower": None if cache is None else cache.computed,
                   "agent_attached_env_steps_per_s": real / dt, "ms_per_step": dt / args.steps * 1e3,
                   "agent_ms_per_step": t_agent / args.steps * 1e3,
                   "env_ms_per_step": (dt - t_agent) / args.steps * 1e3}))
