@@ -99,7 +99,8 @@ typedef struct xr_config {
     double  w_via;            /* 4    */
     double  w_wirelength;     /* 0.5  */
     int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer (0 = default) */
-    int32_t reserved1;        /* must be 0 */
+    int32_t obs_split_permille; /* XR_OBS_SPLIT: per mille of every env's net planes (its highest-ranked nets) that the
+                                   writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all) */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */

@@ -36,7 +36,7 @@ class XrConfig(C.Structure):
                 ("max_route_count", C.c_int32), ("auto_reset", C.c_int32), ("path_cap", C.c_int32),
                 ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("obs_mode", C.c_int32),
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
-                ("obs_writer_blocks", C.c_int32), ("reserved1", C.c_int32)]
+                ("obs_writer_blocks", C.c_int32), ("obs_split_permille", C.c_int32)]
 
 
 class XrRegionDesc(C.Structure):

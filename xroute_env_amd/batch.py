@@ -35,7 +35,8 @@ class RegionBatch:
     def __init__(self, regions: Sequence[Region], n_envs: Optional[int] = None, device="cuda:0",
                  auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
-                 force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0):
+                 force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
+                 obs_split_permille: int = 0):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -51,6 +52,7 @@ class RegionBatch:
         cfg.force_scratch_field = int(force_scratch_field)
         cfg.obs_mode = int(obs_mode)                    # 0 default, 1 fused single launch, 2 split (route || net-plane writer)
         cfg.obs_writer_blocks = int(obs_writer_blocks)
+        cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))

@@ -148,7 +148,7 @@ void xr_config_default(xr_config* c) {
     c->force_scratch_field = 0;
     c->obs_mode = 0;
     c->obs_writer_blocks = 0;
-    c->reserved1 = 0;
+    c->obs_split_permille = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -173,8 +173,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
     if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
-    if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_SPLIT || cfg->obs_writer_blocks < 0 || cfg->reserved1 != 0)
-        return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED or XR_OBS_SPLIT; obs_writer_blocks >= 0; reserved1 = 0");
+    if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_SPLIT || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
+        return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED or XR_OBS_SPLIT; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -437,7 +437,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
-    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0;
+    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
     d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.plan_off = b->plan_off.p;
     if (!b->aux_stream) {
         XR_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
@@ -521,6 +521,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
     // caller's stream -> join.  Everything is ordered by events; the host never waits.
     d.obs_head_only = 1;
+    d.obs_split_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 1000;
     XR_HIP(xr_launch_plan(&d, actions_dev, st));
     XR_HIP(hipEventRecord(b->ev_fork, st));
     XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));

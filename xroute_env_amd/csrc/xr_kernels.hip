@@ -1074,7 +1074,7 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
         float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
         if (b.obs_vec4 == 1) {
-            const int knets = b.obs_head_only ? 0 : K;
+            const int knets = b.obs_head_only ? K - (int)(((int64_t)K * b.obs_split_pm) / 1000) : K;
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
                 xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
         } else if (b.obs_vec4 == 2) {
@@ -1133,8 +1133,11 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
             }
             b.plan_region[e] = r;
         }
-        // block-wide exclusive scan of k
-        int incl = k;
+        // the writer kernel takes the highest floor(k * pm / 1000) ranks of every env, the step kernel the rest
+        const int kw = (int)(((int64_t)k * b.obs_split_pm) / 1000);
+        const int kskip = k - kw;
+        // block-wide exclusive scan of kw
+        int incl = kw;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int t = __shfl_up(incl, d, 64);
@@ -1145,7 +1148,7 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
         int woff = 0;
         for (int w = 0; w < wv; w++) woff += s_wsum[w];
         const int carry = s_carry;
-        const int off = carry + woff + incl - k;
+        const int off = carry + woff + incl - kw;
         if (e < b.n_envs) {
             b.plan_off[e] = off;
             int j = 0;
@@ -1155,8 +1158,10 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
                 while (m) {
                     const int bit = __ffsll((unsigned long long)m) - 1;
                     m &= m - 1;
-                    b.plan_units[off + j] = ((uint32_t)e << 14) | (uint32_t)j;
-                    b.plan_unit_net[off + j] = (w << 6) + bit + 1;
+                    if (j >= kskip) {
+                        b.plan_units[off + j - kskip] = ((uint32_t)e << 14) | (uint32_t)j;
+                        b.plan_unit_net[off + j - kskip] = (w << 6) + bit + 1;
+                    }
                     j++;
                 }
             }
