@@ -86,6 +86,26 @@ def cpu_baseline(regions, seconds, with_obs=True):
                       f"oracle/xr_oracle.c OpenMP over envs, host cpu '{model}' ({os.cpu_count()} logical)"}
 
 
+def parity_check(regions, seeds, gpu_hash, gpu_cum, n_check=256):
+    """Checker leg (oracle as the CHECKER, never the thing measured): replays the bench's own action sequence — the
+    device policy is a counter-based hash of (seed, env, step count), bit-identical in the oracle — on the first
+    `n_check` envs and compares every env's hash chain (all path nodes, metrics and actions of every step) and
+    cumulative metrics with what the GPU produced during the timed run."""
+    import numpy as np
+    from oracle import xr_oracle as orc
+    n = min(len(regions), n_check)
+    ob = orc.OracleBatch(regions[:n])
+    threads = ob.max_threads()
+    steps = 0
+    for sd in seeds:
+        steps += ob.step(ob.random_actions(sd), threads=threads, auto_reset=True)["real_steps"]
+    ref_hash = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
+    ref_cum = np.stack([e.cum() for e in ob.envs])
+    return {"envs": n, "env_steps": int(steps), "hash_chains_equal": bool(np.array_equal(ref_hash, gpu_hash[:n])),
+            "cumulative_metrics_equal": bool(np.array_equal(ref_cum, gpu_cum[:n])),
+            "what": "CPU oracle replay of the same actions on the first envs of rank 0, all warm-up + timed steps"}
+
+
 def main():
     args = parse()
     import torch
@@ -249,6 +269,13 @@ def main():
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
+        if world == 1 and not args.no_cpu_baseline and not args.region_pack and len(regions) >= B:
+            try:        # regions == env slots: rotation keeps every slot on its region, the oracle subset can follow
+                seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
+                out["parity"] = parity_check(regions, seeds, batch.fetch("hash").cpu().numpy().view("uint64"),
+                                             batch.fetch("cum").cpu().numpy())
+            except Exception as ex:
+                out["parity"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=obs is not None)

@@ -33,6 +33,8 @@ def test_bench_json_contract(extra):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
+    p = d["parity"]                                  # the checker leg: oracle replay of the run's own actions
+    assert p["hash_chains_equal"] is True and p["cumulative_metrics_equal"] is True and p["env_steps"] > 0 and p["envs"] == 256
     # value is consistent with the reported step time: real env-steps <= slots
     assert d["value"] <= 256 * 1 / (d["ms_per_step"] * 1e-3) * 1.001
 
