@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0/1 fused launch, 2 split (route kernel || net-plane writer)")
+    ap.add_argument("--writer-blocks", type=int, default=0)
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
                          "synthetic generator; NOT the headline workload")
@@ -141,7 +143,8 @@ def main():
         regions = load_region_pack(args.region_pack)
     else:
         regions = config_regions(args.config, B, first_env=rank * B)
-    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads)
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
+                        obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()

@@ -176,8 +176,8 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
  *                 writer kernel streams all net planes on an internal stream, and the route kernel — running
  *                 concurrently on the caller's stream — writes planes 0..1.  The caller's stream is joined with
  *                 the internal one before the call returns control of the stream (event wait, no host sync).
- *                 Needs every region's N % 4 == 0 and a 16-byte aligned out_dev / env_stride % 4 == 0; otherwise
- *                 the call runs XR_OBS_FUSED. */
+ *                 Needs a 16-byte aligned out_dev and env_stride % 4 == 0 (regions whose N is not a multiple of 4 take
+ *                 a writer that resolves plane boundaries per float); otherwise the call runs XR_OBS_FUSED. */
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
 

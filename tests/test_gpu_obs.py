@@ -141,3 +141,29 @@ def test_split_observation_many_envs_and_two_legal_words():
             valid = (torch.arange(a.obs_env_stride, device="cuda:0")[None, :] < ((2 + 7 * k.long()) * N)[:, None])
             assert torch.equal(torch.where(valid, oa, 0), torch.where(valid, ob, 0)), it
     assert int(a.fetch("region").max()) >= 30            # slots rotated through the region list
+
+
+@pytest.mark.parametrize("permille", [1000, 400])
+def test_split_observation_unaligned_planes(permille):
+    """XR_OBS_SPLIT on regions whose N is not a multiple of 4 (planes start at arbitrary float offsets): the stream
+    form of the net-plane writer + the step kernel's partial stream must reproduce xr_batch_step +
+    xr_batch_observation byte for byte and touch nothing behind an env's last plane."""
+    from xroute_env_amd.batch import RegionBatch
+    dims = [(7, 9, 3), (5, 7, 3), (9, 11, 5), (6, 7, 3)]
+    regions = [generate_region(6500 + i, dims=dims[i % 4], k_range=(1, 9), net_span=4) for i in range(23)]
+    B = 300
+    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=2, max_route_count=2,
+                    obs_writer_blocks=40, obs_split_permille=permille)
+    b = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
+    a.reset(); b.reset()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    oa = torch.full((B, a.obs_env_stride), -7.0, device="cuda:0")
+    ob = torch.full((B, a.obs_env_stride), -7.0, device="cuda:0")
+    for it in range(40):
+        a.random_actions(900 + it, acts)
+        oa.fill_(-7.0); ob.fill_(-7.0)
+        a.step(acts, oa)
+        b.step(acts); b.observation(ob)
+        assert a.observe_timing()[0] == 2
+        assert torch.equal(a.fetch("hash"), b.fetch("hash")) and torch.equal(a.fetch("region"), b.fetch("region"))
+        assert torch.equal(oa, ob), it                    # includes the untouched -7 padding behind every env's planes

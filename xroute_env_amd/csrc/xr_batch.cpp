@@ -22,7 +22,7 @@ hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_route_occupancy(int, int, size_t, int, int*, size_t*);
 hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
-hipError_t xr_launch_netplanes(const XrBatchDev*, int, hipStream_t);
+hipError_t xr_launch_netplanes(const XrBatchDev*, int, int, hipStream_t);
 hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
@@ -511,7 +511,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     const bool aligned = (env_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool can_split = d.obs_vec4 == 1 && b->cfg.n_envs <= (1 << 18) && b->k_max < (1 << 14) && b->k_max >= 1;
+    const bool can_split = (d.obs_vec4 == 1 || (d.obs_vec4 == 2 && b->n_max <= 60 * 1024)) && b->cfg.n_envs <= (1 << 18) && b->k_max < (1 << 14) && b->k_max >= 1;
     const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT;      // default: fused (measured faster)
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
     if (!split) {
@@ -527,7 +527,8 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
     XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));
     XR_HIP(hipEventRecord(b->ev_w0, b->aux_stream));
-    XR_HIP(xr_launch_netplanes(&d, b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : 512, b->aux_stream));
+    XR_HIP(xr_launch_netplanes(&d, b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : 512, d.obs_vec4 == 1 ? 1 : 0,
+                               b->aux_stream));
     XR_HIP(hipEventRecord(b->ev_w1, b->aux_stream));
     XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
     return XR_OK;

@@ -25,6 +25,9 @@ struct XrRegionDev {
 };
 
 // Everything a kernel needs, passed by value.
+// nets of an env with K nets left whose planes the step kernel writes itself in the split form
+#define XR_SPLIT_KEEP(b, K) ((K) - (int)(((int64_t)(K) * (b).obs_split_pm) / 1000))
+
 struct XrBatchDev {
     // regions (static)
     const XrRegionDev* regions;

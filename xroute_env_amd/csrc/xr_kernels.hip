@@ -945,7 +945,7 @@ __device__ __forceinline__ float xr_plane_value(unsigned ft, int plane, int node
 
 template <class Src>
 __device__ __forceinline__ void xr_obs_env_stream(const Src& src, int X, int Y, int Z, int N, const int* s_ids, int K,
-                                                  float* __restrict__ out, unsigned short* s_feat) {
+                                                  float* __restrict__ out, unsigned short* s_feat, int planes = -1) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int f = tid; f < N; f += nthr) {
         float obst; int apnet; bool adj;
@@ -953,7 +953,8 @@ __device__ __forceinline__ void xr_obs_env_stream(const Src& src, int X, int Y, 
         s_feat[f] = (unsigned short)(apnet | (adj ? 0x4000 : 0) | (obst != 0.f ? 0x8000 : 0));
     }
     __syncthreads();
-    const long long total = (long long)(2 + 7 * K) * N;          // floats
+    // `planes` >= 0: only the first `planes` planes are written here (split form: the rest comes from the writer kernel)
+    const long long total = (long long)(planes >= 0 ? planes : 2 + 7 * K) * N;          // floats
     const long long nslot = total >> 2;
     int plane = (int)((4LL * tid) / N), node = (int)((4LL * tid) - (long long)plane * N);
     const int dplane = (4 * nthr) / N, dnode = (4 * nthr) - dplane * N;
@@ -1074,12 +1075,13 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
         float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
         if (b.obs_vec4 == 1) {
-            const int knets = b.obs_head_only ? K - (int)(((int64_t)K * b.obs_split_pm) / 1000) : K;
+            const int knets = b.obs_head_only ? XR_SPLIT_KEEP(b, K) : K;
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
                 xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
         } else if (b.obs_vec4 == 2) {
             unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
-            xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat);
+            const int planes = b.obs_head_only ? 2 + 7 * XR_SPLIT_KEEP(b, K) : -1;
+            xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat, planes);
         } else {
             for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
                 xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
@@ -1133,9 +1135,9 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
             }
             b.plan_region[e] = r;
         }
-        // the writer kernel takes the highest floor(k * pm / 1000) ranks of every env, the step kernel the rest
-        const int kw = (int)(((int64_t)k * b.obs_split_pm) / 1000);
-        const int kskip = k - kw;
+        // the step kernel keeps the lowest XR_SPLIT_KEEP ranks of every env, the writer kernel takes the rest
+        const int kskip = XR_SPLIT_KEEP(b, k);
+        const int kw = k - kskip;
         // block-wide exclusive scan of kw
         int incl = kw;
 #pragma unroll
@@ -1258,6 +1260,87 @@ __global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
             }
 #endif
         }
+    }
+}
+
+// The same units for regions whose N is not a multiple of 4 (design-derived regions): a unit's 7*N floats start at
+// float (2+7*rank)*N of the env's row, 16-byte aligned only by chance.  Per unit the workgroup reduces the net's two
+// node masks to one byte per node in LDS, then writes the unit's float range as aligned float4 slots (plane and node
+// of a slot resolved per float where a slot straddles two planes) plus at most 3 scalar floats at either end.
+__global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // two bits per node, 16 nodes per word: bit 2i = node is an AP of the net, bit 2i+1 = ... with a same-net neighbour
+    uint32_t* s_m = reinterpret_cast<uint32_t*>(smem);
+    const int tid = threadIdx.x;
+    const int total = b.plan_off[b.n_envs];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        const uint32_t ent = b.plan_units[u];
+        const int id = b.plan_unit_net[u];
+        const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
+        const XrRegionDev R = b.regions[b.plan_region[e]];
+        const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
+        const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+        const int nwords = (N + 15) >> 4;
+        for (int w = tid; w <= nwords; w += 256) {                 // one spare word: the funnel shift reads w + 1
+            const int f0 = w << 4;
+            // 16 nodes = two 16-byte loads (node_off is a multiple of 8 elements), issued before any compare
+            int pk[8];
+            if (f0 + 16 <= N) {
+                const int4 v0 = *reinterpret_cast<const int4*>(nn + f0), v1 = *reinterpret_cast<const int4*>(nn + f0 + 8);
+                pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int fa = f0 + 2 * i, fb = fa + 1;
+                    const int lo = fa < N ? (int)(unsigned short)nn[fa] : 0, hi = fb < N ? (int)(unsigned short)nn[fb] : 0;
+                    pk[i] = lo | (hi << 16);
+                }
+            }
+            uint32_t hit = 0;                                      // bit i: node f0 + i is an access point of the net
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int v = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xFFFF);
+                hit |= (v == id && f0 + i < N) ? (1u << i) : 0u;
+            }
+            uint32_t m = 0;
+            while (hit) {                                          // rare: ~1 % of the nodes
+                const int i = __ffs((int)hit) - 1; hit &= hit - 1;
+                const int f = f0 + i;
+                const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+                const bool adj = (x + 1 < X && nn[f + YZ] == id) || (y > 0 && nn[f - Z] == id) || (x > 0 && nn[f - YZ] == id) ||
+                                 (y + 1 < Y && nn[f + Z] == id) || (z + 1 < Z && nn[f + 1] == id) || (z > 0 && nn[f - 1] == id);
+                m |= (adj ? 3u : 1u) << (2 * i);
+            }
+            s_m[w] = m;
+        }
+        __syncthreads();
+        float* __restrict__ row = b.obs_out + (int64_t)e * b.obs_stride;          // 16-byte aligned
+        const long long a = (long long)(2 + 7 * rank) * N;                       // first float of the unit
+        auto bits8 = [&](int f) {                 // masks of nodes f .. f+3 (2 bits each) in the low byte
+            const int bit = f << 1, w = bit >> 5, sh = bit & 31;
+            return __funnelshift_r(s_m[w], s_m[w + 1], sh);
+        };
+        for (int pl = 0; pl < 7; pl++) {
+            const long long p0 = a + (long long)pl * N, p1 = p0 + N;               // this plane's float range
+            const long long s0 = (p0 + 3) >> 2, s1 = p1 >> 2;                      // aligned slots fully inside it
+            const int sel = pl ? 1 : 0;
+            for (long long sl = s0 + tid; sl < s1; sl += 256) {
+                const uint32_t m = bits8((int)((sl << 2) - p0)) >> sel;
+                float4 v;
+                v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
+                XR_ST4(row + (sl << 2), v);
+            }
+            // ragged ends of the plane: at most 3 floats each (the whole plane when it holds no aligned slot)
+            auto one = [&](long long g) { const int f = (int)(g - p0); return ((s_m[f >> 4] >> (((f & 15) << 1) + sel)) & 1u) ? 1.f : 0.f; };
+            if (s0 < s1) {
+                const int nh = (int)((s0 << 2) - p0), nt = (int)(p1 - (s1 << 2));
+                if (tid < nh) row[p0 + tid] = one(p0 + tid);
+                else if (tid >= 64 && tid - 64 < nt) row[(s1 << 2) + (tid - 64)] = one((s1 << 2) + (tid - 64));
+            } else {
+                for (long long g = p0 + tid; g < p1; g += 256) row[g] = one(g);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1395,8 +1478,9 @@ hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream
     return hipGetLastError();
 }
 
-hipError_t xr_launch_netplanes(const XrBatchDev* b, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(xr_netplane_kernel, dim3(blocks), dim3(256), 0, st, *b);
+hipError_t xr_launch_netplanes(const XrBatchDev* b, int blocks, int aligned, hipStream_t st) {
+    if (aligned) hipLaunchKernelGGL(xr_netplane_kernel, dim3(blocks), dim3(256), 0, st, *b);
+    else hipLaunchKernelGGL(xr_netplane_stream_kernel, dim3(blocks), dim3(256), (size_t)(((b->n_max + 15) / 16 + 2) * 4), st, *b);
     return hipGetLastError();
 }
 
