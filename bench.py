@@ -116,9 +116,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # XR_BENCH_BACKEND=gloo + XR_BENCH_SAME_DEVICE=1: run the N > 1 control flow (barriers, max-over-ranks timing, the
+    # batched-env gather) with every rank on cuda:0 of a single-GPU box — a functional check of this path, not a
+    # measurement; the driver's multi-GPU runs use the default (RCCL, one rank per GPU)
+    backend = os.environ.get("XR_BENCH_BACKEND", "nccl")
+    if os.environ.get("XR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)

@@ -48,3 +48,22 @@ def test_step_kernel_keeps_four_workgroups_per_cu_on_ispd_sized_regions():
     batch = RegionBatch(config_regions(3, 8), device="cuda:0")
     wgs, lds = batch.route_occupancy()
     assert wgs == 4 and lds <= 160 * 1024 // 4, (wgs, lds)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """The N > 1 path of bench.py (rendezvous, barriers, max-over-ranks timing, per-step gather of the env records, one
+    JSON line from rank 0) with two ranks sharing cuda:0 over gloo: a functional check on a single-GPU box."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, XR_BENCH_BACKEND="gloo", XR_BENCH_SAME_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--envs", "128"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_envs"] == 256 and "cpu_baseline" not in d and "RCCL all_gather" in d["config"]["workload"]
