@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--agent", choices=["dqn", "ppo"], default="dqn")
 ap.add_argument("--envs", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--env-chunk", type=int, default=128)
+ap.add_argument("--env-chunk", type=int, default=1024)
 ap.add_argument("--net-chunk", type=int, default=512)
 ap.add_argument("--no-cache", action="store_true", help="run the net tower for every (env, net) at every step")
 args = ap.parse_args()
