@@ -12,10 +12,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 regions = config_regions(3, B)
 venv = XRouteVectorEnv(regions)
 q_net = agents.RepActor().to(venv.device).eval()
+cache = agents.NetVectorCache(len(regions), venv.batch.k_max, venv.device)   # net vectors: once per (region, net)
 obs, info = venv.reset()
 ret = torch.zeros(B, dtype=torch.float64, device=venv.device)
 for t in range(4):
-    actions = agents.dqn_actions(q_net, obs, info["nlegal"], regions[0].dims)      # int32 [B], 1-based net ids
+    actions = agents.dqn_actions(q_net, obs, info["nlegal"], regions[0].dims,      # int32 [B], 1-based net ids
+                                 cache=cache, region=info["region"])
     obs, reward, done, info = venv.step(actions)
     ret += reward
     print(f"step {t}: mean reward {reward.mean().item():.1f}, done {int(done.sum())}/{B}")

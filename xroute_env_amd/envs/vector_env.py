@@ -27,26 +27,32 @@ class XRouteVectorEnv:
         self.delta = torch.empty((self.n_envs, 3), dtype=torch.int32, device=self.device)
         self.nlegal = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
         self.legal = torch.empty((self.n_envs, self.batch.legal_words), dtype=torch.int64, device=self.device)
+        self.region = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
 
-    def _collect(self):
+    def _collect(self, observe: bool):
         b = self.batch
-        if self.with_observation:
+        if observe and self.with_observation:
             b.observation(self.obs)
         b.fetch("reward", self.reward)
         b.fetch("done", self.done)
         b.fetch("delta", self.delta)
         b.fetch("nlegal", self.nlegal)
         b.fetch("legal", self.legal)
-        return self.obs, self.reward, self.done, {"delta": self.delta, "nlegal": self.nlegal, "legal": self.legal}
+        b.fetch("region", self.region)          # the region every slot is playing (key of agents.NetVectorCache)
+        return self.obs, self.reward, self.done, {"delta": self.delta, "nlegal": self.nlegal, "legal": self.legal,
+                                                  "region": self.region}
 
     def reset(self):
         self.batch.reset(rotate=True)
-        obs, _, _, info = self._collect()
+        obs, _, _, info = self._collect(observe=True)
         return obs, info
 
     def step(self, actions: torch.Tensor):
+        if self.with_observation:
+            self.batch.step(actions, self.obs)          # one fused launch: route + observation of every env
+            return self._collect(observe=False)
         self.batch.step(actions)
-        return self._collect()
+        return self._collect(observe=False)
 
     def random_actions(self, seed: int, out: Optional[torch.Tensor] = None):
         return self.batch.random_actions(seed, out)
