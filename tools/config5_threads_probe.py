@@ -4,7 +4,7 @@ import torch
 from xroute_env_amd.batch import RegionBatch
 from xroute_env_amd.regions import config_regions
 regions = config_regions(5, 8)
-for B, thr in ((1024, 0), (1024, 512), (1024, 256), (2048, 0), (2048, 512)):
+for B, thr in ((256, 0), (1024, 0), (1024, 512), (1024, 256), (2048, 0), (2048, 512)):
     batch = RegionBatch(regions, n_envs=B, auto_reset=True, block_threads=thr)
     batch.reset()
     acts = torch.empty(B, dtype=torch.int32, device="cuda:0")

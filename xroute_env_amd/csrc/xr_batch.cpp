@@ -347,6 +347,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     const size_t lds_need = (size_t)b->n_lds * 4 + el_bytes + 3 * lw_max * 4 + list_bytes + 16;
     b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && !b->cfg.force_scratch_field;
     b->route_lds = b->lds_dist ? lds_need : el_bytes + 3 * lw_max * 4;
+    // workgroup size of the step kernel unless the caller asks: 256 with the field in LDS (4 waves; 4 workgroups per CU
+    // resident at 24x40x9), 1024 with the field in HBM scratch (latency-bound on memory: more items in flight per env)
+    b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : (b->lds_dist ? 256 : 1024);
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
     const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;
     // flat-stream observation (any N): ids + a 16-bit feature per node in LDS
