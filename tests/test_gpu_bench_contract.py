@@ -48,6 +48,13 @@ def test_step_kernel_keeps_four_workgroups_per_cu_on_ispd_sized_regions():
     batch = RegionBatch(config_regions(3, 8), device="cuda:0")
     wgs, lds = batch.route_occupancy()
     assert wgs == 4 and lds <= 160 * 1024 // 4, (wgs, lds)
+    # xr_config.block_threads is honoured: 8 waves per workgroup halve the resident workgroups (register-bound)
+    wide = RegionBatch(config_regions(3, 8), device="cuda:0", block_threads=512)
+    assert wide.route_occupancy()[0] < wgs
+    # regions too large for LDS run 1024-thread workgroups by default
+    from xroute_env_amd.regions import generate_region
+    big = RegionBatch([generate_region(77, dims=(64, 64, 12), k_range=(3, 3), net_span=20)], device="cuda:0")
+    assert big.route_occupancy()[0] >= 1
 
 
 @pytest.mark.gpu
