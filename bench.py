@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
     ap.add_argument("--block-threads", type=int, default=0)
-    ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0/1 fused launch, 2 split (route kernel || net-plane writer)")
+    ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0 default (queue form where it applies), 1 fused launch, 2 split, 3 queue")
     ap.add_argument("--writer-blocks", type=int, default=0)
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
@@ -226,11 +226,21 @@ def main():
     route_bytes = float((4.0 * n_nodes).sum().item())
     kernels = []
     if fused:
-        kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": obs_bytes + route_bytes,
+        form = batch.observe_timing()[0]            # 1 fused launch, 2 split, 3 queue (the default where it applies)
+        if form == 3:
+            kname = "xr_step_queue_kernel"
+            note = ("step kernel, queue form (xr_batch_step_observe): one persistent launch whose workgroups drain two task "
+                    "queues — envs to route (LDS-resident field, latency-bound) + their planes 0..1, and net-plane units of "
+                    "the fp32 observation (HBM-write-bound); the HIP-event time also covers the planning kernel "
+                    "(xr_plan_kernel, ~10 us) that precedes it on the same stream; bytes = state load + observation")
+        else:
+            kname = "xr_route_kernel"
+            note = ("fused step kernel (xr_batch_step_observe): per env one workgroup routes the net (LDS-resident, "
+                    "latency-bound) and then streams the fp32 observation (HBM-write-bound); bytes = state load + observation"
+                    + ("; split form: the net planes come from xr_netplane_kernel on an internal stream" if form == 2 else ""))
+        kernels.append({"kernel": kname, "bound": "hbm", "ms": route_ms, "bytes": obs_bytes + route_bytes,
                         "achieved": (obs_bytes + route_bytes) / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
-                        "note": "fused step kernel (xr_batch_step_observe): per env one workgroup routes the net "
-                                "(LDS-resident, latency-bound) and then streams the fp32 observation (HBM-write-bound); "
-                                "bytes = state load + observation"})
+                        "note": note})
     else:
         if obs is not None:
             kernels.append({"kernel": "xr_obs_kernel", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
@@ -274,7 +284,7 @@ def main():
                                    +
                                    "full step = random net-order action + XR-Maze v1 route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
-                                   + (" (fused launch)" if fused else "")
+                                   + (" (one persistent launch after a planning kernel)" if fused and batch.observe_timing()[0] == 3 else " (fused launch)" if fused else "")
                                    + (", RCCL all_gather of per-env results" if world > 1 else ""),
                        "envs_per_gpu": B, "global_envs": B * world, "parallelism": f"env-shard x{world}",
                        "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (args.steps * B * world), 4)},

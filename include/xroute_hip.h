@@ -79,6 +79,7 @@ typedef struct xr_batch xr_batch;
  * its control plane (examples/launch_training.py:28). */
 #define XR_OBS_FUSED 1
 #define XR_OBS_SPLIT 2
+#define XR_OBS_QUEUE 3
 typedef struct xr_config {
     int32_t struct_size;      /* = sizeof(xr_config); checked */
     int32_t device;           /* HIP device ordinal */
@@ -93,14 +94,18 @@ typedef struct xr_config {
     int32_t block_threads;    /* route kernel workgroup size, 0 = default */
     int32_t force_scratch_field; /* 1: keep the distance field in HBM scratch even when it would fit LDS (the
                                     large-region code path; for tests and A/B measurements) */
-    int32_t obs_mode;         /* xr_batch_step_observe: 0 = default (= XR_OBS_FUSED, the faster one as measured),
-                                 XR_OBS_FUSED = one launch, XR_OBS_SPLIT = route kernel + concurrent net-plane writer */
+    int32_t obs_mode;         /* xr_batch_step_observe: 0 = default (XR_OBS_QUEUE where it applies, the fastest as measured,
+                                 else XR_OBS_FUSED), XR_OBS_FUSED = one launch of one workgroup per env, XR_OBS_SPLIT = route
+                                 kernel + concurrent net-plane writer, XR_OBS_QUEUE = planning kernel + one persistent launch */
     double  w_violation;      /* 500  */
     double  w_via;            /* 4    */
     double  w_wirelength;     /* 0.5  */
-    int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer (0 = default) */
+    int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer; XR_OBS_QUEUE: workgroups of the
+                                  persistent launch (0 = default: 512 / as many as are resident on the chip) */
     int32_t obs_split_permille; /* XR_OBS_SPLIT: per mille of every env's net planes (its highest-ranked nets) that the
-                                   writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all) */
+                                   writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all).
+                                   XR_OBS_QUEUE: units a workgroup writes after each route task, per mille of the average
+                                   number of units per env (0 = 750) */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */
@@ -168,7 +173,7 @@ int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, voi
 int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
 
 /* Game.step with its observation (baseline/baseline_utils.py:409-423: route, then build_3Dgrid on the new state),
- * out_dev / env_stride as in xr_batch_observation, for envs [0, n_envs).  Two forms, same result:
+ * out_dev / env_stride as in xr_batch_observation, for envs [0, n_envs).  Three forms, same bytes:
  *   XR_OBS_FUSED  one launch: every workgroup routes its env, then streams that env's observation.
  *   XR_OBS_SPLIT  the 7K net planes of an env do not depend on the routing result (they are functions of the
  *                 region's static node array and of which nets remain, which follows from the state before the
@@ -177,7 +182,11 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
  *                 concurrently on the caller's stream — writes planes 0..1.  The caller's stream is joined with
  *                 the internal one before the call returns control of the stream (event wait, no host sync).
  *                 Needs a 16-byte aligned out_dev and env_stride % 4 == 0 (regions whose N is not a multiple of 4 take
- *                 a writer that resolves plane boundaries per float); otherwise the call runs XR_OBS_FUSED. */
+ *                 a writer that resolves plane boundaries per float); otherwise the call runs XR_OBS_FUSED.
+ *   XR_OBS_QUEUE  (default) the same planning kernel, then ONE persistent launch on the caller's stream whose workgroups
+ *                 drain two task queues: envs to route (+ their planes 0..1) and net-plane units to write.  Units do not
+ *                 depend on routing, so they keep HBM busy while other workgroups route and the launch ends in a
+ *                 fine-grained pure-write drain instead of a tail of whole envs.  Same requirements as XR_OBS_SPLIT. */
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
 

@@ -63,11 +63,12 @@ def test_observation_subrange_and_strides():
         assert (out[j, n:] == -1).all()          # nothing written past the env's own channels
 
 
-@pytest.mark.parametrize("obs_mode", [1, 2])
+@pytest.mark.parametrize("obs_mode", [1, 2, 3])
 def test_step_observe_fused_equals_two_launches(obs_mode):
     """xr_batch_step_observe == xr_batch_step followed by xr_batch_observation, for every env and step
     (routing, auto-reset with region rotation and flagged no-op slots alike), in both forms: 1 = one fused launch,
-    2 = split (planning kernel + net-plane writer on the internal stream || route kernel writing planes 0..1)."""
+    2 = split (planning kernel + net-plane writer on the internal stream || route kernel writing planes 0..1),
+    3 = queue (planning kernel + one persistent launch draining route tasks and net-plane units)."""
     from xroute_env_amd.batch import RegionBatch
     regions = [generate_region(6200 + i, dims=(24, 40, 9), k_range=(1, 6)) for i in range(29)]
     a = RegionBatch(regions, n_envs=24, device="cuda:0", auto_reset=True, obs_mode=obs_mode, max_route_count=2)
@@ -113,14 +114,16 @@ def test_step_observe_scalar_path_and_odd_dims():
             assert np.array_equal(ro.ravel(), o[i, :ro.size])
 
 
-def test_split_observation_many_envs_and_two_legal_words():
+@pytest.mark.parametrize("obs_mode", [2, 3])
+def test_split_observation_many_envs_and_two_legal_words(obs_mode):
     """XR_OBS_SPLIT against XR_OBS_FUSED over 2500 env slots (the planning kernel's prefix scan spans three 1024-env
     blocks), K up to 80 (two 64-bit legal words per env), auto-reset with rotation — byte-equal observations."""
     from xroute_env_amd.batch import RegionBatch
     regions = [generate_region(6400 + i, dims=(16, 16, 4), k_range=(1, 80) if i % 3 else (66, 80), net_span=6,
                                pins=(2, 2), aps=(1, 1)) for i in range(37)]
     B = 2500
-    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=2, max_route_count=1, obs_writer_blocks=96)
+    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=obs_mode, max_route_count=1,
+                    obs_writer_blocks=96 if obs_mode == 2 else 0)
     b = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=1, max_route_count=1)
     assert a.legal_words == 2
     a.reset(); b.reset()
@@ -135,7 +138,7 @@ def test_split_observation_many_envs_and_two_legal_words():
         a.step(acts, oa)
         b.step(acts, ob)
         if it % 10 == 9 or it < 3:
-            assert a.observe_timing()[0] == 2 and b.observe_timing()[0] == 1
+            assert a.observe_timing()[0] == obs_mode and b.observe_timing()[0] == 1
             k = a.fetch("nlegal")
             assert torch.equal(k, b.fetch("nlegal")) and torch.equal(a.fetch("region"), b.fetch("region"))
             valid = (torch.arange(a.obs_env_stride, device="cuda:0")[None, :] < ((2 + 7 * k.long()) * N)[:, None])
@@ -143,8 +146,8 @@ def test_split_observation_many_envs_and_two_legal_words():
     assert int(a.fetch("region").max()) >= 30            # slots rotated through the region list
 
 
-@pytest.mark.parametrize("permille", [1000, 400])
-def test_split_observation_unaligned_planes(permille):
+@pytest.mark.parametrize("permille,obs_mode", [(1000, 2), (400, 2), (0, 3)])
+def test_split_observation_unaligned_planes(permille, obs_mode):
     """XR_OBS_SPLIT on regions whose N is not a multiple of 4 (planes start at arbitrary float offsets): the stream
     form of the net-plane writer + the step kernel's partial stream must reproduce xr_batch_step +
     xr_batch_observation byte for byte and touch nothing behind an env's last plane."""
@@ -152,7 +155,7 @@ def test_split_observation_unaligned_planes(permille):
     dims = [(7, 9, 3), (5, 7, 3), (9, 11, 5), (6, 7, 3)]
     regions = [generate_region(6500 + i, dims=dims[i % 4], k_range=(1, 9), net_span=4) for i in range(23)]
     B = 300
-    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=2, max_route_count=2,
+    a = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, obs_mode=obs_mode, max_route_count=2,
                     obs_writer_blocks=40, obs_split_permille=permille)
     b = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
     a.reset(); b.reset()
@@ -164,6 +167,6 @@ def test_split_observation_unaligned_planes(permille):
         oa.fill_(-7.0); ob.fill_(-7.0)
         a.step(acts, oa)
         b.step(acts); b.observation(ob)
-        assert a.observe_timing()[0] == 2
+        assert a.observe_timing()[0] == obs_mode
         assert torch.equal(a.fetch("hash"), b.fetch("hash")) and torch.equal(a.fetch("region"), b.fetch("region"))
         assert torch.equal(oa, ob), it                    # includes the untouched -7 padding behind every env's planes

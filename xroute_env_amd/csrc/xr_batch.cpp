@@ -22,6 +22,7 @@ hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_route_occupancy(int, int, size_t, int, int*, size_t*);
 hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
+hipError_t xr_launch_step_queue(const XrBatchDev*, const int32_t*, int, int, size_t, int, int, hipStream_t);
 hipError_t xr_launch_netplanes(const XrBatchDev*, int, int, hipStream_t);
 hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
@@ -113,7 +114,8 @@ struct xr_batch {
     DevBuf<unsigned short> list_scratch;
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net, plan_off;
-    DevBuf<uint32_t> plan_units;
+    DevBuf<uint32_t> plan_units, queue;
+    int n_cus = 0;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
     int last_obs_mode = 0;
@@ -173,7 +175,7 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
     if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
-    if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_SPLIT || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
+    if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_QUEUE || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED or XR_OBS_SPLIT; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
@@ -395,6 +397,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->total_steps, 1);
     XR_ALLOC(b->phase_cycles, (size_t)B * 8);
     XR_ALLOC(b->plan_region, B);
+    XR_ALLOC(b->queue, 2);
     XR_ALLOC(b->plan_off, (size_t)B + 1);
     XR_ALLOC(b->plan_units, (size_t)B * std::max(1, k_max));
     XR_ALLOC(b->plan_unit_net, (size_t)B * std::max(1, k_max));
@@ -441,7 +444,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
-    d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.plan_off = b->plan_off.p;
+    d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.plan_off = b->plan_off.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
     if (!b->aux_stream) {
         XR_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
         XR_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -515,7 +518,27 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool can_split = (d.obs_vec4 == 1 || (d.obs_vec4 == 2 && b->n_max <= 60 * 1024)) && b->cfg.n_envs <= (1 << 18) && b->k_max < (1 << 14) && b->k_max >= 1;
-    const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT;      // default: fused (measured faster)
+    const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT;
+    if (can_split && (b->cfg.obs_mode == XR_OBS_QUEUE || b->cfg.obs_mode == 0)) {      // the default: measured fastest
+        // plan, then one persistent launch: as many workgroups as the chip holds (occupancy x CUs) drain the two queues
+        b->last_obs_mode = XR_OBS_QUEUE;
+        d.obs_head_only = 1;
+        d.obs_split_pm = 1000;
+        d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
+        XR_HIP(xr_launch_plan(&d, actions_dev, st));
+        if (b->n_cus == 0) {
+            hipDeviceProp_t prop;
+            XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
+            b->n_cus = prop.multiProcessorCount;
+        }
+        int per_cu = 0;
+        size_t stat = 0;
+        XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &per_cu, &stat));
+        const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : std::max(1, per_cu) * b->n_cus;
+        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
+                                    std::min(blocks, 4 * b->cfg.n_envs), st));
+        return XR_OK;
+    }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
     if (!split) {
         XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));

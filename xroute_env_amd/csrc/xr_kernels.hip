@@ -148,7 +148,7 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 #ifdef XR_PHASE_TIMING
 #define XR_T0() long long _t = (threadIdx.x == 0) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define XR_LAP(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); _ph[k] += _n - _t; _t = _n; } } while (0)
-#define XR_TDUMP() do { if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) b.phase_cycles[(int64_t)blockIdx.x * 8 + _k] += _ph[_k]; } while (0)
+#define XR_TDUMP() do { if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) b.phase_cycles[(int64_t)e * 8 + _k] += _ph[_k]; } while (0)
 #else
 #define XR_T0() do {} while (0)
 #define XR_LAP(k) do {} while (0)
@@ -311,7 +311,7 @@ struct XrLayout {
 // ZCH: 0 = generic column pass (chunks of XR_CH); 9 / 12 = every region of the batch has exactly that
 // many layers (single exact chunk).
 template <bool LDS_DIST, int ZCH>
-__device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, char* smem) {
+__device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, const int a, char* smem) {
     // field index of each access point: 16 bits are enough for any field that fits LDS (<= 40 k words)
     using ApIndex = typename std::conditional<LDS_DIST, unsigned short, int>::type;
     __shared__ ApIndex s_ap_l[XR_MAX_AP_PER_NET];
@@ -323,7 +323,6 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int a, c
     __shared__ uint32_t s_bound;
     __shared__ int s_cnt[2][3];                        // worklist sizes (H, V, C), double-buffered by parity
 
-    const int e = blockIdx.x;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
 
@@ -1046,6 +1045,30 @@ __global__ void xr_obs_records_kernel(const uint32_t* __restrict__ rec, int X, i
     xr_obs_write<XrRecSrc, VEC>(src, X, Y, Z, X * Y * Z, s_ids, K, out, blockIdx.x * blockDim.x * VEC);
 }
 
+// observation of env e's CURRENT state by the calling workgroup (the step kernel's epilogue).  head_only: the planes
+// the split / queue forms leave to the step kernel (planes 0..1 + the net planes of the lowest XR_SPLIT_KEEP ranks).
+__device__ __forceinline__ void xr_obs_epilogue(const XrBatchDev& b, int e, char* smem, bool head_only) {
+    __syncthreads();          // this workgroup's owner / legal / region writes are visible to all its threads
+    const XrRegionDev R = b.regions[b.env_region[e]];
+    int* s_ids = reinterpret_cast<int*>(smem);              // the field is dead: reuse its LDS
+    int* s_pref = s_ids + b.legal_words * 64;
+    const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
+    XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
+    float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
+    if (b.obs_vec4 == 1) {
+        const int knets = head_only ? XR_SPLIT_KEEP(b, K) : K;
+        for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
+            xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
+    } else if (b.obs_vec4 == 2) {
+        unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
+        const int planes = head_only ? 2 + 7 * XR_SPLIT_KEEP(b, K) : -1;
+        xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat, planes);
+    } else {
+        for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
+            xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The step kernel: route (xr_route_env) and, when the caller asked for it (xr_batch_step_observe), the
 // observation of the new state written by the same workgroup.  Fusing the two lets the HBM-write-bound
@@ -1061,32 +1084,11 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         b.phase_cycles[(int64_t)blockIdx.x * 8 + 3] = (long long)__smid();
     }
 #endif
-    xr_route_env<LDS_DIST, ZCH>(b, actions[blockIdx.x], smem);
+    xr_route_env<LDS_DIST, ZCH>(b, blockIdx.x, actions[blockIdx.x], smem);
 #ifdef XR_TIMELINE
     if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 1] = (long long)wall_clock64();
 #endif
-    if (b.obs_out) {
-        __syncthreads();          // this workgroup's owner / legal / region writes are visible to all its threads
-        const int e = blockIdx.x;
-        const XrRegionDev R = b.regions[b.env_region[e]];
-        int* s_ids = reinterpret_cast<int*>(smem);              // the field is dead: reuse its LDS
-        int* s_pref = s_ids + b.legal_words * 64;
-        const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
-        XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
-        float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
-        if (b.obs_vec4 == 1) {
-            const int knets = b.obs_head_only ? XR_SPLIT_KEEP(b, K) : K;
-            for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
-                xr_obs_write<XrStateSrc, 4>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
-        } else if (b.obs_vec4 == 2) {
-            unsigned short* s_feat = reinterpret_cast<unsigned short*>(s_pref + ((b.legal_words + 1 + 3) & ~3));
-            const int planes = b.obs_head_only ? 2 + 7 * XR_SPLIT_KEEP(b, K) : -1;
-            xr_obs_env_stream(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat, planes);
-        } else {
-            for (int cb = 0; cb < R.N; cb += (int)blockDim.x)
-                xr_obs_write<XrStateSrc, 1>(src, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb);
-        }
-    }
+    if (b.obs_out) xr_obs_epilogue(b, blockIdx.x, smem, b.obs_head_only != 0);
 #ifdef XR_TIMELINE
     __syncthreads();
     if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 2] = (long long)wall_clock64();
@@ -1172,7 +1174,7 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
         if (tid == 1023) s_carry = carry + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) b.plan_off[b.n_envs] = s_carry;
+    if (tid == 0) { b.plan_off[b.n_envs] = s_carry; b.queue[0] = 0; b.queue[1] = 0; }
 }
 
 #ifdef XR_NP_PLAIN
@@ -1181,166 +1183,225 @@ __global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32
 #define XR_NP_ST4(ptr, val) XR_ST4(ptr, val)
 #endif
 #define XR_NP_J 9            // float4 groups per thread per tile: 256 threads * 4 nodes * 9 = 9216 nodes
-__global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
+// one unit = the 7 planes of one remaining net of one env (aligned planes: every region's N % 4 == 0)
+__device__ __forceinline__ void xr_unit_aligned(const XrBatchDev& b, int u) {
     const int tid = threadIdx.x;
-    const int total = b.plan_off[b.n_envs];
-    for (int u = blockIdx.x; u < total; u += gridDim.x) {
-        const uint32_t ent = b.plan_units[u];
-        const int id = b.plan_unit_net[u];
-        const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
-        const XrRegionDev R = b.regions[b.plan_region[e]];
-        const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
-        const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
-        float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride + (int64_t)(2 + 7 * rank) * N;
-        const int ngrp = N >> 2;                                   // N % 4 == 0 in this mode
-        for (int g0 = 0; g0 < ngrp; g0 += 256 * XR_NP_J) {
-            unsigned bits[XR_NP_J];                                // per group: AP mask (bits 0..3), neighbour mask (4..7)
+    const uint32_t ent = b.plan_units[u];
+    const int id = b.plan_unit_net[u];
+    const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
+    const XrRegionDev R = b.regions[b.plan_region[e]];
+    const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
+    const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+    float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride + (int64_t)(2 + 7 * rank) * N;
+    const int ngrp = N >> 2;                                   // N % 4 == 0 in this mode
+    for (int g0 = 0; g0 < ngrp; g0 += 256 * XR_NP_J) {
+        unsigned bits[XR_NP_J];                                // per group: AP mask (bits 0..3), neighbour mask (4..7)
 #pragma unroll
-            for (int j = 0; j < XR_NP_J; j++) {
-                const int g = g0 + j * 256 + tid;
-                unsigned m = 0;
-                if (g < ngrp) {
-                    const int f0 = g << 2;
-                    const int2 v = *reinterpret_cast<const int2*>(nn + f0);     // 4 x int16, 8-byte aligned
-                    const int n0 = (short)(v.x & 0xFFFF), n1 = v.x >> 16, n2 = (short)(v.y & 0xFFFF), n3 = v.y >> 16;
-                    m = (n0 == id ? 1u : 0u) | (n1 == id ? 2u : 0u) | (n2 == id ? 4u : 0u) | (n3 == id ? 8u : 0u);
-                    if (m) {                                           // rare: ~1 % of the nodes are access points
-                        for (int q = 0; q < 4; q++)
-                            if (m & (1u << q)) {
-                                const int f = f0 + q;
-                                const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
-                                bool adj = false;
-                                if (x + 1 < X && nn[f + YZ] == id) adj = true;
-                                else if (y > 0 && nn[f - Z] == id) adj = true;
-                                else if (x > 0 && nn[f - YZ] == id) adj = true;
-                                else if (y + 1 < Y && nn[f + Z] == id) adj = true;
-                                else if (z + 1 < Z && nn[f + 1] == id) adj = true;
-                                else if (z > 0 && nn[f - 1] == id) adj = true;
-                                if (adj) m |= 16u << q;
-                            }
-                    }
+        for (int j = 0; j < XR_NP_J; j++) {
+            const int g = g0 + j * 256 + tid;
+            unsigned m = 0;
+            if (g < ngrp) {
+                const int f0 = g << 2;
+                const int2 v = *reinterpret_cast<const int2*>(nn + f0);     // 4 x int16, 8-byte aligned
+                const int n0 = (short)(v.x & 0xFFFF), n1 = v.x >> 16, n2 = (short)(v.y & 0xFFFF), n3 = v.y >> 16;
+                m = (n0 == id ? 1u : 0u) | (n1 == id ? 2u : 0u) | (n2 == id ? 4u : 0u) | (n3 == id ? 8u : 0u);
+                if (m) {                                           // rare: ~1 % of the nodes are access points
+                    for (int q = 0; q < 4; q++)
+                        if (m & (1u << q)) {
+                            const int f = f0 + q;
+                            const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+                            bool adj = false;
+                            if (x + 1 < X && nn[f + YZ] == id) adj = true;
+                            else if (y > 0 && nn[f - Z] == id) adj = true;
+                            else if (x > 0 && nn[f - YZ] == id) adj = true;
+                            else if (y + 1 < Y && nn[f + Z] == id) adj = true;
+                            else if (z + 1 < Z && nn[f + 1] == id) adj = true;
+                            else if (z > 0 && nn[f - 1] == id) adj = true;
+                            if (adj) m |= 16u << q;
+                        }
                 }
-                bits[j] = m;
             }
-            // plane 0 of the net: AP mask; planes 1..6: the six aliased "has a same-net axis neighbour" planes
+            bits[j] = m;
+        }
+        // plane 0 of the net: AP mask; planes 1..6: the six aliased "has a same-net axis neighbour" planes
 #ifndef XR_NP_ORDER
 #define XR_NP_ORDER 1
 #endif
 #if XR_NP_ORDER == 0       // plane-major: the workgroup writes the unit as one sequential run
 #pragma unroll 1
-            for (int pl = 0; pl < 7; pl++) {
-                float* __restrict__ pp = out + (int64_t)pl * N;
-                const int sh = pl ? 4 : 0;
-#pragma unroll
-                for (int j = 0; j < XR_NP_J; j++) {
-                    const int g = g0 + j * 256 + tid;
-                    if (g < ngrp) {
-                        const unsigned m = bits[j] >> sh;
-                        float4 v;
-                        v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 2u) ? 1.f : 0.f;
-                        v.z = (m & 4u) ? 1.f : 0.f; v.w = (m & 8u) ? 1.f : 0.f;
-                        XR_NP_ST4(pp + ((int64_t)g << 2), v);
-                    }
-                }
-            }
-#else                      // rotation: 4 KB of each of the 7 planes in turn (the step kernel's own order)
+        for (int pl = 0; pl < 7; pl++) {
+            float* __restrict__ pp = out + (int64_t)pl * N;
+            const int sh = pl ? 4 : 0;
 #pragma unroll
             for (int j = 0; j < XR_NP_J; j++) {
                 const int g = g0 + j * 256 + tid;
                 if (g < ngrp) {
-                    float* __restrict__ pp = out + ((int64_t)g << 2);
-                    const unsigned m0 = bits[j], m1 = bits[j] >> 4;
-                    float4 v0, v1;
-                    v0.x = (m0 & 1u) ? 1.f : 0.f; v0.y = (m0 & 2u) ? 1.f : 0.f; v0.z = (m0 & 4u) ? 1.f : 0.f; v0.w = (m0 & 8u) ? 1.f : 0.f;
-                    v1.x = (m1 & 1u) ? 1.f : 0.f; v1.y = (m1 & 2u) ? 1.f : 0.f; v1.z = (m1 & 4u) ? 1.f : 0.f; v1.w = (m1 & 8u) ? 1.f : 0.f;
-                    XR_NP_ST4(pp, v0);
-#pragma unroll
-                    for (int pl = 1; pl < 7; pl++) XR_NP_ST4(pp + (int64_t)pl * N, v1);
+                    const unsigned m = bits[j] >> sh;
+                    float4 v;
+                    v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 2u) ? 1.f : 0.f;
+                    v.z = (m & 4u) ? 1.f : 0.f; v.w = (m & 8u) ? 1.f : 0.f;
+                    XR_NP_ST4(pp + ((int64_t)g << 2), v);
                 }
             }
-#endif
         }
+#else                      // rotation: 4 KB of each of the 7 planes in turn (the step kernel's own order)
+#pragma unroll
+        for (int j = 0; j < XR_NP_J; j++) {
+            const int g = g0 + j * 256 + tid;
+            if (g < ngrp) {
+                float* __restrict__ pp = out + ((int64_t)g << 2);
+                const unsigned m0 = bits[j], m1 = bits[j] >> 4;
+                float4 v0, v1;
+                v0.x = (m0 & 1u) ? 1.f : 0.f; v0.y = (m0 & 2u) ? 1.f : 0.f; v0.z = (m0 & 4u) ? 1.f : 0.f; v0.w = (m0 & 8u) ? 1.f : 0.f;
+                v1.x = (m1 & 1u) ? 1.f : 0.f; v1.y = (m1 & 2u) ? 1.f : 0.f; v1.z = (m1 & 4u) ? 1.f : 0.f; v1.w = (m1 & 8u) ? 1.f : 0.f;
+                XR_NP_ST4(pp, v0);
+#pragma unroll
+                for (int pl = 1; pl < 7; pl++) XR_NP_ST4(pp + (int64_t)pl * N, v1);
+            }
+        }
+#endif
     }
+}
+
+__global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
+    const int total = b.plan_off[b.n_envs];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) xr_unit_aligned(b, u);
 }
 
 // The same units for regions whose N is not a multiple of 4 (design-derived regions): a unit's 7*N floats start at
 // float (2+7*rank)*N of the env's row, 16-byte aligned only by chance.  Per unit the workgroup reduces the net's two
 // node masks to one byte per node in LDS, then writes the unit's float range as aligned float4 slots (plane and node
 // of a slot resolved per float where a slot straddles two planes) plus at most 3 scalar floats at either end.
+// s_m: LDS, (n_max / 16 + 2) words.  Two bits per node, 16 nodes per word: bit 2i = node is an AP of the net,
+// bit 2i+1 = ... with a same-net neighbour.  Ends with a barrier (s_m may be reused at once).
+__device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint32_t* s_m) {
+    const int tid = threadIdx.x;
+    const uint32_t ent = b.plan_units[u];
+    const int id = b.plan_unit_net[u];
+    const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
+    const XrRegionDev R = b.regions[b.plan_region[e]];
+    const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
+    const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+    const int nwords = (N + 15) >> 4;
+    for (int w = tid; w <= nwords; w += 256) {                 // one spare word: the funnel shift reads w + 1
+        const int f0 = w << 4;
+        // 16 nodes = two 16-byte loads (node_off is a multiple of 8 elements), issued before any compare
+        int pk[8];
+        if (f0 + 16 <= N) {
+            const int4 v0 = *reinterpret_cast<const int4*>(nn + f0), v1 = *reinterpret_cast<const int4*>(nn + f0 + 8);
+            pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int fa = f0 + 2 * i, fb = fa + 1;
+                const int lo = fa < N ? (int)(unsigned short)nn[fa] : 0, hi = fb < N ? (int)(unsigned short)nn[fb] : 0;
+                pk[i] = lo | (hi << 16);
+            }
+        }
+        uint32_t hit = 0;                                      // bit i: node f0 + i is an access point of the net
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int v = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xFFFF);
+            hit |= (v == id && f0 + i < N) ? (1u << i) : 0u;
+        }
+        uint32_t m = 0;
+        while (hit) {                                          // rare: ~1 % of the nodes
+            const int i = __ffs((int)hit) - 1; hit &= hit - 1;
+            const int f = f0 + i;
+            const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+            const bool adj = (x + 1 < X && nn[f + YZ] == id) || (y > 0 && nn[f - Z] == id) || (x > 0 && nn[f - YZ] == id) ||
+                             (y + 1 < Y && nn[f + Z] == id) || (z + 1 < Z && nn[f + 1] == id) || (z > 0 && nn[f - 1] == id);
+            m |= (adj ? 3u : 1u) << (2 * i);
+        }
+        s_m[w] = m;
+    }
+    __syncthreads();
+    float* __restrict__ row = b.obs_out + (int64_t)e * b.obs_stride;          // 16-byte aligned
+    const long long a = (long long)(2 + 7 * rank) * N;                       // first float of the unit
+    auto bits8 = [&](int f) {                 // masks of nodes f .. f+3 (2 bits each) in the low byte
+        const int bit = f << 1, w = bit >> 5, sh = bit & 31;
+        return __funnelshift_r(s_m[w], s_m[w + 1], sh);
+    };
+    for (int pl = 0; pl < 7; pl++) {
+        const long long p0 = a + (long long)pl * N, p1 = p0 + N;               // this plane's float range
+        const long long s0 = (p0 + 3) >> 2, s1 = p1 >> 2;                      // aligned slots fully inside it
+        const int sel = pl ? 1 : 0;
+        for (long long sl = s0 + tid; sl < s1; sl += 256) {
+            const uint32_t m = bits8((int)((sl << 2) - p0)) >> sel;
+            float4 v;
+            v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
+            XR_ST4(row + (sl << 2), v);
+        }
+        // ragged ends of the plane: at most 3 floats each (the whole plane when it holds no aligned slot)
+        auto one = [&](long long g) { const int f = (int)(g - p0); return ((s_m[f >> 4] >> (((f & 15) << 1) + sel)) & 1u) ? 1.f : 0.f; };
+        if (s0 < s1) {
+            const int nh = (int)((s0 << 2) - p0), nt = (int)(p1 - (s1 << 2));
+            if (tid < nh) row[p0 + tid] = one(p0 + tid);
+            else if (tid >= 64 && tid - 64 < nt) row[(s1 << 2) + (tid - 64)] = one((s1 << 2) + (tid - 64));
+        } else {
+            for (long long g = p0 + tid; g < p1; g += 256) row[g] = one(g);
+        }
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // two bits per node, 16 nodes per word: bit 2i = node is an AP of the net, bit 2i+1 = ... with a same-net neighbour
-    uint32_t* s_m = reinterpret_cast<uint32_t*>(smem);
-    const int tid = threadIdx.x;
     const int total = b.plan_off[b.n_envs];
-    for (int u = blockIdx.x; u < total; u += gridDim.x) {
-        const uint32_t ent = b.plan_units[u];
-        const int id = b.plan_unit_net[u];
-        const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
-        const XrRegionDev R = b.regions[b.plan_region[e]];
-        const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
-        const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
-        const int nwords = (N + 15) >> 4;
-        for (int w = tid; w <= nwords; w += 256) {                 // one spare word: the funnel shift reads w + 1
-            const int f0 = w << 4;
-            // 16 nodes = two 16-byte loads (node_off is a multiple of 8 elements), issued before any compare
-            int pk[8];
-            if (f0 + 16 <= N) {
-                const int4 v0 = *reinterpret_cast<const int4*>(nn + f0), v1 = *reinterpret_cast<const int4*>(nn + f0 + 8);
-                pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
+    for (int u = blockIdx.x; u < total; u += gridDim.x) xr_unit_stream(b, u, reinterpret_cast<uint32_t*>(smem));
+}
+
+// ------------------------------------------------------------------------------------------------
+// queue form of the step (XR_OBS_QUEUE): ONE persistent launch (as many workgroups as fit the chip) that drains two task
+// queues — envs to route (+ their planes 0..1) and net-plane units to write.  Units do not depend on routing
+// (xr_plan_kernel), so they are the filler that keeps HBM busy while other workgroups route, and the tail of the
+// launch is one 20 us unit instead of one whole env.  A workgroup alternates one route task with `quota` units (a little
+// under the average units per env, so that the routes run out first and the launch ends in a pure-write drain);
+// odd workgroups start with units so that the launch writes from its first microseconds.  No workgroup ever
+// waits for another one.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_DIST, int ZCH>
+__global__ void xr_step_queue_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_task;
+    const int tid = threadIdx.x;
+    const int B = b.n_envs;
+    const int total = b.plan_off[B];
+    const int quota = max(1, (int)(((int64_t)total * b.queue_quota_pm) / (1000 * (int64_t)B)));
+    bool routes_left = true, units_left = total > 0;
+#ifndef XR_QUEUE_SKIP
+#define XR_QUEUE_SKIP 1
+#endif
+    bool skip_route = XR_QUEUE_SKIP == 1 ? (blockIdx.x & 1) != 0 : XR_QUEUE_SKIP == 2 ? (blockIdx.x & 3) == 3
+                    : XR_QUEUE_SKIP == 3 ? (blockIdx.x & 3) != 0 : false;
+    while (routes_left || units_left) {
+        if (routes_left && !skip_route) {
+            if (tid == 0) s_task = (int)atomicAdd(&b.queue[0], 1u);
+            __syncthreads();
+            const int e = s_task;
+            __syncthreads();
+            if (e < B) {
+                xr_route_env<LDS_DIST, ZCH>(b, e, actions[e], smem);
+                xr_obs_epilogue(b, e, smem, true);
+                __syncthreads();
             } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int fa = f0 + 2 * i, fb = fa + 1;
-                    const int lo = fa < N ? (int)(unsigned short)nn[fa] : 0, hi = fb < N ? (int)(unsigned short)nn[fb] : 0;
-                    pk[i] = lo | (hi << 16);
-                }
-            }
-            uint32_t hit = 0;                                      // bit i: node f0 + i is an access point of the net
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int v = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xFFFF);
-                hit |= (v == id && f0 + i < N) ? (1u << i) : 0u;
-            }
-            uint32_t m = 0;
-            while (hit) {                                          // rare: ~1 % of the nodes
-                const int i = __ffs((int)hit) - 1; hit &= hit - 1;
-                const int f = f0 + i;
-                const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
-                const bool adj = (x + 1 < X && nn[f + YZ] == id) || (y > 0 && nn[f - Z] == id) || (x > 0 && nn[f - YZ] == id) ||
-                                 (y + 1 < Y && nn[f + Z] == id) || (z + 1 < Z && nn[f + 1] == id) || (z > 0 && nn[f - 1] == id);
-                m |= (adj ? 3u : 1u) << (2 * i);
-            }
-            s_m[w] = m;
-        }
-        __syncthreads();
-        float* __restrict__ row = b.obs_out + (int64_t)e * b.obs_stride;          // 16-byte aligned
-        const long long a = (long long)(2 + 7 * rank) * N;                       // first float of the unit
-        auto bits8 = [&](int f) {                 // masks of nodes f .. f+3 (2 bits each) in the low byte
-            const int bit = f << 1, w = bit >> 5, sh = bit & 31;
-            return __funnelshift_r(s_m[w], s_m[w + 1], sh);
-        };
-        for (int pl = 0; pl < 7; pl++) {
-            const long long p0 = a + (long long)pl * N, p1 = p0 + N;               // this plane's float range
-            const long long s0 = (p0 + 3) >> 2, s1 = p1 >> 2;                      // aligned slots fully inside it
-            const int sel = pl ? 1 : 0;
-            for (long long sl = s0 + tid; sl < s1; sl += 256) {
-                const uint32_t m = bits8((int)((sl << 2) - p0)) >> sel;
-                float4 v;
-                v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
-                XR_ST4(row + (sl << 2), v);
-            }
-            // ragged ends of the plane: at most 3 floats each (the whole plane when it holds no aligned slot)
-            auto one = [&](long long g) { const int f = (int)(g - p0); return ((s_m[f >> 4] >> (((f & 15) << 1) + sel)) & 1u) ? 1.f : 0.f; };
-            if (s0 < s1) {
-                const int nh = (int)((s0 << 2) - p0), nt = (int)(p1 - (s1 << 2));
-                if (tid < nh) row[p0 + tid] = one(p0 + tid);
-                else if (tid >= 64 && tid - 64 < nt) row[(s1 << 2) + (tid - 64)] = one((s1 << 2) + (tid - 64));
-            } else {
-                for (long long g = p0 + tid; g < p1; g += 256) row[g] = one(g);
+                routes_left = false;
             }
         }
-        __syncthreads();
+        skip_route = false;
+        if (units_left) {
+            const int n = routes_left ? quota : (1 << 30);
+            for (int i = 0; i < n; i++) {
+                if (tid == 0) s_task = (int)atomicAdd(&b.queue[1], 1u);
+                __syncthreads();
+                const int u = s_task;
+                __syncthreads();
+                if (u >= total) { units_left = false; break; }
+                if (b.obs_vec4 == 1) xr_unit_aligned(b, u);
+                else xr_unit_stream(b, u, reinterpret_cast<uint32_t*>(smem));
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1366,7 +1427,7 @@ __global__ void xr_order_kernel(XrBatchDev b, const int32_t* __restrict__ orders
         const int a = ord[k];
         if (a <= 0) break;                         // list terminator (uniform)
         if (b.nlegal[e] == 0) break;               // everything routed: the rest of the list is ignored
-        xr_route_env<LDS_DIST, ZCH>(b, a, smem);
+        xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
         __syncthreads();
         if (tid == 0) {
             const int st = b.status[e];
@@ -1415,6 +1476,9 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
     const void* fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, 0>), reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
                           reinterpret_cast<const void*>(&xr_route_kernel<true, 12>), reinterpret_cast<const void*>(&xr_route_kernel<false, 0>),
                           reinterpret_cast<const void*>(&xr_route_kernel<false, 9>), reinterpret_cast<const void*>(&xr_route_kernel<false, 12>)};
+    const void* qfns[6] = {reinterpret_cast<const void*>(&xr_step_queue_kernel<true, 0>), reinterpret_cast<const void*>(&xr_step_queue_kernel<true, 9>),
+                           reinterpret_cast<const void*>(&xr_step_queue_kernel<true, 12>), reinterpret_cast<const void*>(&xr_step_queue_kernel<false, 0>),
+                           reinterpret_cast<const void*>(&xr_step_queue_kernel<false, 9>), reinterpret_cast<const void*>(&xr_step_queue_kernel<false, 12>)};
     const void* ofns[6] = {reinterpret_cast<const void*>(&xr_order_kernel<true, 0>), reinterpret_cast<const void*>(&xr_order_kernel<true, 9>),
                            reinterpret_cast<const void*>(&xr_order_kernel<true, 12>), reinterpret_cast<const void*>(&xr_order_kernel<false, 0>),
                            reinterpret_cast<const void*>(&xr_order_kernel<false, 9>), reinterpret_cast<const void*>(&xr_order_kernel<false, 12>)};
@@ -1422,6 +1486,8 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(ofns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(qfns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1471,6 +1537,21 @@ hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threa
     if (e != hipSuccess) return e;
     *static_lds = attr.sharedSizeBytes;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, fn, threads, lds_bytes);
+}
+
+hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
+                                int threads, int blocks, hipStream_t st) {
+    const dim3 g(blocks), t(threads);
+    if (lds_dist) {
+        if (zch == 9) hipLaunchKernelGGL((xr_step_queue_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
+        else if (zch == 12) hipLaunchKernelGGL((xr_step_queue_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_step_queue_kernel<true, 0>), g, t, lds_bytes, st, *b, actions);
+    } else {
+        if (zch == 9) hipLaunchKernelGGL((xr_step_queue_kernel<false, 9>), g, t, lds_bytes, st, *b, actions);
+        else if (zch == 12) hipLaunchKernelGGL((xr_step_queue_kernel<false, 12>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_step_queue_kernel<false, 0>), g, t, lds_bytes, st, *b, actions);
+    }
+    return hipGetLastError();
 }
 
 hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream_t st) {
