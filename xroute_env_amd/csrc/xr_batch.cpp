@@ -113,7 +113,7 @@ struct xr_batch {
     DevBuf<uint32_t> dist_scratch;
     DevBuf<unsigned short> list_scratch;
     // split observation
-    DevBuf<int32_t> plan_region, plan_unit_net, plan_off;
+    DevBuf<int32_t> plan_region, plan_unit_net;
     DevBuf<uint32_t> plan_units, queue;
     int n_cus = 0;
     hipStream_t aux_stream = nullptr;
@@ -397,8 +397,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->total_steps, 1);
     XR_ALLOC(b->phase_cycles, (size_t)B * 8);
     XR_ALLOC(b->plan_region, B);
-    XR_ALLOC(b->queue, 2);
-    XR_ALLOC(b->plan_off, (size_t)B + 1);
+    XR_ALLOC(b->queue, 3);
     XR_ALLOC(b->plan_units, (size_t)B * std::max(1, k_max));
     XR_ALLOC(b->plan_unit_net, (size_t)B * std::max(1, k_max));
     if (!b->lds_dist) {
@@ -444,7 +443,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
-    d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.plan_off = b->plan_off.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
+    d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
     if (!b->aux_stream) {
         XR_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
         XR_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));

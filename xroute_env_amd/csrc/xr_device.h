@@ -80,8 +80,7 @@ struct XrBatchDev {
     int32_t* plan_region;    // [B]
     uint32_t* plan_units;    // [B*k_max] one entry per (env, remaining net): env << 14 | (rank of the net among the remaining)
     int32_t* plan_unit_net;  // [B*k_max] 1-based net id of that unit
-    int32_t* plan_off;       // [B+1] exclusive prefix of the remaining-net counts (= first unit of env e)
-    uint32_t* queue;         // [2] task counters of the queue form: next env to route, next unit to write
+    uint32_t* queue;         // [3] next env to route, next unit to write (queue form); number of units (written by xr_plan_kernel)
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;

@@ -1104,77 +1104,70 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
 // Units are equal-sized and visited in address order by the whole grid, so the write stream is balanced and
 // globally sequential (measured: the fastest write pattern on this device, tools/micro/write_bw.hip).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) xr_plan_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
-    __shared__ int s_wsum[16];
-    __shared__ int s_carry;
+__global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+    // one env per thread; the units of a workgroup's 256 envs are contiguous and in env order (block scan), the
+    // workgroups reserve their runs with one atomic each (queue[2], zeroed by the host before this launch)
+    __shared__ int s_wsum[4];
+    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < b.n_envs; base += 1024) {
-        const int e = base + tid;
-        int k = 0, r = 0;
-        const uint64_t* lsrc = nullptr;        // where the post-step legal words come from
-        int clear_bit = -1;
-        if (e < b.n_envs) {
-            const int nl = b.nlegal[e];
-            r = b.env_region[e];
-            if (nl == 0) {
-                if (b.auto_reset) {            // xr_env_reset(rotate = 1), examples/launch_training.py:37-46
-                    if (b.env_replay[e] == b.max_route_count) r = (int)(((int64_t)r + b.n_envs) % b.n_regions);
-                    const XrRegionDev R = b.regions[r];
-                    lsrc = b.legal0 + R.legal0_off;
-                    k = R.nlegal0;
-                }
-            } else {
+    const int e = blockIdx.x * 256 + tid;
+    int k = 0, r = 0;
+    const uint64_t* lsrc = nullptr;        // where the post-step legal words come from
+    int clear_bit = -1;
+    if (e < b.n_envs) {
+        const int nl = b.nlegal[e];
+        r = b.env_region[e];
+        if (nl == 0) {
+            if (b.auto_reset) {            // xr_env_reset(rotate = 1), examples/launch_training.py:37-46
+                if (b.env_replay[e] == b.max_route_count) r = (int)(((int64_t)r + b.n_envs) % b.n_regions);
                 const XrRegionDev R = b.regions[r];
-                const int a = actions[e];
-                lsrc = b.legal + (int64_t)e * b.legal_words;
-                k = nl;
-                if (a >= 1 && a <= R.n_nets && ((lsrc[(a - 1) >> 6] >> ((a - 1) & 63)) & 1ULL)) {
-                    clear_bit = a - 1;
-                    k = nl - 1;
-                }
+                lsrc = b.legal0 + R.legal0_off;
+                k = R.nlegal0;
             }
-            b.plan_region[e] = r;
-        }
-        // the step kernel keeps the lowest XR_SPLIT_KEEP ranks of every env, the writer kernel takes the rest
-        const int kskip = XR_SPLIT_KEEP(b, k);
-        const int kw = k - kskip;
-        // block-wide exclusive scan of kw
-        int incl = kw;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wv; w++) woff += s_wsum[w];
-        const int carry = s_carry;
-        const int off = carry + woff + incl - kw;
-        if (e < b.n_envs) {
-            b.plan_off[e] = off;
-            int j = 0;
-            for (int w = 0; w < b.legal_words && j < k; w++) {
-                uint64_t m = lsrc[w];
-                if (clear_bit >= 0 && (clear_bit >> 6) == w) m &= ~(1ULL << (clear_bit & 63));
-                while (m) {
-                    const int bit = __ffsll((unsigned long long)m) - 1;
-                    m &= m - 1;
-                    if (j >= kskip) {
-                        b.plan_units[off + j - kskip] = ((uint32_t)e << 14) | (uint32_t)j;
-                        b.plan_unit_net[off + j - kskip] = (w << 6) + bit + 1;
-                    }
-                    j++;
-                }
+        } else {
+            const XrRegionDev R = b.regions[r];
+            const int a = actions[e];
+            lsrc = b.legal + (int64_t)e * b.legal_words;
+            k = nl;
+            if (a >= 1 && a <= R.n_nets && ((lsrc[(a - 1) >> 6] >> ((a - 1) & 63)) & 1ULL)) {
+                clear_bit = a - 1;
+                k = nl - 1;
             }
         }
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + woff + incl;
-        __syncthreads();
+        b.plan_region[e] = r;
     }
-    if (tid == 0) { b.plan_off[b.n_envs] = s_carry; b.queue[0] = 0; b.queue[1] = 0; }
+    // the step kernel keeps the lowest XR_SPLIT_KEEP ranks of every env, the writer takes the rest
+    const int kskip = XR_SPLIT_KEEP(b, k);
+    const int kw = k - kskip;
+    int incl = kw;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff += s_wsum[w];
+    if (tid == 255) s_base = (int)atomicAdd(&b.queue[2], (unsigned)(woff + incl));
+    __syncthreads();
+    const int off = s_base + woff + incl - kw;
+    if (e < b.n_envs) {
+        int j = 0;
+        for (int w = 0; w < b.legal_words && j < k; w++) {
+            uint64_t m = lsrc[w];
+            if (clear_bit >= 0 && (clear_bit >> 6) == w) m &= ~(1ULL << (clear_bit & 63));
+            while (m) {
+                const int bit = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                if (j >= kskip) {
+                    b.plan_units[off + j - kskip] = ((uint32_t)e << 14) | (uint32_t)j;
+                    b.plan_unit_net[off + j - kskip] = (w << 6) + bit + 1;
+                }
+                j++;
+            }
+        }
+    }
 }
 
 #ifdef XR_NP_PLAIN
@@ -1264,7 +1257,7 @@ __device__ __forceinline__ void xr_unit_aligned(const XrBatchDev& b, int u) {
 }
 
 __global__ void __launch_bounds__(256) xr_netplane_kernel(XrBatchDev b) {
-    const int total = b.plan_off[b.n_envs];
+    const int total = (int)b.queue[2];
     for (int u = blockIdx.x; u < total; u += gridDim.x) xr_unit_aligned(b, u);
 }
 
@@ -1347,7 +1340,7 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
 
 __global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int total = b.plan_off[b.n_envs];
+    const int total = (int)b.queue[2];
     for (int u = blockIdx.x; u < total; u += gridDim.x) xr_unit_stream(b, u, reinterpret_cast<uint32_t*>(smem));
 }
 
@@ -1366,7 +1359,7 @@ __global__ void xr_step_queue_kernel(XrBatchDev b, const int32_t* __restrict__ a
     __shared__ int s_task;
     const int tid = threadIdx.x;
     const int B = b.n_envs;
-    const int total = b.plan_off[B];
+    const int total = (int)b.queue[2];
     const int quota = max(1, (int)(((int64_t)total * b.queue_quota_pm) / (1000 * (int64_t)B)));
     bool routes_left = true, units_left = total > 0;
 #ifndef XR_QUEUE_SKIP
@@ -1555,7 +1548,9 @@ hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int
 }
 
 hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream_t st) {
-    hipLaunchKernelGGL(xr_plan_kernel, dim3(1), dim3(1024), 0, st, *b, actions);
+    hipError_t e = hipMemsetAsync(b->queue, 0, 3 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(xr_plan_kernel, dim3((b->n_envs + 255) / 256), dim3(256), 0, st, *b, actions);
     return hipGetLastError();
 }
 
