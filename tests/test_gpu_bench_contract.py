@@ -41,7 +41,7 @@ def test_bench_json_contract(extra):
 
 @pytest.mark.gpu
 def test_step_kernel_keeps_four_workgroups_per_cu_on_ispd_sized_regions():
-    """The LDS budget of the step kernel at 24x40x9 is laid out for 4 workgroups per CU (DESIGN.md §5.2); 3 would cost a
+    """The LDS budget of the step kernel at 24x40x9 is laid out for 4 workgroups per CU (DESIGN.md §5.3); 3 would cost a
     quarter of the throughput without failing any parity test."""
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.regions import config_regions
