@@ -7,7 +7,7 @@ from xroute_env_amd.batch import RegionBatch
 from xroute_env_amd.regions import config_regions
 B = 4096
 regions = config_regions(3, B)
-batch = RegionBatch(regions, n_envs=B, auto_reset=True)
+batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=1)
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
 obs = batch.alloc_observation()

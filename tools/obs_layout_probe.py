@@ -9,7 +9,7 @@ from xroute_env_amd.regions import generate_region
 B = 4096
 for name, kr, warm in (("K~U[4,36] steady state", (4, 36), 10), ("K=10 at reset (dense)", (10, 10), 0), ("K=36 at reset (dense)", (36, 36), 0)):
     regions = [generate_region(3000 + i, k_range=kr) for i in range(256)]
-    batch = RegionBatch(regions, n_envs=B, auto_reset=True)
+    batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=1)
     batch.reset()
     acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
     obs = batch.alloc_observation()

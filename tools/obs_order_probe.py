@@ -11,7 +11,7 @@ ks = np.array([r.n_nets for r in regions])
 rng = np.random.default_rng(1)
 base = rng.integers(0, len(regions), B)
 for name, assign in (("random", base), ("descending K", base[np.argsort(-ks[base], kind="stable")]), ("ascending K", base[np.argsort(ks[base], kind="stable")])):
-    batch = RegionBatch(regions, n_envs=B, auto_reset=False)
+    batch = RegionBatch(regions, n_envs=B, auto_reset=False, obs_mode=1)
     batch.assign(assign); batch.reset()
     obs = batch.alloc_observation()
     k = batch.fetch("nlegal").double()

@@ -11,7 +11,7 @@ from xroute_env_amd.regions import config_regions
 B = 4096
 mode = sys.argv[1] if len(sys.argv) > 1 else "step"
 regions = config_regions(3, B)
-batch = RegionBatch(regions, n_envs=B, auto_reset=True)
+batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=1)
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
 obs = batch.alloc_observation()
