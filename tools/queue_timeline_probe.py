@@ -1,0 +1,33 @@
+"""Per-workgroup accounting of one queue-form step launch (needs `make -C xroute_env_amd/csrc timeline`): how the 1024
+persistent workgroups split their time between route tasks and net-plane units, when the routes run out, and how far
+apart the workgroups finish."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from xroute_env_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libxroute_hip_timeline.so")
+from xroute_env_amd.batch import RegionBatch
+from xroute_env_amd.regions import config_regions
+B = 4096
+pm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+regions = config_regions(3, B)
+batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=3, obs_split_permille=pm)
+batch.reset(rotate=True)
+acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+obs = batch.alloc_observation()
+for i in range(6):
+    batch.random_actions(2024 + i, acts); batch.step(acts, obs)
+torch.cuda.synchronize()
+ph = batch.fetch("phases").cpu().numpy().astype(np.int64)
+ph = ph[ph[:, 7] == 1]
+k = batch.fetch("nlegal").cpu().numpy().astype(np.float64)
+nbytes = (4.0 * (2.0 + 7.0 * k) * 8640).sum()
+t0 = ph[:, 0].min()
+start, end, last_route = (ph[:, 0] - t0) / 100.0, (ph[:, 1] - t0) / 100.0, (ph[:, 6] - t0) / 100.0
+span = end.max()
+print(f"{len(ph)} workgroups, span {span:.0f} us, {nbytes/1e9:.2f} GB -> {nbytes/span/1e6:.2f} TB/s")
+print(f"workgroup start: max {start.max():.0f} us; end: min {end.min():.0f}, p5 {np.percentile(end,5):.0f}, median {np.median(end):.0f}, max {end.max():.0f} us")
+print(f"per workgroup: routing {ph[:,2].mean()/100:.0f} us ({ph[:,4].mean():.2f} routes, {ph[:,2].sum()/max(ph[:,4].sum(),1)/100:.0f} us each), "
+      f"units {ph[:,3].mean()/100:.0f} us ({ph[:,5].mean():.1f} units, {ph[:,3].sum()/max(ph[:,5].sum(),1)/100:.1f} us each), "
+      f"other {(end-start).mean() - (ph[:,2].mean()+ph[:,3].mean())/100:.0f} us")
+print(f"last route task finished at {last_route.max():.0f} us (routes run out at {100*last_route.max()/span:.0f} % of the launch)")
