@@ -10,7 +10,12 @@ from xroute_env_amd.batch import RegionBatch
 from xroute_env_amd.regions import config_regions
 B = 4096
 pm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-regions = config_regions(3, B)
+pack = len(sys.argv) > 2 and sys.argv[2] == "pack"
+if pack:
+    from xroute_env_amd.lefdef import load_region_pack
+    regions = load_region_pack(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ispd18_test1_regions.npz"))
+else:
+    regions = config_regions(3, B)
 batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=3, obs_split_permille=pm)
 batch.reset(rotate=True)
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
@@ -21,7 +26,8 @@ torch.cuda.synchronize()
 ph = batch.fetch("phases").cpu().numpy().astype(np.int64)
 ph = ph[ph[:, 7] == 1]
 k = batch.fetch("nlegal").cpu().numpy().astype(np.float64)
-nbytes = (4.0 * (2.0 + 7.0 * k) * 8640).sum()
+nn = np.array([regions[int(r)].n_nodes for r in batch.fetch("region").cpu().numpy()], dtype=np.float64)
+nbytes = (4.0 * (2.0 + 7.0 * k) * nn).sum()
 t0 = ph[:, 0].min()
 start, end, last_route = (ph[:, 0] - t0) / 100.0, (ph[:, 1] - t0) / 100.0, (ph[:, 6] - t0) / 100.0
 span = end.max()

@@ -1315,16 +1315,38 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
         const int bit = f << 1, w = bit >> 5, sh = bit & 31;
         return __funnelshift_r(s_m[w], s_m[w + 1], sh);
     };
+#ifndef XR_STREAM_ROTATE
+#define XR_STREAM_ROTATE 1
+#endif
+#if XR_STREAM_ROTATE
+    // aligned float4 slots: 4 KB of each of the 7 planes in rotation (slot t of plane pl = nodes r_pl + 4t ..)
+    for (int t = tid; t < (N >> 2) + 1; t += 256) {
+#pragma unroll
+        for (int pl = 0; pl < 7; pl++) {
+            const long long p0 = a + (long long)pl * N;
+            const long long s0 = (p0 + 3) >> 2;
+            const int r = (int)((s0 << 2) - p0);
+            if (t < ((N - r) >> 2)) {
+                const uint32_t m = bits8(r + (t << 2)) >> (pl ? 1 : 0);
+                float4 v;
+                v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
+                XR_ST4(row + ((s0 + t) << 2), v);
+            }
+        }
+    }
+#endif
     for (int pl = 0; pl < 7; pl++) {
         const long long p0 = a + (long long)pl * N, p1 = p0 + N;               // this plane's float range
         const long long s0 = (p0 + 3) >> 2, s1 = p1 >> 2;                      // aligned slots fully inside it
         const int sel = pl ? 1 : 0;
+#if !XR_STREAM_ROTATE
         for (long long sl = s0 + tid; sl < s1; sl += 256) {
             const uint32_t m = bits8((int)((sl << 2) - p0)) >> sel;
             float4 v;
             v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
             XR_ST4(row + (sl << 2), v);
         }
+#endif
         // ragged ends of the plane: at most 3 floats each (the whole plane when it holds no aligned slot)
         auto one = [&](long long g) { const int f = (int)(g - p0); return ((s_m[f >> 4] >> (((f & 15) << 1) + sel)) & 1u) ? 1.f : 0.f; };
         if (s0 < s1) {
