@@ -9,7 +9,7 @@ from xroute_env_amd.regions import config_regions
 B = 4096
 regions = config_regions(3, B)
 want = None
-cases = [(1, 0), (2, 384), (2, 512), (2, 768), (1, 0)]
+cases = [(1, 0), (3, 0), (2, 512), (3, 0), (1, 0)]
 if len(sys.argv) > 1:
     cases = [(2, int(v)) for v in sys.argv[1:]]
 for mode, blocks in cases:
