@@ -8,7 +8,9 @@
 //                         + (xr_batch_step_observe) the observation of the new state by the same workgroup
 //   xr_order_kernel       whole-order re-route (A3C / MCTS contracts): reset + route a list of nets, one launch
 //   xr_obs_kernel         build_3Dgrid: compact state -> fp32 [2+7K, Z, Y, X] observation, streaming
-//   xr_plan_kernel, xr_netplane_kernel   the split form of the step's observation (XR_OBS_SPLIT)
+//   xr_plan_kernel + xr_step_queue_kernel   the step with its observation, default form (XR_OBS_QUEUE): one persistent
+//                         launch draining route tasks and net-plane units
+//   xr_netplane_kernel, xr_netplane_stream_kernel   the writer of the split form (XR_OBS_SPLIT)
 //   xr_random_action_kernel
 //
 // Integer / index work throughout: no MFMA.  What matters here is coalescing (every sweep is
