@@ -170,3 +170,27 @@ def test_split_observation_unaligned_planes(permille, obs_mode):
         assert a.observe_timing()[0] == obs_mode
         assert torch.equal(a.fetch("hash"), b.fetch("hash")) and torch.equal(a.fetch("region"), b.fetch("region"))
         assert torch.equal(oa, ob), it                    # includes the untouched -7 padding behind every env's planes
+
+
+@pytest.mark.parametrize("n_envs", [1, 2, 3, 7])
+def test_queue_form_tiny_batches_and_finished_envs(n_envs):
+    """The persistent launch with fewer envs than workgroups, envs that run out of nets (no units left to write) and,
+    without auto-reset, steps on finished envs (flagged no-ops): same bytes as step + observation."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(6600 + i, dims=(8, 8, 4), k_range=(1, 3), net_span=4) for i in range(n_envs)]
+    for auto in (False, True):
+        a = RegionBatch(regions, device="cuda:0", auto_reset=auto, obs_mode=3)
+        b = RegionBatch(regions, device="cuda:0", auto_reset=auto, obs_mode=1)
+        a.reset(); b.reset()
+        acts = torch.empty(n_envs, dtype=torch.int32, device="cuda:0")
+        oa = torch.full((n_envs, a.obs_env_stride), -5.0, device="cuda:0")
+        ob = torch.full((n_envs, a.obs_env_stride), -5.0, device="cuda:0")
+        for it in range(8):
+            a.random_actions(40 + it, acts)
+            oa.fill_(-5.0); ob.fill_(-5.0)
+            a.step(acts, oa); b.step(acts, ob)
+            assert a.observe_timing()[0] == 3 and b.observe_timing()[0] == 1
+            assert torch.equal(oa, ob), (auto, it)
+            assert torch.equal(a.fetch("status"), b.fetch("status")) and torch.equal(a.fetch("hash"), b.fetch("hash"))
+        if not auto:
+            assert int(a.fetch("nlegal").sum()) == 0 and bool((a.fetch("status") & 1).all())     # all finished: no-ops
