@@ -115,7 +115,7 @@ struct xr_batch {
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net;
     DevBuf<uint32_t> plan_units, queue;
-    int n_cus = 0;
+    int n_cus = 0, queue_blocks = 0;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
     int last_obs_mode = 0;
@@ -525,15 +525,16 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
         d.obs_split_pm = 1000;
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
         XR_HIP(xr_launch_plan(&d, actions_dev, st));
-        if (b->n_cus == 0) {
+        if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel
             hipDeviceProp_t prop;
             XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
+            int per_cu = 0;
+            size_t stat = 0;
+            XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &per_cu, &stat));
             b->n_cus = prop.multiProcessorCount;
+            b->queue_blocks = std::max(1, per_cu) * b->n_cus;
         }
-        int per_cu = 0;
-        size_t stat = 0;
-        XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &per_cu, &stat));
-        const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : std::max(1, per_cu) * b->n_cus;
+        const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : b->queue_blocks;
         XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
                                     std::min(blocks, 4 * b->cfg.n_envs), st));
         return XR_OK;
