@@ -707,7 +707,6 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
                     if (tid == 0) {                 // claim v
                         const int f = (x * Y + y) * Z + z;
                         if (vw & 2u) d_vio += 1;
-                        if (owner[f] == 0) owner[f] = (int16_t)a;
                         s_claim[v >> 5] |= 1u << (v & 31);
                         if (plen < b.path_cap) path[plen] = f;
                         plen++;
@@ -756,6 +755,12 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
                             m &= m - 1;
                             field[l] &= 3u;
                             mark_node(cur, l);
+                            // claim the path node if nobody holds it (done here, by many threads at once, instead
+                            // of one dependent HBM load per node inside the serial back-trace)
+                            int cx, cy, cz;
+                            lay.decode(l, cx, cy, cz);
+                            const int cf = (cx * Y + cy) * Z + cz;
+                            if (owner[cf] == 0) owner[cf] = (int16_t)a;
                         }
                     }
                 }
