@@ -371,3 +371,32 @@ def test_proto_ext_random_roundtrip_and_garbage():
             proto_ext.decode_extras(bytes(bad))
         except (ValueError, UnicodeDecodeError, struct_error):
             pass
+
+
+@pytest.mark.gpu
+def test_gpu_route_order_fullsize_properties():
+    """512 ispd18_test1-sized regions, complete default orders in one launch: per-net deltas add up to the cumulative
+    metrics, every net is routed exactly once, every env ends done, and a second launch with the same orders
+    reproduces the first bit for bit (the launch restarts every env from its region's initial state)."""
+    from xroute_env_amd.envs.order_contracts import OrderSimulator
+    from xroute_env_amd.regions import config_regions
+    regions = config_regions(3, 512)
+    sim = OrderSimulator(regions)
+    orders = sim.default_orders()
+    cum1 = sim.route(orders).clone()
+    stats1 = sim.net_stats.clone()
+    owner1 = sim.batch.fetch("owner").clone()
+    m0 = torch.tensor(np.stack([r.metrics0 for r in regions]).astype(np.int32), device=cum1.device)
+    k = torch.tensor([r.n_nets for r in regions], device=cum1.device)
+    assert torch.equal(stats1[:, :, :3].sum(1), cum1 - m0)
+    routed = torch.arange(sim.stride, device=cum1.device)[None, :] < k[:, None]
+    assert torch.equal(stats1[:, :, 3] == 1, routed) and bool(sim.batch.fetch("done").bool().all())
+    assert torch.equal(sim.batch.fetch("delta"), cum1 - m0)
+    sim.net_stats.zero_()
+    cum2 = sim.route(orders)
+    assert torch.equal(cum2, cum1) and torch.equal(sim.net_stats, stats1) and torch.equal(sim.batch.fetch("owner"), owner1)
+    # a reversed order generally costs something else, and never loses a net
+    rev = torch.where(orders > 0, (k[:, None] + 1 - orders.long()).to(torch.int32), orders)
+    sim.net_stats.zero_()
+    cum3 = sim.route(rev.contiguous())
+    assert bool(sim.batch.fetch("done").bool().all()) and bool((cum3 != cum1).any())
