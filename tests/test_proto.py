@@ -101,3 +101,36 @@ def test_handle_messange_accepts_a_protobuf_like_object():
     c = G2["cases"][0]
     s = Sock()
     assert proto.handle_messange(Msg(bytes.fromhex(c["bytes"])), s) == c["data"]
+
+
+def test_request_records_access_without_net_follows_handle_messange():
+    """ACCESS node with wire net -1: handle_messange gives Net == 0, a plain node (baseline_utils.py:23-26,
+    build_3Dgrid.py:21-24) — it must not show up in netSet as "net 0"; wire net -2 is Net == -1, an obstacle.
+    Maze indices outside the region are refused instead of wrapping."""
+    from xroute_env_amd.build_3Dgrid import legal_nets
+    from xroute_env_amd.regions import ACCESS, BLOCKAGE, NORMAL, unpack_records
+    f = np.zeros((4, 10), np.int32)
+    f[:, 0] = [0, 1, 2, 3]                                   # maze x
+    f[:, 6] = [ACCESS, ACCESS, ACCESS, NORMAL]
+    f[:, 7] = [1, 0, 0, 0]
+    f[:, 8] = [-1, -2, 4, -1]
+    f[:, 9] = [-1, -1, 0, -1]
+    raw = proto.encode_request((4, 1, 1), f, (0, 0, 0), False, [4])
+    m = proto.decode_message(raw)
+    rec = proto.request_records(m)
+    ntype, used, net, pin = unpack_records(rec)
+    assert ntype.tolist() == [NORMAL, BLOCKAGE, ACCESS, NORMAL]
+    assert net.tolist() == [-1, -1, 4, -1] and used.tolist() == [1, 0, 0, 0]
+    assert legal_nets(rec, set(), False, None).tolist() == [5]
+    # and the reference-shaped data list says the same
+    data = proto.handle_messange(raw, Sock())
+    assert [v[2][1] for v in data[1]] == [0, -1, 5, 0]
+    bad = f.copy(); bad[0, 0] = -1
+    with pytest.raises(ValueError):
+        proto.request_records(proto.decode_message(proto.encode_request((4, 1, 1), bad, (0, 0, 0), False, [4])))
+    bad = f.copy(); bad[0, 1] = 1
+    with pytest.raises(ValueError):
+        proto.request_records(proto.decode_message(proto.encode_request((4, 1, 1), bad, (0, 0, 0), False, [4])))
+    bad = f.copy(); bad[0, 8] = -3
+    with pytest.raises(ValueError):
+        proto.request_records(proto.decode_message(proto.encode_request((4, 1, 1), bad, (0, 0, 0), False, [4])))

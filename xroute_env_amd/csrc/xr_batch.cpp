@@ -176,7 +176,7 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
     if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
     if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_QUEUE || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
-        return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED or XR_OBS_SPLIT; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
+        return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -203,6 +203,11 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipSetDevice(b->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int B = b->cfg.n_envs;
+    // a reload invalidates the batch until it has completed: a failure midway must not leave `loaded` set over
+    // freed or partly reallocated device buffers
+    b->loaded = false;
+    b->n_cus = 0;
+    memset(&b->dev, 0, sizeof(b->dev));
 
     std::vector<XrRegionDev> hreg(n_regions);
     std::vector<uint32_t> hrec;
@@ -296,9 +301,6 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         }
     }
     const int legal_words = std::max(1, (k_max + 63) / 64);
-    // the observation kernels stage the ascending legal-id list in LDS (4 bytes per possible net)
-    if ((size_t)legal_words * 64 * 4 + (size_t)(legal_words + 1) * 4 > 60 * 1024)
-        return fail(XR_ERR_RANGE, "k_max %d too large for the observation kernel's LDS id list (max ~15000 nets)", k_max);
     // the observation kernels stage the ascending legal-id list in LDS (4 bytes per possible net)
     if ((size_t)legal_words * 64 * 4 + (size_t)(legal_words + 1) * 4 > 60 * 1024)
         return fail(XR_ERR_RANGE, "k_max %d too large for the observation kernel's LDS id list (max ~15000 nets)", k_max);

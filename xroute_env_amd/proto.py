@@ -122,7 +122,13 @@ def handle_messange(message, socket):
 
 def request_records(msg: DecodedMessage):
     """Dense packed node records (flat order) + coordinate arrays of a decoded Request: the array
-    form the device path consumes (no Python lists)."""
+    form the device path consumes (no Python lists).
+
+    Node-type mapping as handle_messange + getObstaclesAndAccessPoints see it (baseline_utils.py:23-28,
+    build_3Dgrid.py:19-43): an ACCESS node whose wire net is -1 becomes `Net == 0`, i.e. a plain node (obstacle only
+    when used); wire net -2 becomes `Net == -1`, i.e. an obstacle; anything lower trips the reference's
+    `assert Net >= 1` — here a ValueError.  Maze indices outside the region raise too (the reference wraps negative
+    indices silently and dies with an IndexError on large ones, build_3Dgrid.py:100-102)."""
     X, Y, Z = msg.dims
     n = X * Y * Z
     f = msg.fields.astype(np.int64)
@@ -131,10 +137,21 @@ def request_records(msg: DecodedMessage):
     net = np.full(n, -1, np.int64)
     pin = np.full(n, -1, np.int64)
     if len(f):
+        if len(f) > n:
+            raise ValueError(f"Request lists {len(f)} nodes for a {X}x{Y}x{Z} region")
+        m = f[:, 0:3]
+        if (m < 0).any() or (m[:, 0] >= X).any() or (m[:, 1] >= Y).any() or (m[:, 2] >= Z).any():
+            raise ValueError("maze index outside the region dimensions")
+        t = f[:, 6].copy()
+        acc = t == ACCESS
+        if (acc & (f[:, 8] < -2)).any():
+            raise ValueError("ACCESS node with net id < -2 (the reference asserts Net >= 1)")
+        t[acc & (f[:, 8] == -1)] = NORMAL          # Net == 0: a plain node
+        t[acc & (f[:, 8] == -2)] = BLOCKAGE        # Net == -1: an obstacle
+        acc = t == ACCESS
         flat = (f[:, 0] * Y + f[:, 1]) * Z + f[:, 2]
-        ntype[flat] = f[:, 6]
+        ntype[flat] = t
         used[flat] = f[:, 7]
-        acc = f[:, 6] == ACCESS
         net[flat] = np.where(acc, f[:, 8], -1)
         pin[flat] = np.where(acc, f[:, 9], -1)
     return pack_records(ntype, used, net, pin)
