@@ -5,19 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the rank's batch of ispd18_test1-sized regions
-(BASELINE config 3, 4096 env slots per GPU, random net-order policy chosen on the device):
+One "step" = one pass of the hot path over the rank's batch of ispd18_test1-sized regions (north_star target: a 4096-env
+batch; 4096 env slots per GPU by default = weak scaling, `--global-envs 4096` = the same batch split over the ranks =
+strong scaling, BASELINE config 4 at N = 8):
 
-    xr_batch_random_actions -> xr_batch_step (grid build + XR-Maze v1 route + metrics/reward,
-    finished envs are re-initialised) -> xr_batch_observation (reference-layout fp32 [2+7K,Z,Y,X] of
-    every env) -> (N > 1) RCCL all_gather of the compact per-env result record.
+    xr_batch_random_actions (random net-order policy, chosen on the device)
+    -> xr_batch_step_observe = xr_plan_kernel + ONE persistent launch (xr_step_queue_kernel) that routes the chosen net of
+       every env (grid build + XR-Maze v1 + claim + metrics/reward; finished envs are re-initialised) and writes the
+       reference-layout fp32 [2+7K,Z,Y,X] observation of every env
+    -> (N > 1) RCCL all_gather of the 48-byte per-env result records.
 
-All inputs are resident in HBM before the timed region.  `value` counts REAL env-steps (a slot
-that spends the step re-initialising a finished episode is not counted) over all ranks / max-rank time.
-The JSON line also carries `roofline` (dominant kernel, HIP-event timed live) and, on rank 0 at N=1,
-`cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+All inputs are resident in HBM before the timed region.  Before anything is timed the episodes are STAGGERED: env e
+is advanced by hash(e) mod (K0_e + 1) untimed route-only steps, so that every env sits at a uniformly random phase of
+its (periodic) episode cycle — the nets-left distribution is then stationary and `value` does not depend on --warmup.
+`value` counts REAL env-steps (a slot that spends the step re-initialising a finished episode is not counted) over all
+ranks / max-rank time.
+
+The JSON line also carries `roofline` (the step kernel, HIP-event timed live on its launch stream), `kernels` (per kernel:
+the step kernel, the route-only kernel xr_batch_step, and — rank 0, N = 1 — the BASELINE config 5 route kernel on
+256x256x12 regions, each with its own bytes / ms / fraction), `parity` (oracle replay of the run's own actions) and
+`cpu_baseline` (the C oracle on the host cores: one thread and all cores, bounded samples).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+STAGGER_SEED = 0x5EED5EED
 
 
 def parse():
@@ -35,18 +46,26 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
+    ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU (weak scaling)")
+    ap.add_argument("--global-envs", type=int, default=0,
+                    help="total env slots over all ranks (strong scaling: each rank takes its contiguous share); overrides --envs")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--router", type=int, default=0, help="xr_config.router: 0 default, 1 line-segment sweeps, 2 bucketed frontier")
+    ap.add_argument("--dial-mult", type=int, default=0)
     ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0 default (queue form where it applies), 1 fused launch, 2 split, 3 queue")
     ap.add_argument("--writer-blocks", type=int, default=0)
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
                          "synthetic generator; NOT the headline workload")
-    ap.add_argument("--no-observation", action="store_true", help="skip xr_batch_observation (NOT the headline)")
+    ap.add_argument("--no-observation", action="store_true", help="skip the observation (NOT the headline)")
+    ap.add_argument("--no-stagger", action="store_true", help="start every episode at step 0 (round-1 behaviour: NOT stationary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra per-kernel legs (route-only, config 5)")
     ap.add_argument("--no-fuse", action="store_true",
-                    help="two launches (xr_batch_step, xr_batch_observation) instead of the fused xr_batch_step_observe")
+                    help="two launches (xr_batch_step, xr_batch_observation) instead of xr_batch_step_observe")
+    ap.add_argument("--c5-envs", type=int, default=1024, help="env slots of the BASELINE config 5 leg (256x256x12 regions)")
+    ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -54,27 +73,59 @@ def parse():
     return ap.parse_args()
 
 
+def source_sha():
+    """Identity of the kernels being measured (profiles/pmc_traffic.json is only quoted for the same build)."""
+    h = hashlib.sha256()
+    for f in ("xr_kernels.hip", "xr_dial.h", "xr_device.h", "xr_batch.cpp"):
+        with open(os.path.join(ROOT, "xroute_env_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _gen_chunk(args):
+    config, lo, hi = args
+    from xroute_env_amd.regions import config_regions
+    return config_regions(config, hi - lo, first_env=lo)
+
+
+def gen_regions(config, n, first_env=0):
+    """Synthetic regions of a BASELINE config, generated on the host cores (fork pool: call BEFORE touching the GPU)."""
+    workers = min(os.cpu_count() or 1, 32, max(1, n // 16))
+    if workers <= 1:
+        return _gen_chunk((config, first_env, first_env + n))
+    import multiprocessing as mp
+    step = (n + workers - 1) // workers
+    chunks = [(config, first_env + lo, first_env + min(lo + step, n)) for lo in range(0, n, step)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_gen_chunk, chunks)
+    return [r for p in parts for r in p]
+
+
+def splitmix64(x):
+    import numpy as np
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def stagger_offsets(nlegal0, first_env):
+    """Untimed steps env e is advanced by before the run: hash(global env id) mod (K0 + 1) = a uniform phase of its cycle."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        ids = np.arange(first_env, first_env + len(nlegal0), dtype=np.uint64)
+        r = splitmix64(ids ^ np.uint64(STAGGER_SEED))
+    return (r % (nlegal0.astype(np.uint64) + np.uint64(1))).astype(np.int64)
+
+
 def cpu_baseline(regions, seconds, with_obs=True):
-    """Oracle (`port`) on the host cores: same workload, bounded sample."""
+    """Oracle (`port`) on the host cores, same workload, bounded samples: all cores (>= 8 envs per thread, OpenMP dynamic
+    schedule) and a single thread."""
     import numpy as np
     from oracle import xr_oracle as orc
-    n = min(len(regions), 256)
-    ob = orc.OracleBatch(regions[:n])
-    threads = ob.max_threads()
-    stride = max((2 + 7 * r.n_nets) * r.n_nodes for r in regions[:n])
-    obs = np.empty((n, stride), np.float32) if with_obs else None
-    t0 = time.perf_counter()
-    real = 0
-    it = 0
-    while True:
-        acts = ob.random_actions(99)
-        real += ob.step(acts, threads=threads, auto_reset=True)["real_steps"]
-        if with_obs:
-            ob.observation(obs, stride, threads=threads)
-        it += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or it >= 400:
-            break
+    probe = orc.OracleBatch(regions[:1])
+    threads = probe.max_threads()
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -83,39 +134,101 @@ def cpu_baseline(regions, seconds, with_obs=True):
                 break
     except OSError:
         pass
-    return {"value": real / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} envs x {it} batched steps (route + fp32 observation) in {dt:.1f}s, "
-                      f"oracle/xr_oracle.c OpenMP over envs, host cpu '{model}' ({os.cpu_count()} logical)"}
+
+    def run(n, thr, secs, max_it):
+        ob = orc.OracleBatch(regions[:n])
+        stride = max((2 + 7 * r.n_nets) * r.n_nodes for r in regions[:n])
+        obs = np.empty((n, stride), np.float32) if with_obs else None
+        # same stagger as the GPU run: the K distribution is the stationary one
+        nl0 = np.array([e.nlegal() for e in ob.envs])
+        off = stagger_offsets(nl0, 0)
+        for i in range(int(off.max()) if len(off) else 0):
+            a = ob.random_actions(7 + i)
+            a[off <= i] = 0
+            ob.step(a, threads=thr, auto_reset=True)
+        t0 = time.perf_counter()
+        real = it = 0
+        while True:
+            acts = ob.random_actions(99 + it)
+            real += ob.step(acts, threads=thr, auto_reset=True)["real_steps"]
+            if with_obs:
+                ob.observation(obs, stride, threads=thr)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt >= secs or it >= max_it:
+                break
+        return real / dt, n, it, dt
+
+    n_all = min(len(regions), max(256, 8 * threads))
+    v_all, n_a, it_a, dt_a = run(n_all, threads, seconds * 0.6, 400)
+    v_one, n_1, it_1, dt_1 = run(min(len(regions), 32), 1, seconds * 0.4, 400)
+    what = "route + fp32 observation" if with_obs else "route only"
+    return {"value": v_all, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1,
+                              "sample": f"{n_1} envs x {it_1} batched steps ({what}) in {dt_1:.1f}s"},
+            "sample": f"north_star target workload (4096-env batch of ispd18_test1-sized regions), bounded sample: {n_a} envs "
+                      f"({n_a / threads:.1f} per thread, OpenMP dynamic schedule over envs) x {it_a} batched steps ({what}, stationary "
+                      f"nets-left distribution) in {dt_a:.1f}s, oracle/xr_oracle.c, host cpu '{model}' ({os.cpu_count()} logical)"}
 
 
-def parity_check(regions, seeds, gpu_hash, gpu_cum, n_check=256):
+def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256):
     """Checker leg (oracle as the CHECKER, never the thing measured): replays the bench's own action sequence — the
     device policy is a counter-based hash of (seed, env, step count), bit-identical in the oracle — on the first
-    `n_check` envs and compares every env's hash chain (all path nodes, metrics and actions of every step) and
-    cumulative metrics with what the GPU produced during the timed run."""
+    `n_check` envs (stagger pre-roll, warm-up and timed steps) and compares every env's hash chain (all path nodes, metrics
+    and actions of every step) and cumulative metrics with what the GPU produced."""
     import numpy as np
     from oracle import xr_oracle as orc
     n = min(len(regions), n_check)
     ob = orc.OracleBatch(regions[:n])
     threads = ob.max_threads()
     steps = 0
+    if stagger is not None:
+        off, pre_seeds = stagger
+        for i, sd in enumerate(pre_seeds):
+            a = ob.random_actions(sd)
+            a[off[:n] <= i] = 0
+            steps += ob.step(a, threads=threads, auto_reset=True)["real_steps"]
     for sd in seeds:
         steps += ob.step(ob.random_actions(sd), threads=threads, auto_reset=True)["real_steps"]
     ref_hash = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
     ref_cum = np.stack([e.cum() for e in ob.envs])
     return {"envs": n, "env_steps": int(steps), "hash_chains_equal": bool(np.array_equal(ref_hash, gpu_hash[:n])),
             "cumulative_metrics_equal": bool(np.array_equal(ref_cum, gpu_cum[:n])),
-            "what": "CPU oracle replay of the same actions on the first envs of rank 0, all warm-up + timed steps"}
+            "what": "CPU oracle replay of the same actions on the first envs of rank 0: stagger pre-roll + warm-up + timed steps"}
+
+
+def kernel_entry(name, ms, nbytes, env_steps, bound, note):
+    ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": name, "bound": bound, "ms": ms, "bytes": nbytes, "achieved": ach, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS, "env_steps_per_s": env_steps / (ms * 1e-3) if ms > 0 else 0.0, "note": note}
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- env slots of this rank; regions are generated on the host cores BEFORE the GPU is touched (fork pool) -------
+    strong = args.global_envs > 0
+    if strong:
+        from xroute_env_amd.dist import shard_range
+        lo, hi = shard_range(args.global_envs, world, rank)
+        B, first_env = hi - lo, lo
+    else:
+        B, first_env = args.envs, rank * args.envs
+    if args.region_pack:
+        from xroute_env_amd.lefdef import load_region_pack
+        regions = load_region_pack(args.region_pack)
+    else:
+        regions = gen_regions(args.config, B, first_env)
+    do_legs = world == 1 and rank == 0 and not args.no_legs and not args.region_pack
+    c5_regions = gen_regions(5, min(args.c5_regions, args.c5_envs)) if do_legs and args.c5_envs > 0 else None
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # XR_BENCH_BACKEND=gloo + XR_BENCH_SAME_DEVICE=1: run the N > 1 control flow (barriers, max-over-ranks timing, the
     # batched-env gather) with every rank on cuda:0 of a single-GPU box — a functional check of this path, not a
     # measurement; the driver's multi-GPU runs use the default (RCCL, one rank per GPU)
@@ -143,29 +256,37 @@ def main():
         del ca, cb
 
     from xroute_env_amd.batch import RegionBatch
-    from xroute_env_amd.dist import RECORD_WIDTH, gather_records_fixed, pack_records
-    from xroute_env_amd.regions import config_regions
+    from xroute_env_amd.dist import RECORD_BYTES, gather_records_fixed
 
-    B = args.envs
-    if args.region_pack:
-        from xroute_env_amd.lefdef import load_region_pack
-        regions = load_region_pack(args.region_pack)
-    else:
-        regions = config_regions(args.config, B, first_env=rank * B)
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
-                        obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks)
+                        obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
+                        dial_mult=args.dial_mult)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()
-    # compact per-env result record gathered across ranks (xroute_env_amd/dist.py): 6 x f64 per env
-    rec_local = torch.empty((B, RECORD_WIDTH), dtype=torch.float64, device=dev)
-    rec_all = torch.empty((world * B, RECORD_WIDTH), dtype=torch.float64, device=dev) if world > 1 else None
-    reward = torch.empty(B, dtype=torch.float64, device=dev)
-    delta = torch.empty((B, 3), dtype=torch.int32, device=dev)
-    done = torch.empty(B, dtype=torch.uint8, device=dev)
+    # compact per-env result record gathered across ranks: the 48-byte xr_step_record the kernels write themselves
+    rec_local = torch.empty((B, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    rec_all = torch.empty((world * B, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 and not strong else None
+    if world > 1 and strong:
+        rec_all = torch.empty((args.global_envs, RECORD_BYTES), dtype=torch.uint8, device=dev) \
+            if args.global_envs % world == 0 else None
     nsteps_total = args.warmup + args.steps
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
     n_nodes = torch.tensor([regions[e % len(regions)].n_nodes for e in range(B)], dtype=torch.float64, device=dev)
+
+    # ---- stagger: every env to a uniform phase of its episode cycle (untimed, route-only steps) ----------------------
+    stagger = None
+    if not args.no_stagger:
+        nl0 = batch.fetch("nlegal").cpu().numpy()
+        off = stagger_offsets(nl0, first_env)
+        off_d = torch.from_numpy(off).to(dev)
+        pre_seeds = [args.seed ^ 0x51A6 ^ (rank * 7919 + i) for i in range(int(off.max()) if B else 0)]
+        zero = torch.zeros_like(acts)
+        for i, sd in enumerate(pre_seeds):
+            batch.random_actions(sd, acts)
+            torch.where(off_d > i, acts, zero, out=acts)
+            batch.step(acts)
+        stagger = (off, pre_seeds)
 
     fused = (obs is not None) and not args.no_fuse
 
@@ -174,7 +295,7 @@ def main():
         if ev:
             ev[0].record()
         if fused:
-            batch.step(acts, obs)                 # one launch: route + observation of every env
+            batch.step(acts, obs)                 # plan + one persistent launch: route + observation of every env
             if ev:
                 ev[1].record()
         else:
@@ -186,12 +307,13 @@ def main():
         if ev:
             ev[2].record()
         batch.fetch("nlegal", nlegal_log[i])
-        batch.fetch("reward", reward)
-        batch.fetch("delta", delta)
-        batch.fetch("done", done)
+        batch.fetch("record", rec_local)
         if world > 1:
-            pack_records(reward, delta, done, nlegal_log[i], rec_local)
-            gather_records_fixed(rec_local, rec_all)             # RCCL over xGMI: the batched-env gather
+            if rec_all is not None:
+                gather_records_fixed(rec_local, rec_all)         # RCCL over xGMI: the batched-env gather
+            else:
+                from xroute_env_amd.dist import gather_records
+                gather_records(rec_local)
 
     for i in range(args.warmup):
         one_step(i)
@@ -209,6 +331,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     real_steps = batch.total_steps() - steps0
+    gpu_hash = batch.fetch("hash").cpu().numpy().view("uint64")          # state right after the timed region
+    gpu_cum = batch.fetch("cum").cpu().numpy()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([float(real_steps)], dtype=torch.float64, device=dev)
@@ -218,53 +342,81 @@ def main():
     elapsed_max, total_real = float(t.item()), float(s.item())
 
     # ---- per-kernel live timing (HIP events on the launch stream) and algorithmic bytes -----------
-    route_ms = sum(e[0].elapsed_time(e[1]) for e in events) / max(args.steps, 1)
-    obs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / max(args.steps, 1)
+    nst = max(args.steps, 1)
+    route_ms = sum(e[0].elapsed_time(e[1]) for e in events) / nst
+    obs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / nst
     k_after = nlegal_log[args.warmup:args.warmup + args.steps].to(torch.float64)          # K written by each obs launch
-    obs_bytes = float(((4.0 * (2.0 + 7.0 * k_after) + 4.0) * n_nodes[None, :]).sum().item()) / max(args.steps, 1)
-    # route launch: every stepped env loads its compact state (node_net i16 + owner i16 = 4 B/node); path writes are noise
-    route_bytes = float((4.0 * n_nodes).sum().item())
+    # a slot loads its compact state (node_net i16 + owner i16 = 4 B/node; a slot that re-initialises reads and
+    # writes 2 B/node each = 4 B/node too) and the observation writes 4·N·(2+7K); path / result writes are noise
+    state_bytes = float((4.0 * n_nodes).sum().item())
+    obs_bytes = float((4.0 * (2.0 + 7.0 * k_after) * n_nodes[None, :]).sum().item()) / nst
+    real_per_step = real_steps / nst
     kernels = []
     if fused:
         form = batch.observe_timing()[0]            # 1 fused launch, 2 split, 3 queue (the default where it applies)
-        if form == 3:
-            kname = "xr_step_queue_kernel"
-            note = ("step kernel, queue form (xr_batch_step_observe): one persistent launch whose workgroups drain two task "
-                    "queues — envs to route (LDS-resident field, latency-bound) + their planes 0..1, and net-plane units of "
-                    "the fp32 observation (HBM-write-bound); the HIP-event time also covers the planning kernel "
-                    "(xr_plan_kernel, ~10 us) that precedes it on the same stream; bytes = state load + observation")
-        else:
-            kname = "xr_route_kernel"
-            note = ("fused step kernel (xr_batch_step_observe): per env one workgroup routes the net (LDS-resident, "
-                    "latency-bound) and then streams the fp32 observation (HBM-write-bound); bytes = state load + observation"
-                    + ("; split form: the net planes come from xr_netplane_kernel on an internal stream" if form == 2 else ""))
-        kernels.append({"kernel": kname, "bound": "hbm", "ms": route_ms, "bytes": obs_bytes + route_bytes,
-                        "achieved": (obs_bytes + route_bytes) / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
-                        "note": note})
+        kname = "xr_step_queue_kernel" if form == 3 else "xr_route_kernel"
+        note = ("the step kernel (xr_batch_step_observe, queue form): one persistent launch draining route tasks (LDS-resident "
+                "router: latency-bound) and net-plane units of the fp32 observation (HBM-write-bound) — a MIXED kernel, priced "
+                "against the HBM roofline because >99 % of its bytes are the observation stream; the HIP-event time also covers "
+                "the planning kernel (~8 us) before it; bytes = state load + observation" if form == 3 else
+                "fused step kernel (xr_batch_step_observe): per env one workgroup routes, then streams the fp32 observation; "
+                "bytes = state load + observation" + ("; split form: net planes from xr_netplane_kernel" if form == 2 else ""))
+        kernels.append(kernel_entry(kname, route_ms, obs_bytes + state_bytes, real_per_step, "hbm-write (routing phase: lds-latency)", note))
     else:
         if obs is not None:
-            kernels.append({"kernel": "xr_obs_kernel", "bound": "hbm", "ms": obs_ms, "bytes": obs_bytes,
-                            "achieved": obs_bytes / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else 0.0})
-        kernels.append({"kernel": "xr_route_kernel", "bound": "hbm", "ms": route_ms, "bytes": route_bytes,
-                        "achieved": route_bytes / (route_ms * 1e-3) / 1e9 if route_ms > 0 else 0.0,
-                        "note": "distance field LDS-resident: LDS/latency-bound by construction, HBM bytes are the state load only"})
+            kernels.append(kernel_entry("xr_obs_kernel", obs_ms, obs_bytes + state_bytes, real_per_step, "hbm-write", "stand-alone observation"))
+        kernels.append(kernel_entry("xr_route_kernel", route_ms, state_bytes, real_per_step, "lds-latency",
+                                    "route-only step (xr_batch_step): distance field LDS-resident, HBM bytes are the state load only"))
     dom = max(kernels, key=lambda k: k["ms"])
+
+    # ---- extra legs (rank 0, N = 1): route-only kernel and BASELINE config 5, each with its own numbers ---------------
+    if do_legs:
+        try:
+            n_leg = max(args.steps, 5)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_leg)]
+            s0 = batch.total_steps()
+            for i, (e0, e1) in enumerate(evs):
+                batch.random_actions(args.seed + 100000 + i, acts)
+                e0.record()
+                batch.step(acts)
+                e1.record()
+            torch.cuda.synchronize(dev)
+            ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_leg
+            real = (batch.total_steps() - s0) / n_leg
+            if fused:
+                kernels.append(kernel_entry("xr_route_kernel", ms, state_bytes, real, "lds-latency",
+                                            f"route-only step (xr_batch_step) on the same {B} envs at the same stationary nets-left distribution: "
+                                            "the distance field never leaves LDS, so the HBM fraction is ~1 % by construction; "
+                                            "env_steps_per_s is the figure of merit"))
+        except Exception as ex:          # a leg must never take the headline down
+            kernels.append({"kernel": "xr_route_kernel", "error": str(ex)})
+        if c5_regions:
+            try:
+                kernels.append(config5_leg(args, c5_regions, dev))
+            except Exception as ex:
+                kernels.append({"kernel": "config5 route", "error": str(ex)})
+
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # measured offline with rocprofv3 --pmc (see profiles/README.md)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes of THIS command (tools/profile_round.sh)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom["kernel"])
-            if isinstance(traffic, dict):
-                traffic = traffic.get("hbm_total_bytes")
+            pj = json.load(open(pmc))
+            same = pj.get("source_sha") == source_sha() and pj.get("bench_args") == bench_args_key(args, world)
+            if same and isinstance(pj.get(dom["kernel"]), dict):
+                traffic = pj[dom["kernel"]].get("hbm_total_bytes")
         except Exception:
             traffic = None
     roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(dom["achieved"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this exact command and build "
+                                 "(profiles/pmc_traffic.json)" if traffic is not None else
+                                 "null: no PMC pass recorded for this build + command (profiles/pmc_traffic.json carries the last one with its source hash)"),
                 "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes"])}
 
     out = None
     if rank == 0:
         mean_k = float(k_after.mean().item())
+        Bg = args.global_envs if strong else B * world
         out = {
             "metric": "env-steps/sec (batched regions), ispd18_test1-sized regions",
             "value": round(total_real / elapsed_max, 1),
@@ -272,30 +424,32 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4),
+            "ms_per_step": round(elapsed_max / nst * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32 distances / i16 state / fp32 observation",
             "data": "synthetic",
             "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)}, "
                                     if args.region_pack else
-                                    f"BASELINE config {args.config}: {B} ispd18_test1-sized regions (24x40x9, K~U[4,36]) per GPU, ")
+                                    f"north_star target: a {Bg}-env batch of ispd18_test1-sized regions (24x40x9, K~U[4,36]; generator of "
+                                    f"BASELINE configs 2-4), {B} per GPU, ")
                                    +
                                    "full step = random net-order action + XR-Maze v1 route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
                                    + (" (one persistent launch after a planning kernel)" if fused and batch.observe_timing()[0] == 3 else " (fused launch)" if fused else "")
-                                   + (", RCCL all_gather of per-env results" if world > 1 else ""),
-                       "envs_per_gpu": B, "global_envs": B * world, "parallelism": f"env-shard x{world}",
-                       "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (args.steps * B * world), 4)},
+                                   + (", RCCL all_gather of per-env results" if world > 1 else "")
+                                   + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
+                       "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}",
+                       "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (nst * B * world), 4),
+                       "router": {0: "default", 1: "sweep", 2: "dial"}[args.router], "source_sha": source_sha()},
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
         if world == 1 and not args.no_cpu_baseline and not args.region_pack and len(regions) >= B:
             try:        # regions == env slots: rotation keeps every slot on its region, the oracle subset can follow
                 seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
-                out["parity"] = parity_check(regions, seeds, batch.fetch("hash").cpu().numpy().view("uint64"),
-                                             batch.fetch("cum").cpu().numpy())
+                out["parity"] = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum)
             except Exception as ex:
                 out["parity"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
@@ -308,6 +462,55 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_args_key(args, world):
+    return {"gpus": world, "steps": args.steps, "warmup": args.warmup, "envs": args.envs, "global_envs": args.global_envs,
+            "config": args.config, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
+            "no_stagger": bool(args.no_stagger)}
+
+
+def config5_leg(args, c5_regions, dev):
+    """BASELINE config 5 (synthetic 256x256x12 dense-congestion regions), route-only step with the compact state (the fp32
+    observation of one such env would be 711 MB): its own kernel entry with SURVEY §8(d)'s algorithmic bytes."""
+    import torch
+    from xroute_env_amd.batch import RegionBatch
+    Bc = args.c5_envs
+    b5 = RegionBatch(c5_regions, n_envs=Bc, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult)
+    b5.reset()
+    a5 = torch.empty(Bc, dtype=torch.int32, device=dev)
+    for i in range(2):
+        b5.random_actions(555 + i, a5)
+        b5.step(a5)
+    n_t = 5
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
+    s0 = b5.total_steps()
+    sweeps = 0.0
+    plen = 0.0
+    for i, (e0, e1) in enumerate(evs):
+        b5.random_actions(600 + i, a5)
+        e0.record()
+        b5.step(a5)
+        e1.record()
+        sweeps += float(b5.fetch("sweeps").double().sum().item())
+        plen += float(b5.fetch("path_len").double().sum().item())
+    torch.cuda.synchronize(dev)
+    ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
+    real = (b5.total_steps() - s0) / n_t
+    N = float(c5_regions[0].n_nodes)
+    # SURVEY §8(d), HBM-resident maze route: 9·N·S per env-step (S relaxation sweeps) + back-trace 8·L + owner update 2·L,
+    # plus the state load 4·N.  S = the rounds / iterations the router reports (XR_FETCH_SWEEPS): a FULL-sweep algorithm would
+    # move these bytes; this router touches only the nodes near the wavefront, so `touched_bytes_estimate` is what it moves.
+    formula = (4.0 * N * Bc * n_t + 9.0 * N * sweeps + 10.0 * plen) / n_t
+    ent = kernel_entry("xr_route_kernel (BASELINE config 5: 256x256x12)", ms, formula, real, "l2-latency",
+                       f"{Bc} env slots over {len(c5_regions)} distinct regions, K = 32, route-only (compact state); bytes = SURVEY §8(d) formula "
+                       "4·N + 9·N·S + 10·L with S = router rounds: what a full-sweep router would move — the work-efficient router moves far "
+                       "less, so `frac` here is an upper-bound style figure, not HBM utilisation; env_steps_per_s is the figure of merit")
+    ent["mean_rounds"] = sweeps / (n_t * Bc)
+    ent["mean_path_nodes"] = plen / (n_t * Bc)
+    ent["envs"] = Bc
+    b5.close()
+    return ent
 
 
 if __name__ == "__main__":

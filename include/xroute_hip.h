@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 2
+#define XR_ABI_VERSION 3
 
 /* status codes */
 #define XR_OK            0
@@ -77,6 +77,8 @@ typedef struct xr_batch xr_batch;
  * (ispd/ispd18_test1/run-net-ordering-training.tcl:3 `-drc_cost 8`), the reward weights its
  * trainers (baseline/DQN/train_DQN.py:98-99, baseline/PPO/train_PPO.py:101-102), max_route_count
  * its control plane (examples/launch_training.py:28). */
+#define XR_ROUTER_SWEEP 1
+#define XR_ROUTER_DIAL  2
 #define XR_OBS_FUSED 1
 #define XR_OBS_SPLIT 2
 #define XR_OBS_QUEUE 3
@@ -102,6 +104,10 @@ typedef struct xr_config {
     double  w_wirelength;     /* 0.5  */
     int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer; XR_OBS_QUEUE: workgroups of the
                                   persistent launch (0 = default: 512 / as many as are resident on the chip) */
+    int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = default (XR_ROUTER_DIAL where the
+                                 region fits, else XR_ROUTER_SWEEP), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
+                                 worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
+    int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 4) */
     int32_t obs_split_permille; /* XR_OBS_SPLIT: per mille of every env's net planes (its highest-ranked nets) that the
                                    writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all).
                                    XR_OBS_QUEUE: units a workgroup writes after each route task, per mille of the average
@@ -135,8 +141,25 @@ typedef struct xr_region_desc {
 #define XR_FETCH_REGION   11   /* int32 [B]     region index the env currently plays */
 #define XR_FETCH_STEPS    12   /* int64 [1]     env-steps (real routes, not resets) since create */
 #define XR_FETCH_SWEEPS   13   /* int32 [B]     relaxation sweeps used by the last step */
+#define XR_FETCH_RECORD   15   /* xr_step_record[B]  everything a caller needs after a step or a reset, one 48-byte
+                                                 record per env (written by the kernels themselves: one copy, one sync) */
 #define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
                                                  built with -DXR_PHASE_TIMING) */
+
+/* Per-env result of the last xr_batch_step* / xr_batch_reset: what Game.step returns besides the observation
+ * (baseline/baseline_utils.py:426-439) plus what Game.reset records (:472-473), packed for one transfer — also the
+ * record that the multi-GPU gather exchanges (one all_gather of B x 48 bytes per step). */
+typedef struct xr_step_record {
+    double   reward;       /* -(500 dvio + 4 dvia + 0.5 dwl), train_DQN.py:98-99 */
+    int32_t  delta[3];     /* violation, wirelength, via of the last step */
+    int32_t  cum[3];       /* cumulative metrics (data[2]) */
+    int32_t  nlegal;       /* len(netSet) */
+    int32_t  env_steps;    /* real steps of this env slot since create (low 32 bits) */
+    int32_t  path_len;
+    uint8_t  done;
+    uint8_t  pad;
+    uint16_t status;       /* XR_ENV_* bits */
+} xr_step_record;
 
 int32_t     xr_abi_version(void);
 const char* xr_last_error(void);

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo processes shard the env batch, step their shard (the oracle stands
-in for the GPU env here — tests may use it) and all-gather the compact per-env records.  The gathered
-result must equal the single-process run of the whole batch, env for env."""
+in for the GPU env here — tests may use it) and exchange exactly what the RCCL path exchanges: an all-gather of the
+48-byte per-env records (+ legal bitmasks) and, in the learner flow of BASELINE config 4, one broadcast of the actions
+chosen on rank 0.  The gathered results must equal the single-process run of the whole batch, env for env."""
 import os
 import socket
 
@@ -10,11 +11,12 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from xroute_env_amd.dist import RECORD_WIDTH, env_seed, gather_records, pack_records, shard_range
+from xroute_env_amd.dist import (RECORD_BYTES, ShardedVectorEnv, first_legal_policy, gather_records, pack_records,
+                                 shard_range, unpack_records)
 
 N_TOTAL = 11          # ragged on purpose (6 + 5)
-STEPS = 5
-DIMS = dict(dims=(8, 7, 3), k_range=(2, 4))
+STEPS = 7
+CONFIG = 9
 
 
 def _free_port():
@@ -25,39 +27,80 @@ def _free_port():
     return p
 
 
-def _run_shard(lo, hi, steps):
-    from oracle import xr_oracle as orc
-    from xroute_env_amd.regions import generate_region
-    regions = [generate_region(env_seed(9, e), **DIMS) for e in range(lo, hi)]
-    ob = orc.OracleBatch(regions)
-    out = []
-    for it in range(steps):
-        # the random policy hashes (seed, local index, step count): make the seed carry the global offset
-        acts = np.zeros(hi - lo, np.int32)
-        for i, e in enumerate(ob.envs):
-            legal = e.legal()
-            acts[i] = legal[(lo + i + it) % len(legal)] if len(legal) else 0
-        r = ob.step(acts, threads=1, auto_reset=True)
-        nleg = np.array([e.nlegal() for e in ob.envs])
-        rec = pack_records(torch.from_numpy(r["reward"]), torch.from_numpy(r["delta"]), torch.from_numpy(r["done"]),
-                           torch.from_numpy(nleg))
-        out.append(rec)
-    return out
+class OracleVectorEnv:
+    """CPU stand-in with XRouteVectorEnv's surface (reset / step -> obs, reward, done, info with `record` and `legal`),
+    backed by the oracle.  Lets the collective logic of ShardedVectorEnv run under gloo without a GPU."""
+
+    def __init__(self, regions, device=None, with_observation=False, **kw):
+        from oracle import xr_oracle as orc
+        self.ob = orc.OracleBatch(regions)
+        self.n_envs = len(regions)
+        self.device = torch.device("cpu")
+        self.k_max = max(r.n_nets for r in regions)
+        self.words = max(1, (self.k_max + 63) // 64)
+
+    def _info(self, reward, delta, done):
+        nleg = np.array([e.nlegal() for e in self.ob.envs], np.int32)
+        cum = np.stack([e.cum() for e in self.ob.envs])
+        steps = np.array([e.steps() for e in self.ob.envs], np.int32)
+        rec = pack_records(torch.from_numpy(reward), torch.from_numpy(delta), torch.from_numpy(done), torch.from_numpy(nleg),
+                           cum=torch.from_numpy(cum), env_steps=torch.from_numpy(steps))
+        legal = np.zeros((self.n_envs, self.words), np.uint64)
+        for i, e in enumerate(self.ob.envs):
+            for n in e.legal():
+                legal[i, (n - 1) >> 6] |= np.uint64(1) << np.uint64((n - 1) & 63)
+        return {"record": rec, "legal": torch.from_numpy(legal.view(np.int64)), "nlegal": torch.from_numpy(nleg),
+                "delta": torch.from_numpy(delta)}
+
+    def reset(self):
+        for e in self.ob.envs:
+            e.reset()
+        z = np.zeros(self.n_envs)
+        return None, self._info(z, np.zeros((self.n_envs, 3), np.int32), np.zeros(self.n_envs, np.uint8))
+
+    def step(self, actions):
+        r = self.ob.step(actions.cpu().numpy(), threads=1, auto_reset=True)
+        info = self._info(r["reward"], r["delta"], r["done"])
+        return None, torch.from_numpy(r["reward"]), torch.from_numpy(r["done"]), info
+
+
+DIMS = dict(dims=(8, 7, 3), k_range=(2, 4))
+
+
+def _make_env(n_total):
+    import xroute_env_amd.regions as rg
+    rg.CONFIGS[CONFIG] = DIMS                      # a tiny test-only config id
+    return ShardedVectorEnv(CONFIG, n_total, env_factory=OracleVectorEnv, with_observation=False)
+
+
+def _run_learner(n_total, steps):
+    env = _make_env(n_total)
+    _, acts = env.learner_reset(first_legal_policy)
+    recs, sent = [], []
+    for _ in range(steps):
+        sent.append(acts.clone())
+        _, rec_all, acts, _ = env.learner_step(acts, first_legal_policy)
+        recs.append(rec_all.clone())
+    return recs, sent, (env.lo, env.hi)
 
 
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = shard_range(N_TOTAL, world, rank)
-    recs = _run_shard(lo, hi, STEPS)
-    gathered = [gather_records(r) for r in recs]
-    # equal-shard fast path as well: pad the local block to the max shard and use all_gather_into_tensor
+    recs, sent, (lo, hi) = _run_learner(N_TOTAL, STEPS)
+    # plain step + gather (no learner), ragged shards
+    env = _make_env(N_TOTAL)
+    env.reset()
+    plain = []
+    for it in range(3):
+        a = torch.tensor([1 + ((lo + i + it) % 2) for i in range(hi - lo)], dtype=torch.int32)
+        plain.append(env.step(a)[1].clone())
+    # equal-shard fast path (all_gather_into_tensor)
     eq_lo, eq_hi = shard_range(10, world, rank)
-    eq = torch.full((eq_hi - eq_lo, RECORD_WIDTH), float(rank), dtype=torch.float64)
+    eq = torch.full((eq_hi - eq_lo, RECORD_BYTES), rank, dtype=torch.uint8)
     eq_all = gather_records(eq)
-    if rank == 0:
-        q.put(([g.numpy() for g in gathered], eq_all.numpy()))
+    q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,21 +120,59 @@ def test_shard_range_partitions():
         shard_range(4, 2, 2)
 
 
-def test_two_rank_gather_equals_single_process():
+def test_record_pack_unpack_roundtrip():
+    n = 5
+    reward = torch.tensor([-0.0, -1.5, -500.0, -12345.5, 0.0], dtype=torch.float64)
+    delta = torch.arange(15, dtype=torch.int32).reshape(n, 3)
+    done = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8)
+    nleg = torch.tensor([3, 0, 7, 0, 0], dtype=torch.int32)
+    rec = pack_records(reward, delta, done, nleg, cum=delta * 2, env_steps=nleg + 1, path_len=nleg + 2,
+                       status=torch.tensor([0, 8, 2, 1, 4]))
+    assert rec.shape == (n, RECORD_BYTES) and rec.dtype == torch.uint8
+    u = unpack_records(rec)
+    assert torch.equal(u["reward"], reward) and torch.equal(u["delta"], delta) and torch.equal(u["cum"], delta * 2)
+    assert torch.equal(u["nlegal"], nleg) and torch.equal(u["done"], done) and u["status"].tolist() == [0, 8, 2, 1, 4]
+    # layout == the C struct (include/xroute_hip.h xr_step_record), checked through the numpy dtype the GPU path uses
+    from xroute_env_amd._lib import XrStepRecord
+    import ctypes
+    assert ctypes.sizeof(XrStepRecord) == RECORD_BYTES
+    r0 = XrStepRecord.from_buffer_copy(rec[3].numpy().tobytes())
+    assert r0.reward == -12345.5 and list(r0.delta) == [9, 10, 11] and r0.nlegal == 0 and r0.done == 1 and r0.status == 1
+
+
+def test_first_legal_policy():
+    legal = torch.tensor([[0b0110, 0], [0, 1 << 5], [0, 0]], dtype=torch.int64)
+    assert first_legal_policy({}, legal).tolist() == [2, 64 + 6, 0]
+
+
+def test_two_rank_learner_flow_equals_single_process():
+    """BASELINE config 4 loop (gather records + legal sets -> rank-0 policy -> broadcast i32[B] actions -> local step) on
+    two gloo ranks == the same loop in one process."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    gathered, eq_all = q.get(timeout=120)
+    got = {}
+    for _ in range(2):
+        item = q.get(timeout=180)
+        got[item[0]] = item[1:]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    single = _run_shard(0, N_TOTAL, STEPS)
-    assert len(gathered) == STEPS
-    for g, s in zip(gathered, single):
-        assert g.shape == (N_TOTAL, RECORD_WIDTH)
-        assert np.array_equal(g, s.numpy())
-    assert eq_all.shape == (10, RECORD_WIDTH)
-    assert (eq_all[:5] == 0).all() and (eq_all[5:] == 1).all()
+    single_recs, single_sent, _ = _run_learner(N_TOTAL, STEPS)
+    for rank in (0, 1):
+        recs, sent, (lo, hi), plain, eq_all = got[rank]
+        assert len(recs) == STEPS
+        for g, s in zip(recs, single_recs):                     # every rank holds every env's record
+            assert g.shape == (N_TOTAL, RECORD_BYTES) and np.array_equal(g, s.numpy())
+        for a, s in zip(sent, single_sent):                     # the broadcast actions are the rank's slice of the learner's
+            assert np.array_equal(a, s.numpy()[lo:hi])
+        assert eq_all.shape == (10, RECORD_BYTES) and (eq_all[:5] == 0).all() and (eq_all[5:] == 1).all()
+    # the plain gather of ragged shards is in env order on both ranks
+    for p0, p1 in zip(got[0][3], got[1][3]):
+        assert p0.shape == (N_TOTAL, RECORD_BYTES) and np.array_equal(p0, p1)
+    # something was actually routed (non-zero rewards) and episodes ended and restarted
+    u = unpack_records(torch.from_numpy(np.ascontiguousarray(np.stack(got[0][0]).reshape(-1, RECORD_BYTES))))
+    assert (u["reward"] < 0).any() and (u["done"] == 1).any()

@@ -57,18 +57,27 @@ def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
     return total
 
 
-def test_route_parity_ispd_sized():
+@pytest.mark.parametrize("router", [0, 1])          # 0: default (bucketed frontier), 1: line-segment sweeps
+def test_route_parity_ispd_sized(router):
     regions = [generate_region(3000 + i) for i in range(24)]
-    n = _run_episode_parity(regions, policy="random")
+    n = _run_episode_parity(regions, policy="random", router=router)
     assert n > 200
+
+
+@pytest.mark.parametrize("mult", [1, 3, 8, 64])
+def test_route_parity_frontier_bucket_widths(mult):
+    """The bucket width of the frontier router changes the visiting order only, never the result."""
+    regions = [generate_region(3100 + i) for i in range(12)]
+    assert _run_episode_parity(regions, policy="random", router=2, dial_mult=mult) > 100
 
 
 @pytest.mark.parametrize("dims", [(1, 1, 1), (1, 7, 1), (5, 1, 2), (2, 2, 2), (3, 4, 5), (6, 5, 3), (16, 9, 4),
                                   (7, 31, 9), (33, 8, 2), (12, 12, 12)])
-def test_route_parity_odd_dims(dims):
+@pytest.mark.parametrize("router", [0, 1])
+def test_route_parity_odd_dims(dims, router):
     n = dims[0] * dims[1] * dims[2]
     regions = [generate_region(4000 + 17 * i + n, dims=dims, k_range=(1, 6), net_span=4) for i in range(6)]
-    _run_episode_parity(regions, policy="min")
+    _run_episode_parity(regions, policy="min", router=router)
 
 
 @pytest.mark.parametrize("scratch", [False, True])

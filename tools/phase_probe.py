@@ -10,7 +10,9 @@ from xroute_env_amd.regions import config_regions
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 thr = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 regions = config_regions(3, min(B, 512))
-batch = RegionBatch(regions, n_envs=B, auto_reset=True, block_threads=thr)
+router = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mult = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+batch = RegionBatch(regions, n_envs=B, auto_reset=True, block_threads=thr, router=router, dial_mult=mult)
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
 n = 20
@@ -21,9 +23,10 @@ for i in range(n):
     sw += batch.fetch("sweeps").double().mean().item()
 torch.cuda.synchronize()
 ph = batch.fetch("phases").double().mean(0).cpu() / n
-names = ["build+setup", "relax:T", "relax:V+bound", "select+trace", "mark", "epilogue", "-", "-"]
-tot = ph[:6].sum().item()
-print(f"block_threads={thr or 'auto'}  mean sweeps/step {sw / n:.2f}  total {tot:.0f} cycles/WG-step")
+names = ["build+setup", "relax:T", "relax:V+bound", "select+trace", "mark", "epilogue", "-", "-"] if router == 1 else ["build+setup", "round: scan", "round: expand", "select+trace", "sources", "epilogue", "-", "-"]
+tot = ph[:7].sum().item()
+print(f"router={router} mult={mult} block_threads={thr or 'auto'}  mean sweeps/step {sw / n:.2f}  total {tot:.0f} cycles/WG-step")
 for k in range(6):
     print(f"  {names[k]:14s} {ph[k].item():10.0f} cycles  {100 * ph[k].item() / tot:5.1f}%")
+print(f"  round: reduce+barrier {ph[6].item():10.0f} cycles  {100 * ph[6].item() / tot:5.1f}%" if router != 1 else "")
 print(f"  lines visited/step {ph[6].item():.1f}  iterations/step {ph[7].item():.2f}  lines/iteration {ph[6].item() / max(ph[7].item(), 1e-9):.1f}")

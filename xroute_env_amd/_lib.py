@@ -19,7 +19,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 
 (XR_FETCH_CUM, XR_FETCH_DELTA, XR_FETCH_REWARD, XR_FETCH_DONE, XR_FETCH_NLEGAL, XR_FETCH_STATUS,
  XR_FETCH_LEGAL, XR_FETCH_PATH_LEN, XR_FETCH_PATH, XR_FETCH_OWNER, XR_FETCH_HASH, XR_FETCH_REGION,
- XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES) = range(15)
+ XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD) = range(16)
 
 # every symbol include/xroute_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -36,7 +36,18 @@ class XrConfig(C.Structure):
                 ("max_route_count", C.c_int32), ("auto_reset", C.c_int32), ("path_cap", C.c_int32),
                 ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("obs_mode", C.c_int32),
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
-                ("obs_writer_blocks", C.c_int32), ("obs_split_permille", C.c_int32)]
+                ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
+                ("obs_split_permille", C.c_int32)]
+
+
+class XrStepRecord(C.Structure):          # include/xroute_hip.h xr_step_record (48 bytes)
+    _fields_ = [("reward", C.c_double), ("delta", C.c_int32 * 3), ("cum", C.c_int32 * 3), ("nlegal", C.c_int32),
+                ("env_steps", C.c_int32), ("path_len", C.c_int32), ("done", C.c_uint8), ("pad", C.c_uint8),
+                ("status", C.c_uint16)]
+
+
+RECORD_BYTES = 48
+XR_ROUTER_SWEEP, XR_ROUTER_DIAL = 1, 2
 
 
 class XrRegionDesc(C.Structure):
@@ -93,7 +104,7 @@ def lib():
         fn = getattr(L, name)
         if name not in ("xr_last_error", "xr_config_default"):
             fn.restype = C.c_int32
-    if L.xr_abi_version() != 2:
+    if L.xr_abi_version() != 3:
         raise RuntimeError("libxroute_hip.so ABI version mismatch")
     _LIB = L
     return L

@@ -16,6 +16,11 @@ from . import _lib
 from .regions import Region
 
 
+RECORD_DTYPE = np.dtype([("reward", "<f8"), ("delta", "<i4", (3,)), ("cum", "<i4", (3,)), ("nlegal", "<i4"),
+                         ("env_steps", "<i4"), ("path_len", "<i4"), ("done", "u1"), ("pad", "u1"), ("status", "<u2")])
+assert RECORD_DTYPE.itemsize == _lib.RECORD_BYTES
+
+
 def _require_gpu(device) -> torch.device:
     dev = torch.device(device)
     if dev.type != "cuda" or not torch.cuda.is_available():
@@ -36,7 +41,7 @@ class RegionBatch:
                  auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
-                 obs_split_permille: int = 0):
+                 obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -53,6 +58,8 @@ class RegionBatch:
         cfg.obs_mode = int(obs_mode)                    # 0 default, 1 fused single launch, 2 split (route || net-plane writer)
         cfg.obs_writer_blocks = int(obs_writer_blocks)
         cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
+        cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
+        cfg.dial_mult = int(dial_mult)
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))
@@ -218,6 +225,7 @@ class RegionBatch:
         "steps": (_lib.XR_FETCH_STEPS, torch.int64, lambda s: (1,)),
         "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
         "phases": (_lib.XR_FETCH_PHASES, torch.int64, lambda s: (s.n_envs, 8)),
+        "record": (_lib.XR_FETCH_RECORD, torch.uint8, lambda s: (s.n_envs, _lib.RECORD_BYTES)),
     }
 
     def fetch(self, what: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -244,6 +252,11 @@ class RegionBatch:
                     m &= m - 1
             out.append(s)
         return out
+
+    def records(self) -> np.ndarray:
+        """The packed per-env result records (xr_step_record) as a host structured array: ONE device->host copy."""
+        raw = self.fetch("record").cpu().numpy()
+        return raw.view(RECORD_DTYPE).reshape(self.n_envs)
 
     def total_steps(self) -> int:
         return int(self.fetch("steps").item())

@@ -85,6 +85,7 @@ struct xr_batch {
     int lines_max = 0;
     int bits_max = 0;       // tracks + 2 x columns
     int zch = 0;            // 9 / 12 when all regions have that many layers
+    int kzch = 0;           // template selector of the step kernels: zch, or -1 = bucketed-frontier router (xr_dial.h)
     int k_max = 0;
     int legal_words = 1;
     int path_cap = 0;
@@ -106,6 +107,7 @@ struct xr_batch {
     DevBuf<int16_t> owner;
     DevBuf<uint64_t> legal, hash;
     DevBuf<double> reward;
+    DevBuf<XrStepRecord> records;
     DevBuf<uint8_t> done, cls_scratch;
     DevBuf<int64_t> env_steps;
     DevBuf<long long> phase_cycles;
@@ -151,6 +153,8 @@ void xr_config_default(xr_config* c) {
     c->obs_mode = 0;
     c->obs_writer_blocks = 0;
     c->obs_split_permille = 0;
+    c->router = 0;
+    c->dial_mult = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -177,6 +181,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
     if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_QUEUE || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
+    if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL || cfg->dial_mult < 0 || cfg->dial_mult > 64)
+        return fail(XR_ERR_INVALID, "xr_batch_create: router must be 0, XR_ROUTER_SWEEP or XR_ROUTER_DIAL; dial_mult in 0..64");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -237,6 +243,17 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         R.ldir_mask = 0;
         for (int z = 0; z < d.dim_z; z++)
             if (d.layer_dir_host[z]) R.ldir_mask |= (1u << z);
+        {   // bucketed-frontier router: smallest edge length, flat-index decode constants
+            uint32_t wmin = (uint32_t)b->cfg.via_cost;
+            for (int i = 1; i < d.dim_x; i++) wmin = std::min(wmin, (uint32_t)(d.xs_host[i] - d.xs_host[i - 1]));
+            for (int i = 1; i < d.dim_y; i++) wmin = std::min(wmin, (uint32_t)(d.ys_host[i] - d.ys_host[i - 1]));
+            R.w_min = std::max(1u, wmin);
+            const uint32_t yz = (uint32_t)d.dim_y * (uint32_t)d.dim_z, zz = (uint32_t)d.dim_z;
+            R.magic_yz = yz >= 2 ? (uint32_t)((1ULL << 32) / yz) : 0xFFFFFFFFu;
+            R.magic_z = zz >= 2 ? (uint32_t)((1ULL << 32) / zz) : 0xFFFFFFFFu;
+            const uint32_t mwv = (uint32_t)((n64 + 31) / 32);
+            R.magic_mw = mwv >= 2 ? (uint32_t)((1ULL << 32) / mwv) : 0xFFFFFFFFu;
+        }
         R.xs_off = (int32_t)hcoords.size();
         hcoords.insert(hcoords.end(), d.xs_host, d.xs_host + d.dim_x);
         R.ys_off = (int32_t)hcoords.size();
@@ -354,6 +371,21 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     // workgroup size of the step kernel unless the caller asks: 256 with the field in LDS (4 waves; 4 workgroups per CU
     // resident at 24x40x9), 1024 with the field in HBM scratch (latency-bound on memory: more items in flight per env)
     b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : (b->lds_dist ? 256 : 1024);
+    // default router: bucketed frontier expansion with field + three node bitmasks + edge tables in LDS (xr_dial.h);
+    // regions that do not fit keep the sweep router's HBM-scratch form
+    b->kzch = b->zch;
+    {
+        const size_t mw_max = (size_t)b->n_max / 32 + 1;
+        const size_t dial_lds = (size_t)b->n_max * 4 + 4 * mw_max * 4 + el_bytes + 16;
+        if (b->cfg.router != XR_ROUTER_SWEEP && !b->cfg.force_scratch_field && dial_lds + kLdsStatic <= kLdsLimit) {
+            b->kzch = -1;
+            b->lds_dist = true;
+            b->route_lds = dial_lds;
+            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 256;
+        } else if (b->cfg.router == XR_ROUTER_DIAL) {
+            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL needs %zu bytes of LDS for the largest region", dial_lds);
+        }
+    }
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
     const size_t ids_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4;
     // flat-stream observation (any N): ids + a 16-bit feature per node in LDS
@@ -394,6 +426,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->legal, (size_t)B * legal_words);
     XR_ALLOC(b->hash, B);
     XR_ALLOC(b->reward, B);
+    XR_ALLOC(b->records, B);
     XR_ALLOC(b->done, B);
     XR_ALLOC(b->env_steps, B);
     XR_ALLOC(b->total_steps, 1);
@@ -426,6 +459,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemsetAsync(b->total_steps.p, 0, sizeof(unsigned long long), st));
     XR_HIP(hipMemsetAsync(b->phase_cycles.p, 0, (size_t)B * 8 * sizeof(long long), st));
     XR_HIP(hipMemsetAsync(b->nlegal.p, 0, (size_t)B * sizeof(int32_t), st));
+    XR_HIP(hipMemsetAsync(b->records.p, 0, (size_t)B * sizeof(XrStepRecord), st));
     XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
     XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
     std::vector<uint64_t> hhash(B, 0xcbf29ce484222325ULL);
@@ -442,7 +476,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
-    d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p;
+    d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.records = b->records.p;
+    d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 4;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
     d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
@@ -499,7 +534,7 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
     if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_step: null argument");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
-    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
+    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads,
                            static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
@@ -532,18 +567,18 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
             XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
             int per_cu = 0;
             size_t stat = 0;
-            XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &per_cu, &stat));
+            XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, &per_cu, &stat));
             b->n_cus = prop.multiProcessorCount;
             b->queue_blocks = std::max(1, per_cu) * b->n_cus;
         }
         const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : b->queue_blocks;
-        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads,
+        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads,
                                     std::min(blocks, 4 * b->cfg.n_envs), st));
         return XR_OK;
     }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
     if (!split) {
-        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));
+        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
         return XR_OK;
     }
     // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
@@ -553,7 +588,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     XR_HIP(xr_launch_plan(&d, actions_dev, st));
     XR_HIP(hipEventRecord(b->ev_fork, st));
     XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
-    XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, st));
+    XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
     XR_HIP(hipEventRecord(b->ev_w0, b->aux_stream));
     XR_HIP(xr_launch_netplanes(&d, b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : 512, d.obs_vec4 == 1 ? 1 : 0,
                                b->aux_stream));
@@ -568,7 +603,7 @@ int32_t xr_batch_route_occupancy(xr_batch* b, int32_t* workgroups_per_cu, int64_
     XR_HIP(hipSetDevice(b->cfg.device));
     int n = 0;
     size_t stat = 0;
-    XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->zch, b->route_lds, b->route_threads, &n, &stat));
+    XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, &n, &stat));
     *workgroups_per_cu = n;
     *lds_bytes_per_workgroup = (int64_t)(b->route_lds + stat);
     return XR_OK;
@@ -592,7 +627,7 @@ int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t str
     if (stride < b->k_max)
         return fail(XR_ERR_RANGE, "xr_batch_route_order: stride %d < k_max %d", stride, b->k_max);
     XR_HIP(hipSetDevice(b->cfg.device));
-    XR_HIP(xr_launch_order(&b->dev, orders_dev, stride, net_stats_dev, b->lds_dist ? 1 : 0, b->zch, b->route_lds,
+    XR_HIP(xr_launch_order(&b->dev, orders_dev, stride, net_stats_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds,
                            b->route_threads, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
@@ -642,6 +677,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;
     case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;
     default: return fail(XR_ERR_INVALID, "xr_batch_fetch: unknown selector %d", what);
     }

@@ -22,7 +22,25 @@ struct XrRegionDev {
     int32_t ap_off;        // into ap_node[] / ap_pin[]
     int64_t node_off;      // into rg_rec / rg_node_net / rg_owner0
     int64_t legal0_off;    // into legal0[] (uint64 words, legal_words per region)
+    // bucketed-frontier router (xr_dial.h)
+    uint32_t w_min;        // smallest edge length of the region graph: min(x pitches, y pitches, via cost)
+    uint32_t magic_yz;     // floor(2^32 / (Y*Z)) and floor(2^32 / Z) (0xFFFFFFFF for a divisor of 1): flat index -> (x, y, z)
+    uint32_t magic_z;
+    uint32_t magic_mw;     // floor(2^32 / mw), mw = ceil(N / 32): node f <-> (word f % mw, bit f / mw) of the node bitmasks
 };
+
+// Packed per-env result of the last step / reset (XR_FETCH_RECORD; layout = xr_step_record of include/xroute_hip.h)
+struct XrStepRecord {
+    double reward;
+    int32_t delta[3];
+    int32_t cum[3];
+    int32_t nlegal;
+    int32_t env_steps;
+    int32_t path_len;
+    uint8_t done, pad;
+    uint16_t status;
+};
+static_assert(sizeof(XrStepRecord) == 48, "xr_step_record layout");
 
 // Everything a kernel needs, passed by value.
 // nets of an env with K nets left whose planes the step kernel writes itself in the split form
@@ -65,6 +83,7 @@ struct XrBatchDev {
     int64_t* env_steps;
     unsigned long long* total_steps;
     int32_t* sweeps;
+    XrStepRecord* records;   // [B]
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;
     unsigned short* list_scratch;   // [B][lines_max] worklists of the large-region variant
@@ -84,5 +103,6 @@ struct XrBatchDev {
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
+    int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
     double w_violation, w_via, w_wirelength;
 };

@@ -61,6 +61,19 @@ __global__ void xr_ingest_kernel(const uint32_t* __restrict__ rec, int16_t* __re
 // reset of one env by its workgroup (Game.reset bookkeeping, reference
 // baseline/baseline_utils.py:466-473; region rotation examples/launch_training.py:33-54)
 // ------------------------------------------------------------------------------------------------
+// packed result record of env e (thread 0, after it has written the per-field arrays)
+__device__ __forceinline__ void xr_publish_record(const XrBatchDev& b, int e) {
+    XrStepRecord* r = b.records + e;
+    r->reward = b.reward[e];
+    r->delta[0] = b.delta[3 * e]; r->delta[1] = b.delta[3 * e + 1]; r->delta[2] = b.delta[3 * e + 2];
+    r->cum[0] = b.cum[3 * e]; r->cum[1] = b.cum[3 * e + 1]; r->cum[2] = b.cum[3 * e + 2];
+    r->nlegal = b.nlegal[e];
+    r->env_steps = (int32_t)b.env_steps[e];
+    r->path_len = b.path_len[e];
+    r->done = b.done[e]; r->pad = 0;
+    r->status = (uint16_t)b.status[e];
+}
+
 __device__ void xr_env_reset(const XrBatchDev& b, int e, int rotate, int extra_status) {
     __shared__ int s_region;
     const int tid = threadIdx.x;
@@ -100,6 +113,7 @@ __device__ void xr_env_reset(const XrBatchDev& b, int e, int rotate, int extra_s
         b.status[e] = extra_status;
         b.path_len[e] = 0;
         b.sweeps[e] = 0;
+        xr_publish_record(b, e);
     }
 }
 
@@ -148,9 +162,12 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // with only the item bitmasks and edge tables in LDS (larger regions: stores only lowered nodes, loads chunks on demand).
 // ------------------------------------------------------------------------------------------------
 #ifdef XR_PHASE_TIMING
-#define XR_T0() long long _t = (threadIdx.x == 0) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define XR_LAP(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); _ph[k] += _n - _t; _t = _n; } } while (0)
-#define XR_TDUMP() do { if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) b.phase_cycles[(int64_t)e * 8 + _k] += _ph[_k]; } while (0)
+#ifndef XR_TIMING_TID
+#define XR_TIMING_TID 0           // the thread whose cycle counts are recorded
+#endif
+#define XR_T0() long long _t = (threadIdx.x == XR_TIMING_TID) ? clock64() : 0; long long _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define XR_LAP(k) do { if (threadIdx.x == XR_TIMING_TID) { const long long _n = clock64(); _ph[k] += _n - _t; _t = _n; } } while (0)
+#define XR_TDUMP() do { if (threadIdx.x == XR_TIMING_TID) for (int _k = 0; _k < 8; _k++) b.phase_cycles[(int64_t)e * 8 + _k] += _ph[_k]; } while (0)
 #else
 #define XR_T0() do {} while (0)
 #define XR_LAP(k) do {} while (0)
@@ -336,6 +353,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
             b.status[e] = XR_ENV_BAD_ACTION;
             b.delta[3 * e] = 0; b.delta[3 * e + 1] = 0; b.delta[3 * e + 2] = 0;
             b.reward[e] = -0.0; b.path_len[e] = 0; b.sweeps[e] = 0;
+            xr_publish_record(b, e);
         }
         return;
     }
@@ -348,6 +366,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
             b.status[e] = XR_ENV_BAD_ACTION;
             b.delta[3 * e] = 0; b.delta[3 * e + 1] = 0; b.delta[3 * e + 2] = 0;
             b.reward[e] = -0.0; b.path_len[e] = 0; b.sweeps[e] = 0;
+            xr_publish_record(b, e);
         }
         return;
     }
@@ -791,9 +810,25 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
         b.hash[e] = h;
         b.env_steps[e] += 1;
         atomicAdd(b.total_steps, 1ULL);
+        xr_publish_record(b, e);
     }
     XR_LAP(5);
     XR_TDUMP();
+}
+
+#include "xr_dial.h"
+
+// router selection of the step kernels: ZCH == XR_ZCH_DIAL -> the bucketed-frontier router (xr_dial.h, the default),
+// else the line-segment sweeps above (xr_config.router = XR_ROUTER_SWEEP)
+#define XR_ZCH_DIAL (-1)
+template <bool LDS_DIST, int ZCH>
+__device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int e, const int a, char* smem) {
+    if constexpr (ZCH == XR_ZCH_DIAL) {
+        static_assert(LDS_DIST, "the HBM-scratch form of the frontier router is xr_dial_route_env_big");
+        xr_dial_route_env(b, e, a, smem);
+    } else {
+        xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1091,7 +1126,7 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         b.phase_cycles[(int64_t)blockIdx.x * 8 + 3] = (long long)__smid();
     }
 #endif
-    xr_route_env<LDS_DIST, ZCH>(b, blockIdx.x, actions[blockIdx.x], smem);
+    xr_route_dispatch<LDS_DIST, ZCH>(b, blockIdx.x, actions[blockIdx.x], smem);
 #ifdef XR_TIMELINE
     if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 1] = (long long)wall_clock64();
 #endif
@@ -1415,7 +1450,7 @@ __global__ void xr_step_queue_kernel(XrBatchDev b, const int32_t* __restrict__ a
 #ifdef XR_TIMELINE
                 const long long t0 = XR_TL_NOW();
 #endif
-                xr_route_env<LDS_DIST, ZCH>(b, e, actions[e], smem);
+                xr_route_dispatch<LDS_DIST, ZCH>(b, e, actions[e], smem);
                 xr_obs_epilogue(b, e, smem, true);
                 __syncthreads();
 #ifdef XR_TIMELINE
@@ -1484,7 +1519,7 @@ __global__ void xr_order_kernel(XrBatchDev b, const int32_t* __restrict__ orders
         const int a = ord[k];
         if (a <= 0) break;                         // list terminator (uniform)
         if (b.nlegal[e] == 0) break;               // everything routed: the rest of the list is ignored
-        xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
+        xr_route_dispatch<LDS_DIST, ZCH>(b, e, a, smem);
         __syncthreads();
         if (tid == 0) {
             const int st = b.status[e];
@@ -1508,6 +1543,7 @@ __global__ void xr_order_kernel(XrBatchDev b, const int32_t* __restrict__ orders
         b.status[e] = st_acc;
         b.path_len[e] = plen_acc;
         b.sweeps[e] = sweeps_acc;
+        xr_publish_record(b, e);
     }
 }
 
@@ -1530,6 +1566,13 @@ hipError_t xr_launch_reset(const XrBatchDev* b, const uint8_t* mask, int rotate,
 }
 
 hipError_t xr_route_set_max_lds(size_t bytes) {
+    const void* dfns[3] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>),
+                           reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL>),
+                           reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL>)};
+    for (int i = 0; i < 3; i++) {
+        hipError_t e = hipFuncSetAttribute(dfns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
     const void* fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, 0>), reinterpret_cast<const void*>(&xr_route_kernel<true, 9>),
                           reinterpret_cast<const void*>(&xr_route_kernel<true, 12>), reinterpret_cast<const void*>(&xr_route_kernel<false, 0>),
                           reinterpret_cast<const void*>(&xr_route_kernel<false, 9>), reinterpret_cast<const void*>(&xr_route_kernel<false, 12>)};
@@ -1554,7 +1597,9 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
 hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
                            int threads, hipStream_t st) {
     const dim3 g(b->n_envs), t(threads);
-    if (lds_dist) {
+    if (zch == XR_ZCH_DIAL) {
+        hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+    } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_route_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
         else if (zch == 12) hipLaunchKernelGGL((xr_route_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_route_kernel<true, 0>), g, t, lds_bytes, st, *b, actions);
@@ -1569,7 +1614,9 @@ hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_
 hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int stride, int32_t* net_stats, int lds_dist, int zch,
                            size_t lds_bytes, int threads, hipStream_t st) {
     const dim3 g(b->n_envs), t(threads);
-    if (lds_dist) {
+    if (zch == XR_ZCH_DIAL) {
+        hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+    } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_order_kernel<true, 9>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else if (zch == 12) hipLaunchKernelGGL((xr_order_kernel<true, 12>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else hipLaunchKernelGGL((xr_order_kernel<true, 0>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
@@ -1583,7 +1630,8 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
 
 // resident workgroups per CU of the step kernel as the runtime would place it, and its static LDS
 hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threads, int* wg_per_cu, size_t* static_lds) {
-    const void* fn = lds_dist ? (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 9>)
+    const void* fn = zch == XR_ZCH_DIAL ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>)
+                     : lds_dist ? (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 9>)
                                  : zch == 12 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 12>)
                                              : reinterpret_cast<const void*>(&xr_route_kernel<true, 0>))
                               : (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<false, 9>)
@@ -1599,7 +1647,9 @@ hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threa
 hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
                                 int threads, int blocks, hipStream_t st) {
     const dim3 g(blocks), t(threads);
-    if (lds_dist) {
+    if (zch == XR_ZCH_DIAL) {
+        hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+    } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_step_queue_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
         else if (zch == 12) hipLaunchKernelGGL((xr_step_queue_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_step_queue_kernel<true, 0>), g, t, lds_bytes, st, *b, actions);

@@ -1,23 +1,32 @@
 """Multi-GPU sharding of the env batch: one process per GPU, envs statically partitioned, and ONE small
-RCCL collective per step — the batched-env gather of compact per-env results.
+RCCL collective per step — the batched-env gather of compact per-env results (plus, in the learner flow of BASELINE
+config 4, one broadcast of the actions going the other way).
 
 Regions are independent, so the data path has no exchange step inside a step.  Each rank
 owns a contiguous block of env ids for the whole run; after `step` the learner-facing record of every env
-(reward, metric deltas, done, nets left: 6 x f64 = 48 B/env, ~200 KB at 4096 envs) is all-gathered.
-fp32 observations are NOT gathered (2.5 MB/env): they stay on the GPU that owns the env.
+is all-gathered: the 48-byte `xr_step_record` the step kernels write themselves (reward f64, metric deltas and
+cumulative metrics i32[3] each, nets left, step counter, path length, done, status: include/xroute_hip.h) — 196 KB at 4096
+envs, latency-bound, no packing kernels.  fp32 observations are NOT gathered (2.5 MB/env): they stay on the GPU that
+owns the env.
+
+Learner flow (reference caller loop baseline/PPO/train_PPO.py:96-102: `action = agent.select_action(state)`;
+`state, done, ... = game.step(action)`): records (+ legal-net bitmasks) are gathered, the policy runs on rank 0 over ALL
+envs, the chosen actions travel back as one i32[n_total] broadcast and every rank steps its own slice.
 
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" with CPU tensors, which
 is how the world_size-2 tests exercise it without GPUs.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-RECORD_FIELDS = ("reward", "d_violation", "d_wirelength", "d_via", "done", "nlegal")
-RECORD_WIDTH = len(RECORD_FIELDS)
+RECORD_BYTES = 48
+# int32 column view of a record row ([B, 48] uint8 -> [B, 12] int32; reward = float64 view column 0)
+REC_DELTA, REC_CUM, REC_NLEGAL, REC_ENV_STEPS, REC_PATH_LEN, REC_FLAGS = slice(2, 5), slice(5, 8), 8, 9, 10, 11
+RECORD_FIELDS = ("reward", "delta", "cum", "nlegal", "env_steps", "path_len", "done", "status")
 
 
 def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -34,22 +43,40 @@ def env_seed(config: int, env_id: int) -> int:
     return 1000 * config + env_id
 
 
-def pack_records(reward: torch.Tensor, delta: torch.Tensor, done: torch.Tensor, nlegal: torch.Tensor,
-                 out: torch.Tensor = None) -> torch.Tensor:
-    """[B, 6] float64 record (all values are small integers or halves: exact in f64)."""
-    b = reward.shape[0]
+def unpack_records(rec: torch.Tensor) -> dict:
+    """Views (no copies) of a [n, 48] uint8 record tensor: reward f64[n], delta / cum i32[n,3], nlegal, env_steps,
+    path_len i32[n], done u8[n], status i32[n]."""
+    if rec.dtype != torch.uint8 or rec.dim() != 2 or rec.shape[1] != RECORD_BYTES or not rec.is_contiguous():
+        raise ValueError("records must be a contiguous [n, 48] uint8 tensor")
+    i32 = rec.view(torch.int32)
+    flags = i32[:, REC_FLAGS]
+    return {"reward": rec.view(torch.float64)[:, 0], "delta": i32[:, REC_DELTA], "cum": i32[:, REC_CUM],
+            "nlegal": i32[:, REC_NLEGAL], "env_steps": i32[:, REC_ENV_STEPS], "path_len": i32[:, REC_PATH_LEN],
+            "done": (flags & 0xFF).to(torch.uint8), "status": (flags >> 16) & 0xFFFF}
+
+
+def pack_records(reward, delta, done, nlegal, cum=None, env_steps=None, path_len=None, status=None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Host-side packer with the kernels' layout (tests and CPU stand-ins; the GPU path never packs: the step kernels
+    write the records)."""
+    n = reward.shape[0]
     if out is None:
-        out = torch.empty((b, RECORD_WIDTH), dtype=torch.float64, device=reward.device)
-    out[:, 0] = reward
-    out[:, 1:4] = delta.to(torch.float64)
-    out[:, 4] = done.to(torch.float64)
-    out[:, 5] = nlegal.to(torch.float64)
+        out = torch.zeros((n, RECORD_BYTES), dtype=torch.uint8, device=reward.device)
+    i32 = out.view(torch.int32)
+    out.view(torch.float64)[:, 0] = reward.to(torch.float64)
+    i32[:, REC_DELTA] = delta.to(torch.int32)
+    i32[:, REC_CUM] = 0 if cum is None else cum.to(torch.int32)
+    i32[:, REC_NLEGAL] = nlegal.to(torch.int32)
+    i32[:, REC_ENV_STEPS] = 0 if env_steps is None else env_steps.to(torch.int32)
+    i32[:, REC_PATH_LEN] = 0 if path_len is None else path_len.to(torch.int32)
+    st = torch.zeros(n, dtype=torch.int32, device=reward.device) if status is None else status.to(torch.int32)
+    i32[:, REC_FLAGS] = (done.to(torch.int32) & 0xFF) | (st << 16)
     return out
 
 
-def gather_records(local: torch.Tensor, out: torch.Tensor = None, group=None) -> torch.Tensor:
-    """All-gather the per-env records of every rank, in rank (= env id) order.  Equal shard sizes use
-    one all_gather_into_tensor; ragged shards fall back to all_gather on padded blocks."""
+def gather_rows(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+    """All-gather per-env rows of every rank, in rank (= env id) order.  Equal shard sizes use one
+    all_gather_into_tensor; ragged shards fall back to all_gather on padded blocks."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local if out is None else out.copy_(local)
     world = dist.get_world_size(group)
@@ -59,15 +86,18 @@ def gather_records(local: torch.Tensor, out: torch.Tensor = None, group=None) ->
     sizes = [int(s.item()) for s in sizes]
     if len(set(sizes)) == 1:
         if out is None:
-            out = torch.empty((world * sizes[0], local.shape[1]), dtype=local.dtype, device=local.device)
+            out = torch.empty((world * sizes[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
     m = max(sizes)
-    pad = torch.zeros((m, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     blocks = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(blocks, pad, group=group)
     return torch.cat([blk[:s] for blk, s in zip(blocks, sizes)], dim=0)
+
+
+gather_records = gather_rows
 
 
 def gather_records_fixed(local: torch.Tensor, out: torch.Tensor, group=None) -> torch.Tensor:
@@ -76,34 +106,79 @@ def gather_records_fixed(local: torch.Tensor, out: torch.Tensor, group=None) -> 
     return out
 
 
-class ShardedVectorEnv:
-    """The rank-local slice of a global batch of `n_total` envs of BASELINE config `config`."""
+def first_legal_policy(records: dict, legal: torch.Tensor) -> torch.Tensor:
+    """A deterministic stand-in learner policy: the lowest legal net of every env (0 when none).  legal: int64[n, words],
+    bit n-1 of the row <=> net n in netSet."""
+    n, words = legal.shape
+    bits = torch.arange(64, device=legal.device, dtype=torch.int64)
+    m = ((legal.unsqueeze(-1) >> bits) & 1).reshape(n, words * 64)            # [n, 64*words] 0/1
+    has = m.any(dim=1)
+    first = torch.argmax(m, dim=1).to(torch.int32) + 1
+    return torch.where(has, first, torch.zeros_like(first))
 
-    def __init__(self, config: int, n_total: int, device=None, with_observation: bool = True, **batch_kw):
-        from .envs.vector_env import XRouteVectorEnv
+
+class ShardedVectorEnv:
+    """The rank-local slice of a global batch of `n_total` envs of BASELINE config `config`.
+
+    `env_factory(regions, device, **kw)` builds the local vector env (default: XRouteVectorEnv on the MI355X); the tests
+    pass a CPU stand-in with the same surface, so the collective logic below is exactly what runs on RCCL."""
+
+    def __init__(self, config: int, n_total: int, device=None, with_observation: bool = True,
+                 env_factory: Optional[Callable] = None, group=None, **batch_kw):
         from .regions import CONFIGS, generate_region
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi = shard_range(n_total, self.world, self.rank)
         regions = [generate_region(env_seed(config, e), **CONFIGS[config]) for e in range(self.lo, self.hi)]
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.env = XRouteVectorEnv(regions, device=device, with_observation=with_observation, **batch_kw)
+        if env_factory is None:
+            from .envs.vector_env import XRouteVectorEnv
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            env_factory = XRouteVectorEnv
+        self.env = env_factory(regions, device=device, with_observation=with_observation, **batch_kw)
+        self.device = self.env.device
         self.n_local = self.hi - self.lo
         self.n_total = n_total
-        self._rec = torch.empty((self.n_local, RECORD_WIDTH), dtype=torch.float64, device=self.env.device)
-        equal = n_total % self.world == 0
-        self._all = torch.empty((n_total, RECORD_WIDTH), dtype=torch.float64, device=self.env.device) if equal else None
+        self.equal = n_total % self.world == 0
+        self._all = torch.empty((n_total, RECORD_BYTES), dtype=torch.uint8, device=self.device) if self.equal else None
+        self._actions_all = torch.zeros(n_total, dtype=torch.int32, device=self.device)
 
     def reset(self):
         return self.env.reset()
 
-    def step(self, actions: torch.Tensor):
-        """Local step + global gather.  Returns (obs_local, records_all [n_total, 6], info_local)."""
-        obs, reward, done, info = self.env.step(actions)
-        pack_records(reward, info["delta"], done, info["nlegal"], self._rec)
+    def _gather(self, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.world == 1:
-            return obs, self._rec, info
-        if self._all is not None:
-            return obs, gather_records_fixed(self._rec, self._all), info
-        return obs, gather_records(self._rec), info
+            return rows
+        if self.equal and out is not None:
+            return gather_records_fixed(rows, out, self.group)
+        return gather_rows(rows, group=self.group)
+
+    def step(self, actions: torch.Tensor):
+        """Local step + global gather.  Returns (obs_local, records_all uint8[n_total, 48], info_local)."""
+        obs, reward, done, info = self.env.step(actions)
+        return obs, self._gather(info["record"], self._all), info
+
+    # ---- learner flow (BASELINE config 4) ------------------------------------------------------------------------
+    def learner_reset(self, policy: Callable = first_legal_policy):
+        """reset + the first action exchange.  Returns (obs_local, actions_local)."""
+        obs, info = self.env.reset()
+        return obs, self._exchange(info, policy)
+
+    def learner_step(self, actions_local: torch.Tensor, policy: Callable = first_legal_policy):
+        """One step of the config 4 loop: step the local slice with the actions the learner sent, gather every env's
+        record and legal set, let rank 0 choose the next action of ALL envs, broadcast them (i32[n_total]) and return
+        (obs_local, records_all, next_actions_local, info_local)."""
+        obs, reward, done, info = self.env.step(actions_local)
+        nxt = self._exchange(info, policy)
+        return obs, self._records_all, nxt, info
+
+    def _exchange(self, info: dict, policy: Callable) -> torch.Tensor:
+        rec_all = self._gather(info["record"], self._all)
+        legal_all = self._gather(info["legal"])
+        self._records_all = rec_all
+        if self.rank == 0:
+            self._actions_all.copy_(policy(unpack_records(rec_all), legal_all).to(torch.int32))
+        if self.world > 1:
+            dist.broadcast(self._actions_all, src=0, group=self.group)      # actions travel the other way (SURVEY §8e)
+        return self._actions_all[self.lo:self.hi].contiguous()

@@ -12,6 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from ..batch import RegionBatch
+from ..dist import RECORD_BYTES, unpack_records
 
 
 class XRouteVectorEnv:
@@ -22,10 +23,12 @@ class XRouteVectorEnv:
         self.device = self.batch.device
         self.with_observation = with_observation
         self.obs = self.batch.alloc_observation() if with_observation else None
-        self.reward = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        # the 48-byte xr_step_record of every env, written by the step / reset kernels themselves: ONE copy per step;
+        # reward / done / delta / nlegal below are views into it
+        self.record = torch.empty((self.n_envs, RECORD_BYTES), dtype=torch.uint8, device=self.device)
+        rec = unpack_records(self.record)
+        self.reward, self.delta, self.nlegal, self.cum = rec["reward"], rec["delta"], rec["nlegal"], rec["cum"]
         self.done = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
-        self.delta = torch.empty((self.n_envs, 3), dtype=torch.int32, device=self.device)
-        self.nlegal = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
         self.legal = torch.empty((self.n_envs, self.batch.legal_words), dtype=torch.int64, device=self.device)
         self.region = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
 
@@ -33,14 +36,12 @@ class XRouteVectorEnv:
         b = self.batch
         if observe and self.with_observation:
             b.observation(self.obs)
-        b.fetch("reward", self.reward)
+        b.fetch("record", self.record)
         b.fetch("done", self.done)
-        b.fetch("delta", self.delta)
-        b.fetch("nlegal", self.nlegal)
         b.fetch("legal", self.legal)
         b.fetch("region", self.region)          # the region every slot is playing (key of agents.NetVectorCache)
         return self.obs, self.reward, self.done, {"delta": self.delta, "nlegal": self.nlegal, "legal": self.legal,
-                                                  "region": self.region}
+                                                  "region": self.region, "record": self.record, "cum": self.cum}
 
     def reset(self):
         self.batch.reset(rotate=True)
