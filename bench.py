@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--agent", choices=["dqn", "ppo"], default=None,
+                    help="agent-attached line (BASELINE configs 3 / 4) INSTEAD of the env-only headline: actions from the batched DQN / PPO "
+                         "counterpart (random-init weights of the reference architecture), env in compact-consumer mode")
+    ap.add_argument("--agent-full-obs", action="store_true", help="--agent: feed the full fp32 observation (xr_batch_step_observe) instead of the compact mode")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="run 1 GiB fill/add kernels first (known HBM byte counts for rocprofv3 --pmc passes)")
     return ap.parse_args()
@@ -257,6 +261,14 @@ def main():
 
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.dist import RECORD_BYTES, gather_records_fixed
+
+    if args.agent:
+        if rank == 0:
+            print(json.dumps(agent_leg(args, regions, dev, world)), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
                         obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
@@ -468,6 +480,95 @@ def bench_args_key(args, world):
     return {"gpus": world, "steps": args.steps, "warmup": args.warmup, "envs": args.envs, "global_envs": args.global_envs,
             "config": args.config, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
             "no_stagger": bool(args.no_stagger)}
+
+
+def agent_leg(args, regions, dev, world):
+    """BASELINE config 3 ("1024 regions, full maze-route per step, DQN baseline attached") / config 4's PPO: the env batch
+    stepped with actions from the batched policy counterpart.  Compact-consumer mode: per step the env writes planes 0..1
+    only (xr_batch_step_compact); the 7 static planes of a net go through the net tower once per (region, net)
+    (agents.NetVectorCache over xr_batch_net_planes) — the same logits as the reference's per-step re-encoding."""
+    import torch
+    from xroute_env_amd import agents
+    from xroute_env_amd.batch import RegionBatch
+    B = len(regions)
+    torch.manual_seed(0)
+    model = (agents.RepActor() if args.agent == "dqn" else agents.ActorCritic(64)).to(dev).eval()
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult)
+    batch.reset(rotate=True)
+    dims = regions[0].dims
+    full = args.agent_full_obs
+    buf = batch.alloc_observation() if full else batch.alloc_head()
+    if full:
+        batch.observation(buf)
+    else:
+        _head_of(batch, buf)
+    cache = agents.NetVectorCache(len(regions), batch.k_max, dev)
+    nl = torch.empty(B, dtype=torch.int32, device=dev)
+    reg = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def act():
+        batch.fetch("nlegal", nl)
+        batch.fetch("region", reg)
+        kw = dict(cache=cache, region=reg)
+        if not full:
+            kw["planes_fn"] = batch.net_planes
+        if args.agent == "dqn":
+            return agents.dqn_actions(model, buf, nl, dims, **kw)
+        return agents.ppo_actions(model, buf, nl, dims, **kw)[0]
+
+    def env_step(a):
+        if full:
+            batch.step(a, buf)
+        else:
+            batch.step_compact(a, buf)
+
+    for _ in range(max(args.warmup, 2)):            # MIOpen kernel selection + the net-vector cache fills
+        env_step(act())
+    n = max(args.steps, 1)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    torch.cuda.synchronize(dev)
+    s0 = batch.total_steps()
+    t0 = time.perf_counter()
+    for i in range(n):
+        ev[i][0].record()
+        a = act()
+        ev[i][1].record()
+        env_step(a)
+        ev[i][2].record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    real = batch.total_steps() - s0
+    agent_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / n
+    env_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / n
+    N = float(regions[0].n_nodes)
+    kfloat = float(batch.fetch("nlegal").double().mean().item())
+    env_bytes = B * (4.0 * N + (4.0 * N * (2 + 7 * kfloat) if full else 8.0 * N))
+    return {"metric": f"env-steps/sec, {args.agent.upper()} counterpart attached (batched regions), ispd18_test1-sized regions",
+            "value": round(real / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3/4 shape: {B} ispd18_test1-sized regions, full maze route per step, "
+                                   f"{args.agent.upper()} counterpart (random-init weights of the reference architecture, eval mode) choosing every action; "
+                                   + ("full fp32 observation (xr_batch_step_observe)" if full else
+                                      "compact-consumer mode (xr_batch_step_compact: planes 0..1 per step; net planes once per (region, net) via xr_batch_net_planes + NetVectorCache)"),
+                       "envs_per_gpu": B, "global_envs": B, "parallelism": "env-shard x1", "mean_nets_left": round(kfloat, 2)},
+            "env_share_of_step_time": round(env_ms / max(env_ms + agent_ms, 1e-9), 4),
+            "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(env_ms, 4),
+            "net_grids_through_the_tower": cache.computed,
+            "roofline": {"kernel": "xr_route_kernel (+ planes 0..1)" if not full else "xr_step_queue_kernel", "bound": "hbm",
+                         "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "avg_launch_ms": round(env_ms, 4), "algorithmic_bytes_per_launch": int(env_bytes)}}
+
+
+def _head_of(batch, head):
+    """planes 0..1 of the current state of every env into a head buffer (reset-time fill of the compact mode)."""
+    import torch
+    full = batch.alloc_observation()
+    batch.observation(full)
+    head.copy_(full[:, :head.shape[1]])
+    del full
+    return head
 
 
 def config5_leg(args, c5_regions, dev):

@@ -108,6 +108,10 @@ typedef struct xr_config {
                                  region fits, else XR_ROUTER_SWEEP), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
                                  worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
     int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 4) */
+    int32_t stream_per_region; /* 1: "one region per stream" (north_star's first partition): xr_batch_step / _step_observe (fused
+                                  form) / _step_compact launch ONE single-workgroup kernel per env slot, round-robin over a pool of
+                                  internal HIP streams, joined to the caller's stream by events.  For batches of <= 64 slots only
+                                  (XR_ERR_RANGE above); measured against the default one-launch form in DESIGN.md */
     int32_t obs_split_permille; /* XR_OBS_SPLIT: per mille of every env's net planes (its highest-ranked nets) that the
                                    writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all).
                                    XR_OBS_QUEUE: units a workgroup writes after each route task, per mille of the average
@@ -126,7 +130,7 @@ typedef struct xr_region_desc {
                                        (Request.reward_*, net_ordering.proto:36-38) */
 } xr_region_desc;
 
-/* what xr_batch_fetch copies (device -> caller's DEVICE buffer, async on `stream`) */
+/* what xr_batch_fetch copies (device -> caller's buffer: a DEVICE buffer or PINNED host memory; async on `stream`) */
 #define XR_FETCH_CUM       0   /* int32 [B][3]  cumulative (violation, wirelength, via)  = data[2] */
 #define XR_FETCH_DELTA     1   /* int32 [B][3]  last step's deltas  (Game.step :426-433) */
 #define XR_FETCH_REWARD    2   /* double[B]     -(wv*dvio + wvia*dvia + wwl*dwl)  (train_DQN.py:98-99) */
@@ -212,6 +216,21 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
  *                 fine-grained pure-write drain instead of a tail of whole envs.  Same requirements as XR_OBS_SPLIT. */
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
+
+/* Compact-consumer mode.  The reference consumer re-encodes every net's 7 planes at every step (baseline/DQN/DQN.py:138-155),
+ * but those planes are functions of the region's static access points only (baseline/build_3Dgrid.py:106-142): a consumer
+ * that caches per-(region, net) results (xroute_env_amd.agents.NetVectorCache) needs, per step, only the two planes that
+ * change — plane 0 (obstacles) and plane 1 (net order).
+ *   xr_batch_step_compact  = xr_batch_step + planes 0..1 of every env at head_out_dev + e*head_stride (floats; 16-byte
+ *                            aligned buffer, head_stride % 4 == 0, head_stride >= 2*n_max): 8·N bytes per env-step instead
+ *                            of 4·N·(2+7K).
+ *   xr_batch_net_planes    = the 7 planes [7, Z, Y, X] of n_pairs (region index, 1-based net id) pairs, pair i at
+ *                            out_dev + i*pair_stride (floats, pair_stride >= 7*n_max) — byte-identical to planes 2+7i..8+7i
+ *                            of xr_batch_observation for an env playing that region with that net at rank i. */
+int32_t xr_batch_step_compact(xr_batch* b, const int32_t* actions_dev, float* head_out_dev, int64_t head_stride,
+                              void* stream);
+int32_t xr_batch_net_planes(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs,
+                            float* out_dev, int64_t pair_stride, void* stream);
 
 /* Whole-order re-route, the step of the reference's two other env contracts: the A3C env answers the simulator with
  * a complete net list (baseline/A3C/utils.py:305-307, Response.net_list of net_ordering.proto v2 field 2) and the

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--envs", "256", "--cpu-seconds", "1"] + extra, capture_output=True, text=True, timeout=600)
+                          "--envs", "256", "--cpu-seconds", "2", "--c5-envs", "8", "--c5-regions", "2"] + extra, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -31,8 +31,17 @@ def test_bench_json_contract(extra):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0          # never a pasted constant: null unless a PMC pass of this build + command exists
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
+    names = [k["kernel"] for k in d["kernels"]]
+    assert not any("error" in k for k in d["kernels"]), d["kernels"]
+    if not extra:
+        # per-kernel lines: the step kernel, the route-only kernel and the BASELINE config 5 route, each with its own numbers
+        assert names[0] == "xr_step_queue_kernel" and "xr_route_kernel" in names and any("config 5" in n for n in names)
+        for k in d["kernels"]:
+            assert k["ms"] > 0 and k["bytes"] > 0 and abs(k["frac"] - k["achieved"] / 8000.0) < 1e-3 and k["env_steps_per_s"] > 0
     p = d["parity"]                                  # the checker leg: oracle replay of the run's own actions
     assert p["hash_chains_equal"] is True and p["cumulative_metrics_equal"] is True and p["env_steps"] > 0 and p["envs"] == 256
     # value is consistent with the reported step time: real env-steps <= slots
@@ -74,3 +83,19 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_envs"] == 256 and "cpu_baseline" not in d and "RCCL all_gather" in d["config"]["workload"]
+    # strong scaling (BASELINE config 4 shape): the same global batch split over the ranks
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--global-envs", "256"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["global_envs"] == 256 and d["config"]["envs_per_gpu"] == 128
+
+
+def test_bench_value_is_stationary_in_warmup():
+    """The episodes are staggered before timing: mean nets left (and so the bytes per step) does not drift with --warmup."""
+    a = _run(["--no-legs", "--no-cpu-baseline", "--envs", "1024", "--steps", "10"])
+    b = _run(["--no-legs", "--no-cpu-baseline", "--envs", "1024", "--steps", "10", "--warmup", "25"])
+    ka, kb = a["config"]["mean_nets_left"], b["config"]["mean_nets_left"]
+    assert abs(ka - kb) / kb < 0.04, (ka, kb)

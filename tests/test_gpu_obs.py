@@ -194,3 +194,76 @@ def test_queue_form_tiny_batches_and_finished_envs(n_envs):
             assert torch.equal(a.fetch("status"), b.fetch("status")) and torch.equal(a.fetch("hash"), b.fetch("hash"))
         if not auto:
             assert int(a.fetch("nlegal").sum()) == 0 and bool((a.fetch("status") & 1).all())     # all finished: no-ops
+
+
+@pytest.mark.parametrize("dims", [(24, 40, 9), (7, 9, 5)])          # aligned planes (N % 4 == 0) and unaligned
+def test_compact_consumer_mode_composes_the_reference_tensor(dims):
+    """xr_batch_step_compact (planes 0..1 per step) + xr_batch_net_planes (the 7 static planes of a (region, net), on demand)
+    == xr_batch_observation, byte for byte, through episodes with auto-reset and region rotation; and against the oracle."""
+    import torch
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import generate_region
+    regions = [generate_region(8800 + i, dims=dims, k_range=(2, 7), net_span=6) for i in range(6)]
+    B = 10                                                   # more slots than regions: rotation changes a slot's region
+    batch = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
+    batch.reset(rotate=True)
+    head = batch.alloc_head()
+    full = batch.alloc_observation()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    for it in range(14):
+        batch.random_actions(31 + it, acts)
+        batch.step_compact(acts, head)
+        batch.observation(full)
+        nleg = batch.fetch("nlegal").cpu().numpy()
+        reg = batch.fetch("region").cpu().numpy()
+        legal = batch.legal_sets()
+        for e in range(B):
+            N = regions[reg[e]].n_nodes
+            assert torch.equal(head[e, :2 * N], full[e, :2 * N]), (it, e)
+            ids = sorted(legal[e])
+            assert len(ids) == nleg[e]
+            if ids:
+                pl = batch.net_planes(torch.full((len(ids),), int(reg[e]), dtype=torch.int32), torch.tensor(ids, dtype=torch.int32))
+                comp = torch.cat([pl[i, :7 * N] for i in range(len(ids))])
+                assert torch.equal(comp, full[e, 2 * N:(2 + 7 * len(ids)) * N]), (it, e)
+    # the static planes against the oracle's build_3Dgrid restatement, every net of every region
+    for r, rg in enumerate(regions):
+        env = orc.OracleEnv(rg)
+        ref = env.observation()                                # [2+7K, Z, Y, X], all nets legal after reset
+        ids = env.legal()
+        pl = batch.net_planes(torch.full((len(ids),), r, dtype=torch.int32), torch.tensor(ids, dtype=torch.int32)).cpu().numpy()
+        for i in range(len(ids)):
+            assert np.array_equal(pl[i, :7 * rg.n_nodes], ref[2 + 7 * i:9 + 7 * i].ravel()), (r, i)
+    # argument errors
+    from xroute_env_amd._lib import XRouteError
+    with pytest.raises(XRouteError):
+        batch.step_compact(acts, torch.empty((B, 8), dtype=torch.float32, device="cuda:0"))
+
+
+def test_compact_mode_logits_equal_full_observation_logits():
+    """The agent counterpart fed by the compact mode (head planes + cached per-(region, net) vectors from xr_batch_net_planes)
+    chooses from the same logits as when fed the full reference-layout observation."""
+    import torch
+    from xroute_env_amd import agents
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import generate_region
+    regions = [generate_region(8900 + i, dims=(24, 40, 9), k_range=(3, 8)) for i in range(8)]
+    torch.manual_seed(1)
+    model = agents.RepActor().to("cuda:0").eval()
+    batch = RegionBatch(regions, device="cuda:0", auto_reset=True)
+    batch.reset()
+    full = batch.alloc_observation()
+    head = batch.alloc_head()
+    cache = agents.NetVectorCache(len(regions), batch.k_max, "cuda:0")
+    acts = torch.empty(len(regions), dtype=torch.int32, device="cuda:0")
+    for it in range(4):
+        batch.random_actions(5 + it, acts)
+        batch.step_compact(acts, head)
+        batch.observation(full)
+        nl, reg = batch.fetch("nlegal"), batch.fetch("region")
+        lg_full, e1, id1, _ = agents.batched_logits(model, full, nl, regions[0].dims)
+        lg_cmp, e2, id2, _ = agents.batched_logits(model, head, nl, regions[0].dims, cache=cache, region=reg,
+                                                   planes_fn=batch.net_planes)
+        assert torch.equal(e1, e2) and torch.equal(id1, id2)
+        assert torch.allclose(lg_full, lg_cmp, atol=2e-3, rtol=0)

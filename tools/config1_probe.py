@@ -1,22 +1,35 @@
-"""BASELINE config 1 (single region, batch = 1) through the reference-shaped API: Game.reset / Game.step with the
-observation returned as a CPU tensor (PCIe-inclusive), and with the observation left on the device."""
+"""BASELINE config 1 (single region, batch 1) through the reference-shaped Game API, in-process simulator:
+per-step latency of the small-batch path — default (one launch), stream-per-region mode, device / host observation,
+both routers."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from xroute_env_amd import Game
+from xroute_env_amd.game import Game
 from xroute_env_amd.regions import config_regions
+
 regions = config_regions(1, 8)
-for ret_dev in (False, True):
-    game = Game(regions=regions, return_device=ret_dev)
-    game.reset()
-    n = 0; t_step = 0.0; t_reset = 0.0
-    for ep in range(10):
-        t0 = time.perf_counter(); obs, _ = game.reset(); torch.cuda.synchronize(); t_reset += time.perf_counter() - t0
+
+
+def run(label, **kw):
+    g = Game(regions=regions, **kw)
+    g.reset()
+    ts, tr = [], []
+    for ep in range(6):
+        t0 = time.perf_counter(); g.reset(); torch.cuda.synchronize(); tr.append(time.perf_counter() - t0)
         done = False
         while not done:
-            a = min(game.legal_action_set)
+            a = min(g.legal_action_set)
             t0 = time.perf_counter()
-            obs, done, dv, dw, dvia = game.step(a)
-            torch.cuda.synchronize()
-            t_step += time.perf_counter() - t0; n += 1
-    print(f"Game(return_device={ret_dev}): step {t_step / n * 1e3:.3f} ms ({n / t_step:.0f} env-steps/s), reset {t_reset / 10 * 1e3:.3f} ms, obs {tuple(obs.shape)} on {obs.device}")
+            obs, done, *_ = g.step(a)
+            ts.append(time.perf_counter() - t0)
+    ts.sort(); tr.sort()
+    print(f"{label:46s} step median {ts[len(ts)//2]*1e3:.3f} ms  p10 {ts[len(ts)//10]*1e3:.3f}  p90 {ts[9*len(ts)//10]*1e3:.3f}   "
+          f"reset median {tr[len(tr)//2]*1e3:.3f} ms   ({len(ts)} steps, obs on {obs.device})")
+
+
+run("default (host observation, like the reference)")
+run("return_device=True", return_device=True)
+run("stream_per_region, host observation", stream_per_region=True)
+run("stream_per_region, return_device=True", stream_per_region=True, return_device=True)
+run("router=sweep, return_device=True", return_device=True, router=1)
+run("obs_mode=fused, return_device=True", return_device=True, obs_mode=1)

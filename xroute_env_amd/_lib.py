@@ -25,7 +25,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 SYMBOLS = [
     "xr_abi_version", "xr_last_error", "xr_config_default", "xr_device_count",
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
-    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
+    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_step_compact", "xr_batch_net_planes", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 
@@ -37,7 +37,7 @@ class XrConfig(C.Structure):
                 ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("obs_mode", C.c_int32),
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
                 ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
-                ("obs_split_permille", C.c_int32)]
+                ("stream_per_region", C.c_int32), ("obs_split_permille", C.c_int32)]
 
 
 class XrStepRecord(C.Structure):          # include/xroute_hip.h xr_step_record (48 bytes)
@@ -92,6 +92,8 @@ def lib():
     L.xr_batch_reset.argtypes = [vp, vp, C.c_int32, vp]
     L.xr_batch_step.argtypes = [vp, vp, vp]
     L.xr_batch_step_observe.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.xr_batch_step_compact.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.xr_batch_net_planes.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
     L.xr_batch_random_actions.argtypes = [vp, vp, C.c_uint64, vp]
     L.xr_batch_observation.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.xr_batch_fetch.argtypes = [vp, C.c_int32, vp, C.c_size_t, vp]

@@ -41,7 +41,8 @@ class RegionBatch:
                  auto_reset: bool = False, via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400,
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
-                 obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0):
+                 obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0,
+                 stream_per_region: bool = False):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -60,6 +61,7 @@ class RegionBatch:
         cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
         cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
         cfg.dial_mult = int(dial_mult)
+        cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))
@@ -139,6 +141,40 @@ class RegionBatch:
                                                         C.c_void_p(obs_out.data_ptr()), obs_out.shape[1],
                                                         _stream_ptr(self.device)))
         return obs_out
+
+    def alloc_head(self) -> torch.Tensor:
+        """[n_envs, 2*n_max] fp32 buffer for the compact-consumer step (planes 0..1 of every env)."""
+        return torch.empty((self.n_envs, 2 * self.n_max), dtype=torch.float32, device=self.device)
+
+    def step_compact(self, actions: torch.Tensor, head_out: torch.Tensor):
+        """Game.step for every env + only the two observation planes that change (obstacles, net order):
+        xr_batch_step_compact.  The net planes come once per (region, net) from `net_planes`."""
+        if actions.device != self.device or actions.dtype != torch.int32 or not actions.is_contiguous() \
+                or actions.numel() != self.n_envs:
+            raise ValueError("actions must be a contiguous int32 tensor of n_envs entries on the batch device")
+        if head_out.device != self.device or head_out.dtype != torch.float32 or not head_out.is_contiguous() \
+                or head_out.dim() != 2 or head_out.shape[0] < self.n_envs:
+            raise ValueError("head_out must be a contiguous fp32 [n_envs, stride] tensor on the batch device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_step_compact(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(head_out.data_ptr()),
+                                                    head_out.shape[1], _stream_ptr(self.device)))
+        return head_out
+
+    def net_planes(self, region: torch.Tensor, net: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 7 static planes of (region index, 1-based net id) pairs: [n, 7*n_max] fp32 (xr_batch_net_planes)."""
+        region = region.to(device=self.device, dtype=torch.int32).contiguous()
+        net = net.to(device=self.device, dtype=torch.int32).contiguous()
+        n = region.numel()
+        if net.numel() != n:
+            raise ValueError("region and net must have the same length")
+        if out is None:
+            out = torch.empty((n, 7 * self.n_max), dtype=torch.float32, device=self.device)
+        if out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 2 or out.shape[0] < n:
+            raise ValueError("out must be a contiguous fp32 [n, stride] tensor on the batch device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_net_planes(self._h, C.c_void_p(region.data_ptr()), C.c_void_p(net.data_ptr()), n,
+                                                  C.c_void_p(out.data_ptr()), out.shape[1], _stream_ptr(self.device)))
+        return out
 
     def route_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the step kernel for the loaded regions."""
@@ -233,6 +269,17 @@ class RegionBatch:
         sel, dtype, shape = self._FETCH[what]
         if out is None:
             out = torch.empty(shape(self), dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_fetch(self._h, sel, C.c_void_p(out.data_ptr()),
+                                             out.numel() * out.element_size(), _stream_ptr(self.device)))
+        return out
+
+    def fetch_host(self, what: str, out: torch.Tensor) -> torch.Tensor:
+        """Copy one result array straight into a PINNED host tensor (async on the current stream; synchronise the stream
+        before reading it).  One transfer instead of device copy + .cpu(): the small-batch path."""
+        sel, dtype, shape = self._FETCH[what]
+        if out.device.type != "cpu" or not out.is_pinned() or out.dtype != dtype or not out.is_contiguous():
+            raise ValueError("out must be a contiguous pinned host tensor of the array's dtype")
         with torch.cuda.device(self.device):
             _lib.check(self.L.xr_batch_fetch(self._h, sel, C.c_void_p(out.data_ptr()),
                                              out.numel() * out.element_size(), _stream_ptr(self.device)))

@@ -28,6 +28,7 @@ hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
 hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
+hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const int32_t*, int, float*, int64_t, int, hipStream_t);
 }
 
 namespace {
@@ -119,6 +120,8 @@ struct xr_batch {
     DevBuf<uint32_t> plan_units, queue;
     int n_cus = 0, queue_blocks = 0;
     hipStream_t aux_stream = nullptr;
+    std::vector<hipStream_t> region_streams;        // stream-per-region mode
+    std::vector<hipEvent_t> region_events;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
     int last_obs_mode = 0;
     XrBatchDev dev{};
@@ -128,6 +131,8 @@ struct xr_batch {
         if (ev_w0) (void)hipEventDestroy(ev_w0);
         if (ev_w1) (void)hipEventDestroy(ev_w1);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
+        for (hipEvent_t ev : region_events) (void)hipEventDestroy(ev);
+        for (hipStream_t s : region_streams) (void)hipStreamDestroy(s);
     }
 };
 
@@ -155,6 +160,7 @@ void xr_config_default(xr_config* c) {
     c->obs_split_permille = 0;
     c->router = 0;
     c->dial_mult = 0;
+    c->stream_per_region = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -183,6 +189,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL || cfg->dial_mult < 0 || cfg->dial_mult > 64)
         return fail(XR_ERR_INVALID, "xr_batch_create: router must be 0, XR_ROUTER_SWEEP or XR_ROUTER_DIAL; dial_mult in 0..64");
+    if (cfg->stream_per_region < 0 || cfg->stream_per_region > 1 || (cfg->stream_per_region && cfg->n_envs > 64))
+        return fail(XR_ERR_RANGE, "xr_batch_create: stream_per_region is 0 or 1 and needs n_envs <= 64");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -480,6 +488,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 4;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
+    d.env_base = 0; d.env_count = 0;
     d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
     if (!b->aux_stream) {
         XR_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
@@ -530,13 +539,45 @@ int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, voi
     return XR_OK;
 }
 
+namespace {
+// One launch over all env slots, or — stream_per_region — one single-workgroup launch per slot on a pool of internal streams
+// (fork from / join to the caller's stream with events; the host never waits).
+int32_t launch_route_form(xr_batch* b, const XrBatchDev& d, const int32_t* actions_dev, hipStream_t st) {
+    if (!b->cfg.stream_per_region) {
+        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
+        return XR_OK;
+    }
+    const int B = b->cfg.n_envs;
+    if (b->region_streams.empty()) {
+        const int ns = std::min(B, 16);
+        for (int i = 0; i < ns; i++) {
+            hipStream_t s; hipEvent_t ev;
+            XR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            XR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            b->region_streams.push_back(s); b->region_events.push_back(ev);
+        }
+    }
+    const int ns = (int)b->region_streams.size();
+    XR_HIP(hipEventRecord(b->ev_fork, st));
+    for (int i = 0; i < ns; i++) XR_HIP(hipStreamWaitEvent(b->region_streams[i], b->ev_fork, 0));
+    for (int e = 0; e < B; e++) {
+        XrBatchDev de = d;
+        de.env_base = e; de.env_count = 1;
+        XR_HIP(xr_launch_route(&de, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, b->region_streams[e % ns]));
+    }
+    for (int i = 0; i < ns; i++) {
+        XR_HIP(hipEventRecord(b->region_events[i], b->region_streams[i]));
+        XR_HIP(hipStreamWaitEvent(st, b->region_events[i], 0));
+    }
+    return XR_OK;
+}
+}  // namespace
+
 int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
     if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_step: null argument");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
-    XR_HIP(xr_launch_route(&b->dev, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads,
-                           static_cast<hipStream_t>(stream)));
-    return XR_OK;
+    return launch_route_form(b, b->dev, actions_dev, static_cast<hipStream_t>(stream));
 }
 
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream) {
@@ -554,8 +595,8 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool can_split = (d.obs_vec4 == 1 || (d.obs_vec4 == 2 && b->n_max <= 60 * 1024)) && b->cfg.n_envs <= (1 << 18) && b->k_max < (1 << 14) && b->k_max >= 1;
-    const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT;
-    if (can_split && (b->cfg.obs_mode == XR_OBS_QUEUE || b->cfg.obs_mode == 0)) {      // the default: measured fastest
+    const bool split = can_split && b->cfg.obs_mode == XR_OBS_SPLIT && !b->cfg.stream_per_region;
+    if (can_split && (b->cfg.obs_mode == XR_OBS_QUEUE || b->cfg.obs_mode == 0) && !b->cfg.stream_per_region) {      // the default: measured fastest
         // plan, then one persistent launch: as many workgroups as the chip holds (occupancy x CUs) drain the two queues
         b->last_obs_mode = XR_OBS_QUEUE;
         d.obs_head_only = 1;
@@ -577,10 +618,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
         return XR_OK;
     }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
-    if (!split) {
-        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
-        return XR_OK;
-    }
+    if (!split) return launch_route_form(b, d, actions_dev, st);
     // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
     // caller's stream -> join.  Everything is ordered by events; the host never waits.
     d.obs_head_only = 1;
@@ -594,6 +632,40 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
                                b->aux_stream));
     XR_HIP(hipEventRecord(b->ev_w1, b->aux_stream));
     XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
+    return XR_OK;
+}
+
+int32_t xr_batch_step_compact(xr_batch* b, const int32_t* actions_dev, float* head_out_dev, int64_t head_stride, void* stream) {
+    if (!b || !actions_dev || !head_out_dev) return fail(XR_ERR_INVALID, "xr_batch_step_compact: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step_compact: load regions first");
+    if (head_stride < (int64_t)2 * b->n_max_nodes)
+        return fail(XR_ERR_RANGE, "xr_batch_step_compact: head_stride %lld < 2*n_max = %lld", (long long)head_stride,
+                    (long long)2 * b->n_max_nodes);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XrBatchDev d = b->dev;
+    d.obs_out = head_out_dev;
+    d.obs_stride = head_stride;
+    const bool aligned = (head_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(head_out_dev) & 15) == 0);
+    d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
+    if (d.obs_vec4 == 0)        // (the scalar epilogue has no head-only form)
+        return fail(XR_ERR_INVALID, "xr_batch_step_compact: head_out_dev must be 16-byte aligned and head_stride a multiple of 4");
+    d.obs_head_only = 1;          // the epilogue writes planes 0..1 and the net planes of the lowest XR_SPLIT_KEEP ranks: none
+    d.obs_split_pm = 1000;
+    b->last_obs_mode = XR_OBS_FUSED;
+    return launch_route_form(b, d, actions_dev, static_cast<hipStream_t>(stream));
+}
+
+int32_t xr_batch_net_planes(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs,
+                            float* out_dev, int64_t pair_stride, void* stream) {
+    if (!b || !out_dev || (n_pairs > 0 && (!pair_region_dev || !pair_net_dev))) return fail(XR_ERR_INVALID, "xr_batch_net_planes: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_net_planes: load regions first");
+    if (n_pairs < 0 || pair_stride < (int64_t)7 * b->n_max_nodes)
+        return fail(XR_ERR_RANGE, "xr_batch_net_planes: pair_stride %lld < 7*n_max = %lld", (long long)pair_stride,
+                    (long long)7 * b->n_max_nodes);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    const bool aligned = (pair_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    XR_HIP(xr_launch_netplanes_pairs(&b->dev, pair_region_dev, pair_net_dev, n_pairs, out_dev, pair_stride, aligned ? 1 : 0,
+                                     static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 
@@ -684,7 +756,9 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     if (dst_bytes < bytes)
         return fail(XR_ERR_RANGE, "xr_batch_fetch(%d): destination holds %zu bytes, need %zu", what, dst_bytes, bytes);
     XR_HIP(hipSetDevice(b->cfg.device));
-    XR_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    // (hipMemcpyDefault: the destination may be a device buffer or PINNED host memory — one copy straight to the host for
+    // the small-batch path)
+    XR_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 

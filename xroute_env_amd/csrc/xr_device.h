@@ -103,6 +103,7 @@ struct XrBatchDev {
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
+    int32_t env_base, env_count;   // route kernel: envs [env_base, env_base + env_count) (env_count 0 = all); stream-per-region mode
     int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
     double w_violation, w_via, w_wirelength;
 };

@@ -1126,11 +1126,12 @@ __global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ action
         b.phase_cycles[(int64_t)blockIdx.x * 8 + 3] = (long long)__smid();
     }
 #endif
-    xr_route_dispatch<LDS_DIST, ZCH>(b, blockIdx.x, actions[blockIdx.x], smem);
+    const int e_ = (int)blockIdx.x + b.env_base;             // (env_base > 0: one launch per region, stream-per-region mode)
+    xr_route_dispatch<LDS_DIST, ZCH>(b, e_, actions[e_], smem);
 #ifdef XR_TIMELINE
     if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 1] = (long long)wall_clock64();
 #endif
-    if (b.obs_out) xr_obs_epilogue(b, blockIdx.x, smem, b.obs_head_only != 0);
+    if (b.obs_out) xr_obs_epilogue(b, (int)blockIdx.x + b.env_base, smem, b.obs_head_only != 0);
 #ifdef XR_TIMELINE
     __syncthreads();
     if (threadIdx.x == 0) b.phase_cycles[(int64_t)blockIdx.x * 8 + 2] = (long long)wall_clock64();
@@ -1548,6 +1549,52 @@ __global__ void xr_order_kernel(XrBatchDev b, const int32_t* __restrict__ orders
 }
 
 // ------------------------------------------------------------------------------------------------
+// compact-consumer mode: the 7 planes of a (region, net) pair on demand.  They are functions of the region's static node
+// array only (build_3Dgrid.py:106-142: access-point mask + the aliased "has a same-net axis neighbour" plane), so a consumer
+// that caches per-(region, net) results (agents.NetVectorCache; the reference consumer baseline/DQN/DQN.py:138-155 re-encodes
+// every net at every step) needs them ONCE per episode set, while the step writes planes 0..1 only (xr_batch_step_compact).
+// One workgroup per pair; float4 stores when the planes are 16-byte aligned.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xr_netplanes_pairs_kernel(XrBatchDev b, const int32_t* __restrict__ pair_region,
+                                                               const int32_t* __restrict__ pair_net, float* __restrict__ out,
+                                                               int64_t pair_stride, int vec4) {
+    const int p = blockIdx.x;
+    const int r = pair_region[p], id = pair_net[p];
+    float* __restrict__ o = out + (int64_t)p * pair_stride;
+    if (r < 0 || r >= b.n_regions) return;
+    const XrRegionDev R = b.regions[r];
+    const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
+    const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+    auto feat = [&](int f) -> unsigned {          // bit 0: access point of the net, bit 1: ... with a same-net axis neighbour
+        if (f >= N || id <= 0 || nn[f] != id) return 0u;
+        const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+        const bool adj = (x + 1 < X && nn[f + YZ] == id) || (y > 0 && nn[f - Z] == id) || (x > 0 && nn[f - YZ] == id) ||
+                         (y + 1 < Y && nn[f + Z] == id) || (z + 1 < Z && nn[f + 1] == id) || (z > 0 && nn[f - 1] == id);
+        return adj ? 3u : 1u;
+    };
+    if (vec4 && (N & 3) == 0) {
+        for (int f0 = threadIdx.x * 4; f0 < N; f0 += 256 * 4) {
+            unsigned m[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = feat(f0 + j);
+            const float4 v0 = make_float4((m[0] & 1u) ? 1.f : 0.f, (m[1] & 1u) ? 1.f : 0.f, (m[2] & 1u) ? 1.f : 0.f, (m[3] & 1u) ? 1.f : 0.f);
+            const float4 v1 = make_float4((m[0] & 2u) ? 1.f : 0.f, (m[1] & 2u) ? 1.f : 0.f, (m[2] & 2u) ? 1.f : 0.f, (m[3] & 2u) ? 1.f : 0.f);
+            XR_ST4(o + f0, v0);
+#pragma unroll
+            for (int pl = 1; pl < 7; pl++) XR_ST4(o + (int64_t)pl * N + f0, v1);
+        }
+    } else {
+        for (int f = threadIdx.x; f < N; f += 256) {
+            const unsigned m = feat(f);
+            o[f] = (m & 1u) ? 1.f : 0.f;
+            const float a = (m & 2u) ? 1.f : 0.f;
+#pragma unroll
+            for (int pl = 1; pl < 7; pl++) o[(int64_t)pl * N + f] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers (kept here so that only this TU needs the <<<>>> syntax)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1596,7 +1643,7 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
 // zch: 9 / 12 when every region of the batch has exactly that many layers, else 0
 hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
                            int threads, hipStream_t st) {
-    const dim3 g(b->n_envs), t(threads);
+    const dim3 g(b->env_count > 0 ? b->env_count : b->n_envs), t(threads);
     if (zch == XR_ZCH_DIAL) {
         hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
     } else if (lds_dist) {
@@ -1699,6 +1746,13 @@ hipError_t xr_launch_obs(const XrBatchDev* b, float* out, int64_t env_stride, in
             hipLaunchKernelGGL(xr_obs_kernel<1>, dim3(chunks, cnt), dim3(256), lds, st, *b, o, env_stride, lo);
         }
     }
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_netplanes_pairs(const XrBatchDev* b, const int32_t* pair_region, const int32_t* pair_net, int n_pairs,
+                                     float* out, int64_t pair_stride, int vec4, hipStream_t st) {
+    if (n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xr_netplanes_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, *b, pair_region, pair_net, out, pair_stride, vec4);
     return hipGetLastError();
 }
 

@@ -19,7 +19,8 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import proto
+from . import _lib, proto
+from .batch import RECORD_DTYPE
 from .build_3Dgrid import build_3Dgrid, legal_nets, observation_from_records
 from .regions import Region
 
@@ -60,7 +61,7 @@ class Game:
 
     def __init__(self, port_recv="5556", port_initial="6667", regions: Optional[Sequence[Region]] = None,
                  transport=None, device="cuda:0", return_device: bool = False, max_route_count: int = 10,
-                 via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400):
+                 via_cost: int = 800, drc_cost: int = 8, drc_unit: int = 400, **batch_kw):
         self.socket = None
         self.port_recv = port_recv
         self.port_initial = port_initial
@@ -77,42 +78,85 @@ class Game:
             from .batch import RegionBatch
             self.batch = RegionBatch(list(regions), n_envs=1, device=device, auto_reset=False,
                                      max_route_count=max_route_count, via_cost=via_cost, drc_cost=drc_cost,
-                                     drc_unit=drc_unit)
+                                     drc_unit=drc_unit, **batch_kw)
             self.regions = list(regions)
             self._actions = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._setup_inproc()
 
     # ---- in-process simulator ----------------------------------------------------------------
-    def _obs_inproc(self, nlegal: int):
-        obs = self.batch.env_observation(0, nlegal)
-        return obs if self.return_device else obs.cpu()
+    # Small-batch path (BASELINE config 1): per step ONE xr_batch_step_observe (route + observation of the new state), the
+    # packed 48-byte result record and the legal bitmask copied straight into pinned host memory, the observation copied
+    # with its exact size (the host knows K after the step: netSet minus the routed net) — one stream synchronisation.
+    def _setup_inproc(self):
+        b = self.batch
+        self._obs_dev = b.alloc_observation()
+        self._rec_host = torch.empty((1, _lib.RECORD_BYTES), dtype=torch.uint8).pin_memory()
+        self._legal_host = torch.empty((1, b.legal_words), dtype=torch.int64).pin_memory()
+        self._region_host = torch.empty(1, dtype=torch.int32).pin_memory()
+
+    def _legal_set(self):
+        out = set()
+        for w in range(self.batch.legal_words):
+            m = int(self._legal_host[0, w].item()) & 0xFFFFFFFFFFFFFFFF
+            while m:
+                bit = (m & -m).bit_length() - 1
+                out.add(w * 64 + bit + 1)
+                m &= m - 1
+        return out
+
+    def _record(self):
+        return self._rec_host.numpy().view(RECORD_DTYPE).reshape(-1)[0]
+
+    def _obs_view(self, nlegal: int):
+        reg = self.regions[int(self._region_host[0].item())]
+        X, Y, Z = reg.dims
+        c = 2 + 7 * nlegal
+        dev_view = self._obs_dev[0, : c * reg.n_nodes]
+        if self.return_device:
+            return dev_view.clone().view(1, c, Z, Y, X)
+        return dev_view.cpu().view(1, c, Z, Y, X)            # a fresh host tensor, like the reference's (callers keep them)
+
+    def _sync(self):
+        torch.cuda.current_stream(self.device).synchronize()
 
     def _reset_inproc(self):
         reset_try_time = 0
         limit = len(self.regions) * self.batch.cfg.max_route_count + 1
         while True:
             self.batch.reset(rotate=True)
-            legal = self.batch.legal_sets()[0]
+            self.batch.fetch_host("record", self._rec_host)
+            self.batch.fetch_host("legal", self._legal_host)
+            self.batch.fetch_host("region", self._region_host)
+            self._sync()
+            legal = self._legal_set()
             if len(legal) != 0:
                 break
             reset_try_time += 1            # region without routable nets: ask for the next one (:475-479)
             if reset_try_time > limit:
                 raise RuntimeError("no region with a routable net")
-        cum = self.batch.fetch("cum").cpu()[0].tolist()
+        cum = [int(v) for v in self._record()["cum"]]
         self.routed_nets = set()
         self.action_space = legal
         self.legal_action_set = set(legal)
         self.violation_last_step, self.total_wirelength_last_step, self.via_last_step = cum
-        self.observation = self._obs_inproc(len(legal))
+        self.batch.observation(self._obs_dev)
+        self.observation = self._obs_view(len(legal))
         return self.observation, reset_try_time
 
     def _step_inproc(self, action):
         self._actions.fill_(int(action))
-        self.batch.step(self._actions)
+        self.batch.step(self._actions, self._obs_dev)          # route + observation of the new state
+        self.batch.fetch_host("record", self._rec_host)
+        self.batch.fetch_host("legal", self._legal_host)
         self.routed_nets.add(action)
-        cum = self.batch.fetch("cum").cpu()[0].tolist()
-        net_set = self.batch.legal_sets()[0]
-        self.violation_cur_step, self.wirelength_cur_step, self.via_cur_step = cum
-        observation = self._obs_inproc(len(net_set))
+        k_after = len(self.legal_action_set) - (1 if action in self.legal_action_set else 0)
+        observation = self._obs_view(k_after)                   # (.cpu() / .clone() on the same stream: orders after the step)
+        self._sync()
+        rec = self._record()
+        net_set = self._legal_set()
+        if len(net_set) != k_after:                             # cannot happen; keeps the tensor honest if it ever does
+            observation = self._obs_view(len(net_set))
+        self.violation_cur_step, self.wirelength_cur_step, self.via_cur_step = (int(v) for v in rec["cum"])
         return observation, net_set
 
     # ---- protocol mode ---------------------------------------------------------------------------
