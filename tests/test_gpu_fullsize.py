@@ -92,3 +92,51 @@ def test_fullsize_observation_properties(regions):
                 assert np.array_equal(o[2 + 7 * j + 1], o[2 + 7 * j + c])                # the six aliased planes
             assert (o[2 + 7 * j + 1] <= o[2 + 7 * j]).all()
         assert set(np.unique(o[2:])) <= {0.0, 1.0}
+
+
+def test_queue_form_observation_bytes_vs_oracle_with_rotation():
+    """The default step form (plan + persistent queue launch) against the ORACLE's observation bytes — not against another
+    HIP form: 256 env slots over 192 ispd18_test1-sized regions (K up to 36), 40 batched steps with auto-reset and region
+    rotation (2 replays per region, so slots change region), 32 observations compared byte for byte every step (a different
+    set each step), deltas / done / reward of all 256 envs every step, hash chains at the end."""
+    import torch
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+    B, R, STEPS = 256, 192, 40
+    regions = config_regions(3, R)
+    assert max(r.n_nets for r in regions) >= 34
+    batch = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
+    batch.reset(rotate=True)
+    envs = [orc.OracleEnv(regions[e % R]) for e in range(B)]
+    cur_region = [e % R for e in range(B)]
+    obs = batch.alloc_observation()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    checked = 0
+    for it in range(STEPS):
+        batch.random_actions(777 + it, acts)
+        a = acts.cpu().numpy()
+        batch.step(acts, obs)
+        assert batch.observe_timing()[0] == 3                  # XR_OBS_QUEUE
+        rec = batch.records()
+        region = batch.fetch("region").cpu().numpy()
+        for e in range(B):
+            if rec["status"][e] & 8:                           # XR_ENV_WAS_RESET: the slot re-initialised (maybe on its next region)
+                if region[e] != cur_region[e]:
+                    cur_region[e] = int(region[e])
+                    envs[e] = orc.OracleEnv(regions[cur_region[e]])
+                else:
+                    envs[e].reset()
+                assert rec["nlegal"][e] == envs[e].nlegal() and list(rec["cum"][e]) == envs[e].cum().tolist()
+                continue
+            ref = envs[e].step(int(a[e]))
+            assert list(rec["delta"][e]) == ref["delta"].tolist(), (it, e)
+            assert bool(rec["done"][e]) == ref["done"] and rec["path_len"][e] == ref["path_len"]
+            assert rec["reward"][e] == orc.reward(*[int(v) for v in ref["delta"]])
+            assert rec["nlegal"][e] == envs[e].nlegal()
+        for e in range((it * 37) % 8, B, 8):
+            ro = envs[e].observation().ravel()
+            assert np.array_equal(obs[e, : ro.size].cpu().numpy(), ro), (it, e)
+            checked += 1
+    assert checked == STEPS * 32
+    assert len(set(cur_region)) > 1 and any(cur_region[e] != e % R for e in range(B))     # rotation really happened
