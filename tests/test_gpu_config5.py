@@ -43,7 +43,7 @@ def test_config5_fullsize_steps_match_oracle(regions):
             assert np.array_equal(path[e, :n], res["path"][:n])
             assert np.array_equal(owner[e, : regions[e].n_nodes], env.owner())
             assert int(hashes[e]) & 0xFFFFFFFFFFFFFFFF == env.hash() & 0xFFFFFFFFFFFFFFFF
-    assert int(batch.fetch("sweeps").cpu().min()) > 0
+    assert int(batch.fetch("sweeps").cpu().max()) > 0
 
 
 def test_config5_fullsize_route_order_matches_oracle(regions):
@@ -63,3 +63,33 @@ def test_config5_fullsize_route_order_matches_oracle(regions):
             env.step(int(a))
         assert cum[e].tolist() == env.cum().tolist()
         assert np.array_equal(owner[e, : r.n_nodes], env.owner())
+
+
+@pytest.mark.parametrize("router", [0, 1])       # 0: bucketed frontier, HBM-scratch form (default); 1: line-segment sweeps in scratch
+def test_config5_32_envs_10_steps_match_oracle(router):
+    """32 full-size config 5 envs x 10 batched steps (random net order, K = 32) against the oracle stepped with OpenMP over
+    envs: deltas, done, path length, reward of every env at every step; owner grids, cumulative metrics and the hash chains
+    (every path node of every step) at the end.  The scratch of the frontier router must be left CLEAN by every route —
+    a stale word would corrupt a later step of the same slot."""
+    from xroute_env_amd.batch import RegionBatch
+    B, STEPS = 32, 10
+    regs = config_regions(5, B)
+    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router)
+    batch.reset()
+    ob = orc.OracleBatch(regs)
+    threads = ob.max_threads()
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    for it in range(STEPS):
+        batch.random_actions(900 + it, acts)
+        a = acts.cpu().numpy()
+        batch.step(acts)
+        ref = ob.step(a, threads=threads, auto_reset=True)
+        rec = batch.records()
+        assert np.array_equal(rec["delta"], ref["delta"]), it
+        assert np.array_equal(rec["done"], ref["done"]) and np.array_equal(rec["reward"], ref["reward"])
+    owner = batch.fetch("owner").cpu().numpy()
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    for e, env in enumerate(ob.envs):
+        assert np.array_equal(owner[e, : env.n], env.owner()), e
+        assert int(hashes[e]) == env.hash() and rec["cum"][e].tolist() == env.cum().tolist()
+    assert int(batch.fetch("sweeps").cpu().max()) > 0

@@ -10,6 +10,8 @@
 #define CAP 0x30000000u
 #define UNREACHED 0xFFFFFFFDu
 
+int g_astar = 0;      /* 1: buckets keyed on f = d + h(v), h = distance to the bounding box of the unconnected targets */
+int g_chain = 0;      /* 1: a neighbour lowered into the current bucket is expanded within the same round */
 typedef struct {
     long rounds, expansions, relax_ok, searches, max_open, scans_nonempty_words, routes;
 } dial_stats;
@@ -45,19 +47,32 @@ int dial_route(int X, int Y, int Z, const int32_t* xs, const int32_t* ys, const 
     st->routes++;
     while (remaining > 0) {
         st->searches++;
+        /* bounding box of the unconnected targets (coordinates) */
+        int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30), bz0 = 1 << 30, bz1 = -1;
+        for (int i = 0; i < nap; i++) if (!conn[i]) {
+            int f = ap_node[i], x = f / YZ, y = (f / Z) % Y, z = f % Z;
+            if (xs[x] < bx0) bx0 = xs[x]; if (xs[x] > bx1) bx1 = xs[x];
+            if (ys[y] < by0) by0 = ys[y]; if (ys[y] > by1) by1 = ys[y];
+            if (z < bz0) bz0 = z; if (z > bz1) bz1 = z;
+        }
+#define HEUR(f) (g_astar ? (uint32_t)(({ int _x = (f) / YZ, _y = ((f) / Z) % Y, _z = (f) % Z; \
+            int _hx = xs[_x] < bx0 ? bx0 - xs[_x] : (xs[_x] > bx1 ? xs[_x] - bx1 : 0); \
+            int _hy = ys[_y] < by0 ? by0 - ys[_y] : (ys[_y] > by1 ? ys[_y] - by1 : 0); \
+            int _hz = _z < bz0 ? bz0 - _z : (_z > bz1 ? _z - bz1 : 0); _hx + _hy + _hz * via_cost; })) : 0u)
         for (int f = 0; f < N; f++) if (defer[f]) { open[f] = 1; defer[f] = 0; }
         uint32_t best = 0xFFFFFFFFu;
         for (;;) {
             for (int i = 0; i < nap; i++) if (!conn[i]) { uint32_t w = field[ap_node[i]]; if (w < UNREACHED && (w >> 2) < best) best = w >> 2; }
             uint32_t m = 0xFFFFFFFFu; long nopen = 0;
-            for (int f = 0; f < N; f++) if (open[f]) { nopen++; if ((field[f] >> 2) < m) m = field[f] >> 2; }
+            for (int f = 0; f < N; f++) if (open[f]) { nopen++; uint32_t k = (field[f] >> 2) + HEUR(f); if (k < m) m = k; }
             if (nopen > st->max_open) st->max_open = nopen;
             if (m == 0xFFFFFFFFu || m > best) break;
             st->rounds++;
             const uint32_t hi = m + delta_w;
             /* snapshot semantics of one parallel round: collect the bucket first */
             int* bucket = (int*)malloc(sizeof(int) * (nopen + 1)); int nb = 0;
-            for (int f = 0; f < N; f++) if (open[f] && (field[f] >> 2) < hi) { bucket[nb++] = f; open[f] = 0; }
+            int bcap = nopen + 1;
+            for (int f = 0; f < N; f++) if (open[f] && (field[f] >> 2) + HEUR(f) < hi) { bucket[nb++] = f; open[f] = 0; }
             for (int bi = 0; bi < nb; bi++) {
                 const int f = bucket[bi];
                 const uint32_t w = field[f], d = w >> 2;
@@ -80,8 +95,12 @@ int dial_route(int X, int Y, int Z, const int32_t* xs, const int32_t* ys, const 
                     if (cand >= CAP) continue;
                     const uint32_t cw = ((uint32_t)cand << 2) | (wn & 3u);
                     if (cw >= wn) continue;
-                    if (cand > best) { defer[f] = 1; continue; }
-                    field[nf[k]] = cw; open[nf[k]] = 1; st->relax_ok++;
+                    if (cand + HEUR(nf[k]) > best) { defer[f] = 1; continue; }
+                    field[nf[k]] = cw; st->relax_ok++;
+                    if (g_chain && cand + HEUR(nf[k]) < hi) {
+                        if (nb >= bcap) { bcap *= 2; bucket = (int*)realloc(bucket, sizeof(int) * bcap); }
+                        bucket[nb++] = nf[k]; open[nf[k]] = 0;
+                    } else open[nf[k]] = 1;
                 }
             }
             free(bucket);

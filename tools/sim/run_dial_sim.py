@@ -11,6 +11,8 @@ class Stats(C.Structure):
 L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdial_sim.so"))
 vp = C.c_void_p
 L.dial_route.argtypes = [C.c_int]*3 + [vp]*5 + [C.c_int, vp, vp] + [C.c_int]*4 + [vp, vp, C.c_int, vp, vp]
+C.c_int.in_dll(L, 'g_astar').value = int(os.environ.get('ASTAR', '0'))
+C.c_int.in_dll(L, 'g_chain').value = int(os.environ.get('CHAIN', '0'))
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 nreg = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 mults = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4]

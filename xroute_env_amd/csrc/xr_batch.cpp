@@ -113,7 +113,8 @@ struct xr_batch {
     DevBuf<int64_t> env_steps;
     DevBuf<long long> phase_cycles;
     DevBuf<unsigned long long> total_steps;
-    DevBuf<uint32_t> dist_scratch;
+    DevBuf<uint32_t> dist_scratch, dg_field, dg_masks, dg_touch, dg_path;
+    bool dial_big = false;
     DevBuf<unsigned short> list_scratch;
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net;
@@ -385,13 +386,23 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     {
         const size_t mw_max = (size_t)b->n_max / 32 + 1;
         const size_t dial_lds = (size_t)b->n_max * 4 + 4 * mw_max * 4 + el_bytes + 16;
+        // HBM-scratch form (regions too large for LDS, or force_scratch_field): groups of 1024 nodes must fit the LDS group table
+        const size_t big_lds = 1024 * 4 + 1024 * 2 + 256 * 4 + 1024 * 4 + 2 * 512 * 8 + el_bytes + 16;
+        const bool big_ok = ((size_t)b->n_max / 1024 + 2) <= 1024;
+        b->dial_big = false;
         if (b->cfg.router != XR_ROUTER_SWEEP && !b->cfg.force_scratch_field && dial_lds + kLdsStatic <= kLdsLimit) {
             b->kzch = -1;
             b->lds_dist = true;
             b->route_lds = dial_lds;
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 256;
+        } else if (b->cfg.router != XR_ROUTER_SWEEP && big_ok) {
+            b->kzch = -1;
+            b->lds_dist = false;
+            b->dial_big = true;
+            b->route_lds = big_lds;
+            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 256;
         } else if (b->cfg.router == XR_ROUTER_DIAL) {
-            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL needs %zu bytes of LDS for the largest region", dial_lds);
+            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL: the largest region (%d nodes) exceeds the frontier router's limits", b->n_max);
         }
     }
     // the fused observation epilogue stages the ascending legal-id list in the same LDS
@@ -443,7 +454,13 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->queue, 3);
     XR_ALLOC(b->plan_units, (size_t)B * std::max(1, k_max));
     XR_ALLOC(b->plan_unit_net, (size_t)B * std::max(1, k_max));
-    if (!b->lds_dist) {
+    if (b->dial_big) {
+        const size_t mwg = (size_t)b->n_max / 32 + 1;
+        XR_ALLOC(b->dg_field, (size_t)B * b->n_max);
+        XR_ALLOC(b->dg_masks, (size_t)B * 2 * mwg);
+        XR_ALLOC(b->dg_touch, (size_t)B * b->n_max);
+        XR_ALLOC(b->dg_path, (size_t)B * b->n_max);
+    } else if (!b->lds_dist) {
         XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->list_scratch, (size_t)B * b->lines_max);
@@ -470,6 +487,14 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemsetAsync(b->records.p, 0, (size_t)B * sizeof(XrStepRecord), st));
     XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
     XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
+    if (b->dial_big) {      // the persistent CLEAN state of the scratch: field CLEAN, no open bits, word minima = infinity
+        const size_t mwg = (size_t)b->n_max / 32 + 1;
+        XR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->dg_field.p), (int)0xFFFFFFFEu, (size_t)B * b->n_max, st));
+        for (int e = 0; e < B; e++) {
+            XR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->dg_masks.p + (size_t)e * 2 * mwg), 0, mwg, st));
+            XR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->dg_masks.p + (size_t)e * 2 * mwg + mwg), (int)0xFFFFFFFFu, mwg, st));
+        }
+    }
     std::vector<uint64_t> hhash(B, 0xcbf29ce484222325ULL);
     XR_HIP(hipMemcpyAsync(b->hash.p, hhash.data(), (size_t)B * sizeof(uint64_t), hipMemcpyHostToDevice, st));
 
@@ -486,6 +511,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.records = b->records.p;
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 4;
+    d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
+    d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
     d.env_base = 0; d.env_count = 0;

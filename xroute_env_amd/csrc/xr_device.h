@@ -87,6 +87,11 @@ struct XrBatchDev {
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;
     unsigned short* list_scratch;   // [B][lines_max] worklists of the large-region variant
+    // HBM-scratch form of the frontier router (xr_dial_route_env_big): persistent per-env scratch, CLEAN between routes
+    uint32_t* dg_field;      // [B][n_max]
+    uint32_t* dg_masks;      // [B][2][n_max/32 + 1]  open bits, cached word minima
+    uint32_t* dg_touch;      // [B][n_max]  nodes touched by the current route
+    uint32_t* dg_path;       // [B][n_max]  first half: path of the current trace; second half: deferred nodes
     long long* phase_cycles; // [B][8] thread-0 cycle counts per kernel phase (only written with -DXR_PHASE_TIMING)
     // fused observation output of the step kernel (null: route only)
     float* obs_out;
@@ -104,6 +109,7 @@ struct XrBatchDev {
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     int32_t env_base, env_count;   // route kernel: envs [env_base, env_base + env_count) (env_count 0 = all); stream-per-region mode
+    int32_t dial_mult_big;   // the same for the HBM-scratch form
     int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
     double w_violation, w_via, w_wirelength;
 };

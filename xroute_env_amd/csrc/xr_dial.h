@@ -25,6 +25,15 @@
 // atomic exchange BEFORE it reads the distances, so a node lowered concurrently is either seen with its new value or
 // re-opened by the thread that lowered it — no lost update for any bucket width.
 //
+// Buckets are keyed on f = d + h(v), not on d (A* order): h(v) = distance from v to the bounding box of the access points of the
+// still unconnected pins (coordinate differences + via cost per layer: a consistent lower bound of the remaining cost, so f never
+// decreases along a path and Dial's bucket order applies to f).  The search stops when the smallest open key exceeds `best`
+// (the smallest tentative distance of a target, whose h is 0): every node with d + h <= best is exact by then — that covers every
+// node on a shortest path to the chosen target, every tight predecessor the back-trace may look at, and every target tied
+// with it.  Candidates with d + h > best are not written.  The explored set shrinks from a ball around the component to a band
+// around the connection (6.5x fewer expansions on BASELINE config 3 regions, 2x on config 5; tools/sim/dial_sim.c), and all
+// nodes of an obstacle-free straight connection share ONE key, so run-ahead carries a distance along it within one round.
+//
 // Later pins re-use the field: after a connection the path nodes and the reached pin's access points become sources
 // (distance 0, open); every other value is still an upper bound.
 //
@@ -117,6 +126,93 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
     xr_publish_record(b, e);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Isolated pins.  A pin whose access points sit in a pocket closed by BLOCKAGE nodes can never be reached (and, when it is
+// the net's first pin, can never reach anything): XR-Maze v1 then charges one violation per unreachable pin — but only after a
+// search with no reachable target has explored the WHOLE component (no bound ever prunes it), the slowest thing a router can be
+// asked to do: 4-5 % of the BASELINE config 5 env-steps, each costing 10-40x an average route.  Pockets are tiny (1-3
+// nodes in every case measured), so each wave floods one pin's pocket with a budget of XR_POCKET_CAP nodes before the first
+// search: a flood that closes without meeting another pin's access point marks the pin isolated (s_ap_conn = 2) and the
+// searches skip it.  Same results by construction (the pocket's boundary is static), nothing explored for nothing.
+// ------------------------------------------------------------------------------------------------
+#define XR_POCKET_CAP 12
+template <class ApT, class BlockedFn>
+__device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_of, const short* s_ap_pin, unsigned char* s_ap_conn,
+                                                       int X, int Y, int Z, uint32_t ldir, uint32_t magic_yz, uint32_t magic_z,
+                                                       BlockedFn blocked, int (*s_pocket)[XR_POCKET_CAP + 8], int* s_niso, int* s_src_iso,
+                                                       int first_pin) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwv = min((int)(blockDim.x >> 6), 4);
+    if (wv >= nwv) return;
+    const int YZ = Y * Z;
+    int* vis = s_pocket[wv];
+    int pj = 0;                                           // running index of distinct pins (wave-uniform)
+    for (int i0 = 0; i0 < nap; i0++) {
+        if (!(s_ap_conn[i0] & 0x80)) continue;           // (bit 7: first access point of its pin, set by the caller)
+        const short pin = s_ap_pin[i0];
+        const int mine = (pj++ % nwv) == wv;
+        if (!mine) continue;
+        // seed: the pin's access points
+        int cnt = 0;
+        bool open_pocket = false;
+        for (int b0 = 0; b0 < nap; b0 += 64) {
+            const int i = b0 + lane;
+            const bool is = i < nap && s_ap_pin[i] == pin;
+            const unsigned long long mm = __ballot(is);
+            const int pos = cnt + __popcll(mm & ((1ULL << lane) - 1ULL));
+            if (is && pos < XR_POCKET_CAP) vis[pos] = (int)ap_f_of[i];
+            cnt += __popcll(mm);
+        }
+        if (cnt > XR_POCKET_CAP) continue;                // (not a small pocket)
+        __builtin_amdgcn_wave_barrier();
+        int lo = 0;
+        while (lo < cnt && !open_pocket) {
+            const int hi = min(cnt, lo + 16);
+            // lane = (frontier node, direction)
+            const int k = lo + (lane >> 2), dir = lane & 3;
+            int nf = -1;
+            if (k < hi) {
+                const int f = vis[k];
+                uint32_t x, r, y, z;
+                xr_divmod((uint32_t)f, (uint32_t)YZ, magic_yz, x, r);
+                xr_divmod(r, (uint32_t)Z, magic_z, y, z);
+                const bool vert = (ldir >> z) & 1u;
+                if (dir == 0) nf = vert ? ((int)y + 1 < Y ? f + Z : -1) : ((int)x + 1 < X ? f + YZ : -1);
+                else if (dir == 1) nf = vert ? (y > 0 ? f - Z : -1) : (x > 0 ? f - YZ : -1);
+                else if (dir == 2) nf = ((int)z + 1 < Z) ? f + 1 : -1;
+                else nf = (z > 0) ? f - 1 : -1;
+                if (nf >= 0 && blocked(nf)) nf = -1;
+                if (nf >= 0) for (int q = 0; q < cnt; q++) if (vis[q] == nf) { nf = -1; break; }      // (cnt <= XR_POCKET_CAP)
+            }
+            unsigned long long cand = __ballot(nf >= 0);
+            lo = hi;
+            while (cand) {                                // append in lane order, de-duplicating against what was just appended
+                const int src = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int c = __builtin_amdgcn_readlane(nf, src);
+                if (__ballot(lane < cnt && vis[lane] == c)) continue;          // already in the pocket (cnt <= 64 entries)
+                if (cnt >= XR_POCKET_CAP) { open_pocket = true; break; }
+                if (lane == 0) vis[cnt] = c;
+                cnt++;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (open_pocket) continue;
+        // closed pocket: isolated unless it holds an access point of another pin of the net
+        bool other = false;
+        for (int b0 = 0; b0 < nap; b0 += 64) {
+            const int i = b0 + lane;
+            bool hit = false;
+            if (i < nap && s_ap_pin[i] != pin) { const int f = (int)ap_f_of[i]; for (int q = 0; q < cnt; q++) hit |= (vis[q] == f); }
+            if (__ballot(hit)) other = true;
+        }
+        if (other) continue;
+        for (int i = lane; i < nap; i += 64) if (s_ap_pin[i] == pin) s_ap_conn[i] = (s_ap_conn[i] & 0x80) | 2;
+        if (lane == 0) { if ((int)pin == first_pin) *s_src_iso = 1; else atomicAdd(s_niso, 1); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS form.  LDS carve (dynamic):  field u32[n_max] | open | defer | claim | wmin  (u32[mw_max] each, mw_max =
 // n_max / 32 + 1) | el4x | el4y.
@@ -129,7 +225,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
     __shared__ uint32_t s_min[3], s_bst[3];
     __shared__ unsigned long long s_tkey;
-    __shared__ int s_remaining, s_target_i, s_first_pin, s_npins;
+    __shared__ int s_hb[6];                                   // bounding box of the unconnected targets: x, y (coordinates x4), z
+    __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
+    __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -151,8 +249,10 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     uint32_t* s_defer = s_open + mw_max;
     uint32_t* s_claim = s_defer + mw_max;
     uint32_t* s_wmin = s_claim + mw_max;
-    uint32_t* s_el4x = s_wmin + mw_max;
-    uint32_t* s_el4y = s_el4x + (b.x_max + 2);
+    // coordinate tables (x4, relative to the first track): s_xc[k] = 4*(xs[clamp(k-1)] - xs[0]), k = 0 .. X+1, so that the
+    // coordinate of track x is s_xc[x+1] and the edge between tracks i-1 and i is s_xc[i+1] - s_xc[i] (0 at both ends)
+    uint32_t* s_xc = s_wmin + mw_max;
+    uint32_t* s_yc = s_xc + (b.x_max + 2);
 
     // access points of the net and the edge tables: loads issued now, consumed after the grid build (three dependent
     // global round trips otherwise sit on the critical path of a 100 us kernel)
@@ -160,9 +260,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     const int nap = ap_hi - ap_lo;    // 1 <= nap <= XR_MAX_AP_PER_NET (checked at load)
     int my_ap_f = 0, my_ap_pin = 0;
     if (tid < nap) { my_ap_f = b.ap_node[R.ap_off + ap_lo + tid]; my_ap_pin = b.ap_pin[R.ap_off + ap_lo + tid]; }
-    uint32_t my_elx = 0, my_ely = 0;
-    if (tid >= 1 && tid < X) my_elx = (uint32_t)(b.coords[R.xs_off + tid] - b.coords[R.xs_off + tid - 1]) << 2;
-    if (tid >= 1 && tid < Y) my_ely = (uint32_t)(b.coords[R.ys_off + tid] - b.coords[R.ys_off + tid - 1]) << 2;
+    uint32_t my_xc = 0, my_yc = 0;
+    if (tid <= X + 1) my_xc = (uint32_t)(b.coords[R.xs_off + min(max(tid - 1, 0), X - 1)] - b.coords[R.xs_off]) << 2;
+    if (tid <= Y + 1) my_yc = (uint32_t)(b.coords[R.ys_off + min(max(tid - 1, 0), Y - 1)] - b.coords[R.ys_off]) << 2;
 
     // ---- grid build: field word of every node for THIS net.  node_net / owner rows are padded to multiples of 8
     // elements (16-byte loads); pad slots and blockages become 0.  Loads of four chunks are issued before the first use.
@@ -199,14 +299,15 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         }
     }
     for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_claim[i] = 0; s_wmin[i] = XR_DIAL_INF; }
-    // edge length tables (x4): el4x[i] = 4*(xs[i]-xs[i-1]), 0 at both ends
-    if (tid <= X) s_el4x[tid] = my_elx;
-    if (tid <= Y) s_el4y[tid] = my_ely;
-    for (int i = tid + nthr; i <= X; i += nthr)
-        s_el4x[i] = (i < X) ? (uint32_t)(b.coords[R.xs_off + i] - b.coords[R.xs_off + i - 1]) << 2 : 0u;
-    for (int i = tid + nthr; i <= Y; i += nthr)
-        s_el4y[i] = (i < Y) ? (uint32_t)(b.coords[R.ys_off + i] - b.coords[R.ys_off + i - 1]) << 2 : 0u;
-    if (tid == 0) { s_first_pin = 0x7FFFFFFF; s_npins = 0; }
+    if (tid <= X + 1) s_xc[tid] = my_xc;
+    if (tid <= Y + 1) s_yc[tid] = my_yc;
+    for (int i = tid + nthr; i <= X + 1; i += nthr)
+        s_xc[i] = (uint32_t)(b.coords[R.xs_off + min(i - 1, X - 1)] - b.coords[R.xs_off]) << 2;
+    for (int i = tid + nthr; i <= Y + 1; i += nthr)
+        s_yc[i] = (uint32_t)(b.coords[R.ys_off + min(i - 1, Y - 1)] - b.coords[R.ys_off]) << 2;
+    auto el4x = [&](int i) { return s_xc[i + 1] - s_xc[i]; };
+    auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
+    if (tid == 0) { s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0; }
     __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
@@ -230,10 +331,18 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         bool seen = false;
         for (int j = 0; j < i; j++) seen |= (s_ap_pin[j] == pin);
         if (!seen) atomicAdd(&s_npins, 1);
-        if (pin == (short)s_first_pin) { s_ap_conn[i] = 1; make_source(s_ap_f[i]); }
+        unsigned char cflag = seen ? 0 : 0x80;            // bit 7: first access point of its pin (for xr_mark_isolated_pins)
+        if (pin == (short)s_first_pin) { cflag |= 1; make_source(s_ap_f[i]); }
+        s_ap_conn[i] = cflag;
     }
     __syncthreads();
-    if (tid == 0) s_remaining = s_npins - 1;
+    // pins in closed pockets are never searched for (see xr_mark_isolated_pins)
+    xr_mark_isolated_pins(nap, s_ap_f, s_ap_pin, s_ap_conn, X, Y, Z, ldir, R.magic_yz, R.magic_z,
+                          [&](int f) { return field[f] == XR_W_BLOCK; }, s_pocket, &s_niso, &s_src_iso, s_first_pin);
+    __syncthreads();
+    for (int i = tid; i < nap; i += nthr) s_ap_conn[i] &= 0x7F;
+    const int n_isolated = s_src_iso ? s_npins - 1 : s_niso;       // unreachable pins known up front
+    if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
     XR_LAP(0);
 
     const uint32_t via4 = (uint32_t)b.via_cost << 2;
@@ -251,6 +360,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
             s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
             s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
             s_tkey = ~0ULL;
+            s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1;
         }
         for (int i = tid; i < mw; i += nthr) {
             const uint32_t m = s_defer[i];
@@ -258,6 +368,25 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         }
         __syncthreads();
         if (s_remaining <= 0) break;          // uniform: written before the barrier above
+        // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
+        for (int i = tid; i < nap; i += nthr)
+            if (!s_ap_conn[i]) {
+                uint32_t ax, ar, ay, az;
+                xr_divmod((uint32_t)s_ap_f[i], uYZ, R.magic_yz, ax, ar);
+                xr_divmod(ar, uZ, R.magic_z, ay, az);
+                atomicMin(&s_hb[0], (int)s_xc[ax + 1]); atomicMax(&s_hb[1], (int)s_xc[ax + 1]);
+                atomicMin(&s_hb[2], (int)s_yc[ay + 1]); atomicMax(&s_hb[3], (int)s_yc[ay + 1]);
+                atomicMin(&s_hb[4], (int)az); atomicMax(&s_hb[5], (int)az);
+            }
+        __syncthreads();
+        const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
+        // h(v): distance to that box — coordinate differences + one via cost per layer (a consistent lower bound)
+        auto heur = [&](int x, int y, int z) -> uint32_t {
+            const int xc = (int)s_xc[x + 1], yc = (int)s_yc[y + 1];
+            const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
+            const int hz = max(0, max(hb4 - z, z - hb5));
+            return ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
+        };
         int cur = 0;
         for (;;) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
@@ -294,15 +423,21 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                             q[j] = bits ? __ffsll((long long)bits) - 1 : -1;
                             bits &= bits - 1;                        // (0 stays 0)
                         }
+                        int fq[4];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) w[j] = q[j] >= 0 ? field[(q[j] & 31) * mw + (q[j] < 32 ? wi : wi2)] : XR_DIAL_INF;
+                        for (int j = 0; j < 4; j++) fq[j] = (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) w[j] = q[j] >= 0 ? field[fq[j]] : XR_DIAL_INF;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             if (q[j] < 0) continue;
-                            const uint32_t d = w[j] >> 2;
-                            if (d >= hi) {
+                            uint32_t cx, cr, cy, cz;
+                            xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx, cr);
+                            xr_divmod(cr, uZ, R.magic_z, cy, cz);
+                            const uint32_t key = (w[j] >> 2) + heur((int)cx, (int)cy, (int)cz);
+                            if (key >= hi) {
                                 keep |= 1ULL << q[j];
-                                if (q[j] < 32) kminA = d < kminA ? d : kminA; else kminB = d < kminB ? d : kminB;
+                                if (q[j] < 32) kminA = key < kminA ? key : kminA; else kminB = key < kminB ? key : kminB;
                             } else expd |= 1ULL << q[j];
                         }
                     }
@@ -329,21 +464,30 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         int nf[4];
                         uint32_t len4[4], wn[4], cw[4], old[4];
                         nf[0] = vert ? ((int)y + 1 < Y ? (int)f + Z : -1) : ((int)x + 1 < X ? (int)f + YZ : -1);
-                        len4[0] = vert ? s_el4y[y + 1] : s_el4x[x + 1];
+                        len4[0] = vert ? el4y(y + 1) : el4x(x + 1);
                         nf[1] = vert ? (y > 0 ? (int)f - Z : -1) : (x > 0 ? (int)f - YZ : -1);
-                        len4[1] = vert ? s_el4y[y] : s_el4x[x];
+                        len4[1] = vert ? el4y(y) : el4x(x);
                         nf[2] = ((int)z + 1 < Z) ? (int)f + 1 : -1; len4[2] = via4;
                         nf[3] = (z > 0) ? (int)f - 1 : -1;          len4[3] = via4;
 #pragma unroll
                         for (int k = 0; k < 4; k++) wn[k] = nf[k] >= 0 ? field[nf[k]] : XR_W_BLOCK;
                         bool refused = false;
+                        uint32_t key[4];
+                        {   // h of the four neighbours (coordinates differ from f's in one component)
+                            const int ix = (int)x, iy = (int)y, iz = (int)z;
+                            key[0] = vert ? heur(ix, min(iy + 1, Y - 1), iz) : heur(min(ix + 1, X - 1), iy, iz);
+                            key[1] = vert ? heur(ix, max(iy - 1, 0), iz) : heur(max(ix - 1, 0), iy, iz);
+                            key[2] = heur(ix, iy, min(iz + 1, Z - 1));
+                            key[3] = heur(ix, iy, max(iz - 1, 0));
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const uint32_t cand4 = d4 + len4[k] + ((wn[k] & 2u) ? pen4 : 0u);
                             cw[k] = cand4 | (wn[k] & 3u);
+                            key[k] += cand4 >> 2;                                 // f = d + h
                             // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
                             bool go = wn[k] != XR_W_BLOCK && cand4 < XR_W_USABLE_END && cw[k] < wn[k];
-                            if (go && (cand4 >> 2) > best) { refused = true; go = false; }      // bound pruning
+                            if (go && key[k] > best) { refused = true; go = false; }             // bound pruning (on f)
                             if (!go) cw[k] = XR_DIAL_INF;
                         }
                         // the four atomics are issued back to back; their results are looked at afterwards
@@ -353,12 +497,12 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             if (cw[k] < old[k]) {                      // lowered
-                                if (XR_DIAL_CHAIN && next_f < 0 && (cw[k] >> 2) < hi) { next_f = nf[k]; continue; }
+                                if (XR_DIAL_CHAIN && next_f < 0 && key[k] < hi) { next_f = nf[k]; continue; }
                                 uint32_t oq, orr;                      // the neighbour becomes open
                                 xr_divmod((uint32_t)nf[k], umw, magic_mw, oq, orr);
                                 atomicOr(&s_open[orr], 1u << oq);
-                                atomicMin(&s_wmin[orr], cw[k] >> 2);
-                                lmin = (cw[k] >> 2) < lmin ? (cw[k] >> 2) : lmin;
+                                atomicMin(&s_wmin[orr], key[k]);
+                                lmin = key[k] < lmin ? key[k] : lmin;
                             }
                         }
                         if (refused) xr_mask_or(s_defer, f, umw, magic_mw);
@@ -429,10 +573,10 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     int u = -1;
                     uint32_t len4 = 0;
                     switch (tid) {
-                    case 0: if (!vert && x + 1 < X) { u = v + YZ; len4 = s_el4x[x + 1]; } break;   // E
-                    case 1: if (vert && y > 0)      { u = v - Z;  len4 = s_el4y[y]; } break;       // S
-                    case 2: if (!vert && x > 0)     { u = v - YZ; len4 = s_el4x[x]; } break;       // W
-                    case 3: if (vert && y + 1 < Y)  { u = v + Z;  len4 = s_el4y[y + 1]; } break;   // N
+                    case 0: if (!vert && x + 1 < X) { u = v + YZ; len4 = el4x(x + 1); } break;   // E
+                    case 1: if (vert && y > 0)      { u = v - Z;  len4 = el4y(y); } break;       // S
+                    case 2: if (!vert && x > 0)     { u = v - YZ; len4 = el4x(x); } break;       // W
+                    case 3: if (vert && y + 1 < Y)  { u = v + Z;  len4 = el4y(y + 1); } break;   // N
                     case 4: if (z + 1 < Z)          { u = v + 1;  len4 = via4; } break;           // U
                     case 5: if (z > 0)              { u = v - 1;  len4 = via4; } break;           // D
                     default: break;
@@ -509,7 +653,470 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         // (the barrier at the top of the loop orders these writes before the next search / the exit test)
     }
 
-    if (tid == 0) xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h);
+    if (tid == 0) {
+        if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
+        xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h);
+    }
+    XR_LAP(5);
+    XR_TDUMP();
+}
+
+// ------------------------------------------------------------------------------------------------
+// HBM-scratch form for regions whose field does not fit LDS (BASELINE config 5: 256x256x12 = 786 k nodes).
+//
+// Same algorithm, different placement — and NO per-step sweep over the N nodes: the per-env field lives in HBM scratch in
+// a persistent CLEAN state (0xFFFFFFFE = "never touched in this route"); a node's word is created the first time a
+// neighbour relaxes it (blockage / held flags derived from node_net / owner on the spot), every first touch is logged
+// in a `touched` list and the route ends by resetting exactly those nodes.  A route that explores 29 k of 786 k nodes
+// (the BASELINE config 5 average) therefore moves ~1 MB instead of the 6.3 MB a grid build alone would cost.
+//
+//   field  u32[n_max]   CLEAN | (distance << 2) | (held << 1) | 1           (all accesses: L2-scope atomics / sc1 loads)
+//   open   u32[n_max/32]         node bit f & 31 of word f >> 5 (flat order: a word = 32 consecutive nodes)
+//   defer  a LIST of nodes (an expanded node with an edge refused by the bound), re-opened when the next search starts
+//   wmin   u32[n_max/32]         lower bound of the open distances of a word        (HBM)
+//   gmin   u32[n_max/1024]       lower bound per group of 32 words                  (LDS)
+//
+// A round is a staged pipeline over compact work lists in LDS, so that every global round trip is taken by ALL work items
+// at once (the latency of an L2 atomic is ~1-2 us; a lane-per-word scan as in the LDS form would serialise them):
+//   A  groups with gmin < hi -> list G          A2  their words with wmin < hi -> list A
+//   B  take the open bits of the words of A -> node list N
+//   C  classify the nodes of N by distance: beyond the bucket -> back into open / wmin / gmin; inside -> list E (f, d)
+//   D  one lane per (node of E, direction): relax the neighbour.  A neighbour lowered INTO the bucket goes to the next E list
+//      and stage D runs again (run-ahead within the round: one barrier + two round trips per hop instead of a full round).
+// Lists have fixed capacities; whatever does not fit stays in (or is put back into) the open mask and is picked up by
+// the next chunk / round — capacity never affects the result.
+// ------------------------------------------------------------------------------------------------
+#define XR_BIG_CLEAN 0xFFFFFFFEu
+#define XR_BIG_CA 256          // words per chunk
+#define XR_BIG_CN 1024         // nodes per chunk
+#define XR_BIG_CE 512          // (node, distance) pairs per expansion wave
+#define XR_BIG_MAXG 1024       // groups (1024 nodes each): regions up to 1 M nodes
+
+__device__ __forceinline__ uint32_t xr_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xr_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const int e, const int a, char* smem) {
+    __shared__ int s_ap_f[XR_MAX_AP_PER_NET];
+    __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
+    __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
+    __shared__ uint32_t s_min[3], s_bst[3];
+    __shared__ unsigned long long s_tkey;
+    __shared__ int s_hb[6];
+    __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
+    __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
+    __shared__ int s_nG, s_nA, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    if (!xr_step_prologue(b, e, a)) return;
+
+    XR_T0();
+    const XrRegionDev R = b.regions[b.env_region[e]];
+    const int X = R.X, Y = R.Y, Z = R.Z, N = R.N;
+    const int YZ = Y * Z;
+    const uint32_t ldir = R.ldir_mask;
+    const int mw = (N + 31) >> 5;
+    const int ng = (mw + 31) >> 5;
+    const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
+    int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
+    const int64_t mwg = (int64_t)(b.n_max >> 5) + 1;
+    uint32_t* __restrict__ fieldg = b.dg_field + (int64_t)e * b.n_max;
+    uint32_t* __restrict__ openg = b.dg_masks + (int64_t)e * 2 * mwg;
+    uint32_t* __restrict__ wming = openg + mwg;
+    uint32_t* __restrict__ touchg = b.dg_touch + (int64_t)e * b.n_max;
+    uint32_t* __restrict__ pathg = b.dg_path + (int64_t)e * b.n_max;          // first half: path of the current trace
+    const int defer_cap = b.n_max >> 1;
+    uint32_t* __restrict__ deferl = pathg + defer_cap;                        // second half: deferred nodes
+
+    // LDS carve: gmin u32[MAXG] | G u16[MAXG] | A u32[CA] | N u32[CN] | E0, E1 uint2[CE] | el4x | el4y
+    uint32_t* s_gmin = reinterpret_cast<uint32_t*>(smem);
+    unsigned short* s_G = reinterpret_cast<unsigned short*>(s_gmin + XR_BIG_MAXG);
+    uint32_t* s_A = reinterpret_cast<uint32_t*>(s_G + XR_BIG_MAXG);
+    uint32_t* s_N = s_A + XR_BIG_CA;
+    uint2* s_E0 = reinterpret_cast<uint2*>(s_N + XR_BIG_CN);
+    uint2* s_E1 = s_E0 + XR_BIG_CE;
+    uint32_t* s_xc = reinterpret_cast<uint32_t*>(s_E1 + XR_BIG_CE);          // coordinate tables, see the LDS form
+    uint32_t* s_yc = s_xc + (b.x_max + 2);
+
+    for (int i = tid; i < ng; i += nthr) s_gmin[i] = XR_DIAL_INF;
+    for (int i = tid; i <= X + 1; i += nthr)
+        s_xc[i] = (uint32_t)(b.coords[R.xs_off + min(max(i - 1, 0), X - 1)] - b.coords[R.xs_off]) << 2;
+    for (int i = tid; i <= Y + 1; i += nthr)
+        s_yc[i] = (uint32_t)(b.coords[R.ys_off + min(max(i - 1, 0), Y - 1)] - b.coords[R.ys_off]) << 2;
+    auto el4x = [&](int i) { return s_xc[i + 1] - s_xc[i]; };
+    auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
+    const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
+    const int nap = ap_hi - ap_lo;
+    if (tid == 0) { s_first_pin = 0x7FFFFFFF; s_npins = 0; s_ntouched = 0; s_ndefer = 0; s_niso = 0; s_src_iso = 0; }
+    __syncthreads();
+    for (int i = tid; i < nap; i += nthr) {
+        const int pin = b.ap_pin[R.ap_off + ap_lo + i];
+        s_ap_f[i] = b.ap_node[R.ap_off + ap_lo + i];
+        s_ap_pin[i] = (short)pin;
+        s_ap_conn[i] = 0;
+        atomicMin(&s_first_pin, pin);
+    }
+    __syncthreads();
+    // flags of a node for THIS net: 0 = blockage, else 1 | held << 1
+    auto node_flags = [&](int f) -> uint32_t {
+        const int nn = node_net[f], ow = owner[f];
+        if (nn == -1) return 0u;
+        return 1u | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
+    };
+    // first touch of a node in this route: remember it for the final reset
+    auto touch = [&](uint32_t f) { const int k = atomicAdd(&s_ntouched, 1); touchg[k] = f; };
+    // a node becomes a source: distance 0, open
+    auto make_source = [&](int f) {
+        const uint32_t old = xr_ld(&fieldg[f]);
+        if (old == XR_BIG_CLEAN) touch((uint32_t)f);
+        xr_st(&fieldg[f], old == XR_BIG_CLEAN ? node_flags(f) : (old & 3u));
+        atomicOr(&openg[f >> 5], 1u << (f & 31));
+        xr_st(&wming[f >> 5], 0u);
+        s_gmin[f >> 10] = 0u;
+    };
+    for (int i = tid; i < nap; i += nthr) {
+        const short pin = s_ap_pin[i];
+        bool seen = false;
+        for (int j = 0; j < i; j++) seen |= (s_ap_pin[j] == pin);
+        if (!seen) atomicAdd(&s_npins, 1);
+        unsigned char cflag = seen ? 0 : 0x80;            // bit 7: first access point of its pin (for xr_mark_isolated_pins)
+        if (pin == (short)s_first_pin) { cflag |= 1; make_source(s_ap_f[i]); }
+        s_ap_conn[i] = cflag;
+    }
+    __syncthreads();
+    // pins in closed pockets are never searched for (see xr_mark_isolated_pins)
+    xr_mark_isolated_pins(nap, s_ap_f, s_ap_pin, s_ap_conn, X, Y, Z, ldir, R.magic_yz, R.magic_z,
+                          [&](int f) { return node_net[f] == -1; }, s_pocket, &s_niso, &s_src_iso, s_first_pin);
+    __syncthreads();
+    for (int i = tid; i < nap; i += nthr) s_ap_conn[i] &= 0x7F;
+    const int n_isolated = s_src_iso ? s_npins - 1 : s_niso;       // unreachable pins known up front
+    if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
+    XR_LAP(0);
+
+    const uint32_t via4 = (uint32_t)b.via_cost << 2;
+    const uint32_t pen4 = (uint32_t)b.pen_cost << 2;
+    const uint32_t delta = R.w_min * (uint32_t)b.dial_mult_big;
+    const uint32_t uYZ = (uint32_t)YZ, uZ = (uint32_t)Z;
+    int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK;   // thread 0 only
+    int nrounds = 0;
+    uint64_t h = (tid == 0) ? b.hash[e] : 0;
+    int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
+
+    // put a node (back) into the open structure with distance d
+    auto open_insert = [&](uint32_t f, uint32_t d) {
+        atomicOr(&openg[f >> 5], 1u << (f & 31));
+        atomicMin(&wming[f >> 5], d);
+        atomicMin(&s_gmin[f >> 10], d);
+    };
+
+    for (;;) {
+        // ---- new search ---------------------------------------------------------------------------------
+        if (tid == 0) {
+            s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
+            s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
+            s_tkey = ~0ULL;
+            s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1;
+        }
+        // deferred nodes are looked at again (the list overflowed: every reached node is — re-expanding one is harmless)
+        {
+            const int ndf = s_ndefer;
+            const bool ovf = ndf > defer_cap;
+            const int cnt = ovf ? s_ntouched : ndf;
+            const uint32_t* __restrict__ src = ovf ? touchg : deferl;
+            for (int i = tid; i < cnt; i += nthr) {
+                const uint32_t f = src[i];
+                const uint32_t w = xr_ld(&fieldg[f]);
+                if (w < XR_W_USABLE_END) open_insert(f, w >> 2);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_ndefer = 0;
+        __syncthreads();
+        if (s_remaining <= 0) break;          // uniform
+        // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
+        for (int i = tid; i < nap; i += nthr)
+            if (!s_ap_conn[i]) {
+                uint32_t ax, ar, ay, az;
+                xr_divmod((uint32_t)s_ap_f[i], uYZ, R.magic_yz, ax, ar);
+                xr_divmod(ar, uZ, R.magic_z, ay, az);
+                atomicMin(&s_hb[0], (int)s_xc[ax + 1]); atomicMax(&s_hb[1], (int)s_xc[ax + 1]);
+                atomicMin(&s_hb[2], (int)s_yc[ay + 1]); atomicMax(&s_hb[3], (int)s_yc[ay + 1]);
+                atomicMin(&s_hb[4], (int)az); atomicMax(&s_hb[5], (int)az);
+            }
+        __syncthreads();
+        const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
+        auto heur = [&](int x, int y, int z) -> uint32_t {
+            const int xc = (int)s_xc[x + 1], yc = (int)s_yc[y + 1];
+            const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
+            const int hz = max(0, max(hb4 - z, z - hb5));
+            return ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
+        };
+        int cur = 0;
+        for (;;) {
+            const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
+            const uint32_t m = s_min[cur], best = s_bst[cur];
+            if (m == XR_DIAL_INF || m > best) break;                 // uniform
+            const uint32_t hi = m + delta;
+            uint32_t lmin = XR_DIAL_INF;
+            if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; s_nG = 0; }
+            for (int i = tid; i < nap; i += nthr)
+                if (!s_ap_conn[i]) { const uint32_t w = xr_ld(&fieldg[s_ap_f[i]]); if (w < XR_W_USABLE_END) atomicMin(&s_bst[nx1], w >> 2); }
+            __syncthreads();
+            // ---- A: active groups ------------------------------------------------------------------
+            for (int g = tid; g < ng; g += nthr) {
+                const uint32_t gm = s_gmin[g];
+                if (gm < hi) { s_gmin[g] = XR_DIAL_INF; s_G[atomicAdd(&s_nG, 1)] = (unsigned short)g; }
+                else lmin = gm < lmin ? gm : lmin;
+            }
+            __syncthreads();
+            const int nG = s_nG;
+            // chunks of the active groups: 8 groups (= 256 words = one A list) at a time
+            for (int g0 = 0; g0 < nG; g0 += XR_BIG_CA / 32) {
+                if (tid == 0) { s_nA = 0; s_nN = 0; s_nE[0] = 0; s_nE[1] = 0; }
+                __syncthreads();
+                // ---- A2: active words of these groups --------------------------------------------------
+                for (int i = tid; i < XR_BIG_CA; i += nthr) {
+                    const int gi = g0 + (i >> 5);
+                    if (gi < nG) {
+                        const int g = s_G[gi];
+                        const int wd = (g << 5) + (i & 31);
+                        if (wd < mw) {
+                            const uint32_t wm = xr_ld(&wming[wd]);
+                            // active: the cached minimum is reset HERE — the barrier below orders the reset before any lane takes
+                            // the bits (stage B), so a concurrent insertion is either seen by stage C or keeps its own minimum
+                            if (wm < hi) { s_A[atomicAdd(&s_nA, 1)] = (uint32_t)wd; xr_st(&wming[wd], XR_DIAL_INF); }
+                            else if (wm != XR_DIAL_INF) { atomicMin(&s_gmin[g], wm); lmin = wm < lmin ? wm : lmin; }
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- B: take the open bits of the active words -> node list --------------------------------
+                const int nA = s_nA;
+                for (int i = tid; i < nA; i += nthr) {
+                    const uint32_t wd = s_A[i];
+                    uint32_t bits = atomicExch(&openg[wd], 0u);
+                    const int cnt = __popc(bits);
+                    if (cnt) {
+                        const int pos = atomicAdd(&s_nN, cnt);
+                        if (pos + cnt <= XR_BIG_CN) {
+                            int k = pos;
+                            while (bits) { s_N[k++] = (wd << 5) + (uint32_t)(__ffs((int)bits) - 1); bits &= bits - 1; }
+                        } else {                                        // no room in this chunk: back into the mask, seen again next round
+                            atomicAdd(&s_nN, -cnt);
+                            atomicOr(&openg[wd], bits);
+                            atomicMin(&wming[wd], m);
+                            atomicMin(&s_gmin[wd >> 5], m);
+                            lmin = m < lmin ? m : lmin;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- C: classify ---------------------------------------------------------------------
+                const int nN = min(s_nN, XR_BIG_CN);
+                for (int i = tid; i < nN; i += nthr) {
+                    const uint32_t f = s_N[i];
+                    const uint32_t w = xr_ld(&fieldg[f]);
+                    uint32_t cx, cr, cy, cz;
+                    xr_divmod(f, uYZ, R.magic_yz, cx, cr);
+                    xr_divmod(cr, uZ, R.magic_z, cy, cz);
+                    const uint32_t d = (w >> 2) + heur((int)cx, (int)cy, (int)cz);          // the key f = d + h
+                    bool keep = d >= hi;
+                    if (!keep) {
+                        const int pos = atomicAdd(&s_nE[0], 1);
+                        if (pos < XR_BIG_CE) s_E0[pos] = make_uint2(f, w & ~3u);
+                        else keep = true;                               // no room: stays open
+                    }
+                    if (keep) { open_insert(f, d); lmin = d < lmin ? d : lmin; }
+                }
+                __syncthreads();
+                // ---- D: relax, one lane per (node, direction); run ahead inside the bucket -----------------------
+                int eb = 0;
+                for (;;) {
+                    const int nE = min(s_nE[eb], XR_BIG_CE);
+                    if (nE == 0) break;                                  // uniform
+                    uint2* Ecur = eb ? s_E1 : s_E0;
+                    uint2* Enxt = eb ? s_E0 : s_E1;
+                    for (int it = tid; it < 4 * nE; it += nthr) {
+                        const uint2 en = Ecur[it >> 2];
+                        const int dir = it & 3;
+                        const uint32_t f = en.x, d4 = en.y;
+                        uint32_t x, r, y, z;
+                        xr_divmod(f, uYZ, R.magic_yz, x, r);
+                        xr_divmod(r, uZ, R.magic_z, y, z);
+                        const bool vert = (ldir >> z) & 1u;
+                        int nf = -1;
+                        int nx = (int)x, ny = (int)y, nz = (int)z;
+                        uint32_t len4 = via4;
+                        if (dir == 0) { nf = vert ? ((int)y + 1 < Y ? (int)f + Z : -1) : ((int)x + 1 < X ? (int)f + YZ : -1); len4 = vert ? el4y(y + 1) : el4x(x + 1); if (vert) ny++; else nx++; }
+                        else if (dir == 1) { nf = vert ? (y > 0 ? (int)f - Z : -1) : (x > 0 ? (int)f - YZ : -1); len4 = vert ? el4y(y) : el4x(x); if (vert) ny--; else nx--; }
+                        else if (dir == 2) { nf = ((int)z + 1 < Z) ? (int)f + 1 : -1; nz++; }
+                        else { nf = (z > 0) ? (int)f - 1 : -1; nz--; }
+                        if (nf < 0) continue;
+                        uint32_t wn = xr_ld(&fieldg[nf]);
+                        uint32_t fl;
+                        if (wn == XR_BIG_CLEAN) { fl = node_flags(nf); if (fl == 0u) continue; }     // first touch: derive the flags
+                        else fl = wn & 3u;
+                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u);
+                        if (cand4 >= XR_W_USABLE_END) continue;
+                        const uint32_t cw = cand4 | fl;
+                        if (cw >= wn) continue;
+                        const uint32_t key = (cand4 >> 2) + heur(nx, ny, nz);        // f = d + h
+                        if (key > best) {                              // bound pruning: f is looked at again by the next search
+                            const int k = atomicAdd(&s_ndefer, 1);
+                            if (k < defer_cap) deferl[k] = f;
+                            continue;
+                        }
+                        const uint32_t old = atomicMin(&fieldg[nf], cw);
+                        if (old == XR_BIG_CLEAN) touch((uint32_t)nf);
+                        if (cw < old) {
+                            bool chained = false;
+                            if (key < hi) {                             // lowered INTO the bucket: expand it in the next D pass
+                                const int pos = atomicAdd(&s_nE[eb ^ 1], 1);
+                                if (pos < XR_BIG_CE) { Enxt[pos] = make_uint2((uint32_t)nf, cand4); chained = true; }
+                            }
+                            if (!chained) { open_insert((uint32_t)nf, key); lmin = key < lmin ? key : lmin; }
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) s_nE[eb] = 0;
+                    eb ^= 1;
+                    __syncthreads();
+                }
+            }
+            lmin = xr_wave_min_u32(lmin);
+            if ((tid & 63) == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
+            nrounds++;
+#ifdef XR_PHASE_TIMING
+            if (tid == XR_TIMING_TID) _ph[7] += 1;
+#endif
+            __syncthreads();
+            cur = nx1;
+        }
+        XR_LAP(2);
+
+        // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
+        if (tid < 64) {
+            for (int i = tid; i < nap; i += 64) {
+                if (s_ap_conn[i]) continue;
+                const uint32_t w = xr_ld(&fieldg[s_ap_f[i]]);
+                if (w >= XR_W_USABLE_END) continue;                    // CLEAN: never reached
+                atomicMin(&s_tkey, ((unsigned long long)(w >> 2) << 32) | (unsigned)s_ap_f[i]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long bestk = s_tkey;
+            int best_i = -1;
+            if (bestk != ~0ULL) {
+                const int bf = (int)(bestk & 0xFFFFFFFFu);
+                for (int i0 = 0; i0 < nap && best_i < 0; i0 += 64) {
+                    const int i = i0 + tid;
+                    const unsigned long long mm = __ballot(i < nap && s_ap_f[i] == bf);
+                    if (mm) best_i = i0 + __ffsll((long long)mm) - 1;
+                }
+            }
+            if (tid == 0) { s_target_i = best_i; s_plen = 0; }
+
+            if (best_i < 0) {
+                if (tid == 0) {
+                    d_vio += s_remaining;
+                    status |= XR_ENV_UNREACHABLE;
+                    s_remaining = 0;
+                }
+            } else {
+                // back-trace (see the LDS form); a CLEAN neighbour was never reached and cannot be a predecessor
+                int v = __builtin_amdgcn_readfirstlane(s_ap_f[best_i]);
+                uint32_t vw = xr_ld(&fieldg[v]);
+                uint32_t ux, ur, uy, uz;
+                xr_divmod((uint32_t)v, uYZ, R.magic_yz, ux, ur);
+                xr_divmod(ur, uZ, R.magic_z, uy, uz);
+                int x = (int)ux, y = (int)uy, z = (int)uz;
+                int np = 0;
+                while ((vw >> 2) > 0) {
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);
+                    const bool vert = (ldir >> z) & 1u;
+                    int u = -1;
+                    uint32_t len4 = 0;
+                    switch (tid) {
+                    case 0: if (!vert && x + 1 < X) { u = v + YZ; len4 = el4x(x + 1); } break;   // E
+                    case 1: if (vert && y > 0)      { u = v - Z;  len4 = el4y(y); } break;       // S
+                    case 2: if (!vert && x > 0)     { u = v - YZ; len4 = el4x(x); } break;       // W
+                    case 3: if (vert && y + 1 < Y)  { u = v + Z;  len4 = el4y(y + 1); } break;   // N
+                    case 4: if (z + 1 < Z)          { u = v + 1;  len4 = via4; } break;           // U
+                    case 5: if (z > 0)              { u = v - 1;  len4 = via4; } break;           // D
+                    default: break;
+                    }
+                    uint32_t uw = XR_W_BLOCK;
+                    bool ok = false;
+                    if (u >= 0) {
+                        uw = xr_ld(&fieldg[u]);
+                        ok = (uw - 1u) < (XR_W_USABLE_END - 1u) && (uw & ~3u) + len4 == need4;
+                    }
+                    const unsigned long long mm = __ballot(ok);
+                    if (mm == 0) { if (tid == 0) status |= 0x100; break; }
+                    const int src = __ffsll((long long)mm) - 1;
+                    const int pu = __builtin_amdgcn_readlane(u, src);
+                    const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw, src);
+                    const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len4, src);
+                    if (tid == 0) {
+                        if (vw & 2u) d_vio += 1;
+                        pathg[np] = (uint32_t)v;
+                        if (plen < b.path_cap) path[plen] = v;
+                        plen++;
+                        fnv_mix(h, (uint32_t)v);
+                        if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
+                    }
+                    np++;
+                    x += (src == 0) - (src == 2);
+                    y += (src == 3) - (src == 1);
+                    z += (src == 4) - (src == 5);
+                    v = pu; vw = puw;
+                }
+                if (tid == 0 && (status & 0x100)) {
+                    s_remaining = 0;
+                } else if (tid == 0) {
+                    if (owner[v] == 0) {
+                        owner[v] = (int16_t)a;
+                        if (plen < b.path_cap) path[plen] = v;
+                        plen++;
+                        fnv_mix(h, (uint32_t)v);
+                    }
+                    s_remaining -= 1;
+                    s_plen = np;
+                }
+            }
+        }
+        __syncthreads();
+        XR_LAP(3);
+        {
+            const int ti = s_target_i;
+            if (ti >= 0) {
+                const short pin = s_ap_pin[ti];
+                for (int i = tid; i < nap; i += nthr)
+                    if (s_ap_pin[i] == pin) { s_ap_conn[i] = 1; make_source(s_ap_f[i]); }
+                const int np = s_plen;
+                for (int i = tid; i < np; i += nthr) {
+                    const int f = (int)pathg[i];
+                    make_source(f);
+                    if (owner[f] == 0) owner[f] = (int16_t)a;
+                }
+            }
+        }
+        XR_LAP(4);
+    }
+
+    // ---- leave the scratch CLEAN: reset exactly what this route touched -------------------------------------
+    {
+        const int nt = s_ntouched;
+        for (int i = tid; i < nt; i += nthr) {
+            const uint32_t f = touchg[i];
+            xr_st(&fieldg[f], XR_BIG_CLEAN);
+            xr_st(&openg[f >> 5], 0u);
+            xr_st(&wming[f >> 5], XR_DIAL_INF);
+        }
+    }
+    if (tid == 0) {
+        if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
+        xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h);
+    }
     XR_LAP(5);
     XR_TDUMP();
 }

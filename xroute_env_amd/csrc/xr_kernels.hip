@@ -824,8 +824,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int e, const int a, char* smem) {
     if constexpr (ZCH == XR_ZCH_DIAL) {
-        static_assert(LDS_DIST, "the HBM-scratch form of the frontier router is xr_dial_route_env_big");
-        xr_dial_route_env(b, e, a, smem);
+        if constexpr (LDS_DIST) xr_dial_route_env(b, e, a, smem);
+        else xr_dial_route_env_big(b, e, a, smem);
     } else {
         xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
     }
@@ -1613,10 +1613,13 @@ hipError_t xr_launch_reset(const XrBatchDev* b, const uint8_t* mask, int rotate,
 }
 
 hipError_t xr_route_set_max_lds(size_t bytes) {
-    const void* dfns[3] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>),
+    const void* dfns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>),
                            reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL>),
-                           reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL>)};
-    for (int i = 0; i < 3; i++) {
+                           reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL>),
+                           reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL>),
+                           reinterpret_cast<const void*>(&xr_step_queue_kernel<false, XR_ZCH_DIAL>),
+                           reinterpret_cast<const void*>(&xr_order_kernel<false, XR_ZCH_DIAL>)};
+    for (int i = 0; i < 6; i++) {
         hipError_t e = hipFuncSetAttribute(dfns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
@@ -1645,7 +1648,8 @@ hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_
                            int threads, hipStream_t st) {
     const dim3 g(b->env_count > 0 ? b->env_count : b->n_envs), t(threads);
     if (zch == XR_ZCH_DIAL) {
-        hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+        if (lds_dist) hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_route_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
     } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_route_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
         else if (zch == 12) hipLaunchKernelGGL((xr_route_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
@@ -1662,7 +1666,8 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
                            size_t lds_bytes, int threads, hipStream_t st) {
     const dim3 g(b->n_envs), t(threads);
     if (zch == XR_ZCH_DIAL) {
-        hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        if (lds_dist) hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else hipLaunchKernelGGL((xr_order_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_order_kernel<true, 9>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else if (zch == 12) hipLaunchKernelGGL((xr_order_kernel<true, 12>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
@@ -1677,7 +1682,8 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
 
 // resident workgroups per CU of the step kernel as the runtime would place it, and its static LDS
 hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threads, int* wg_per_cu, size_t* static_lds) {
-    const void* fn = zch == XR_ZCH_DIAL ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>)
+    const void* fn = zch == XR_ZCH_DIAL ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>)
+                                                    : reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL>))
                      : lds_dist ? (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 9>)
                                  : zch == 12 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 12>)
                                              : reinterpret_cast<const void*>(&xr_route_kernel<true, 0>))
@@ -1695,7 +1701,8 @@ hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int
                                 int threads, int blocks, hipStream_t st) {
     const dim3 g(blocks), t(threads);
     if (zch == XR_ZCH_DIAL) {
-        hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+        if (lds_dist) hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_step_queue_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
     } else if (lds_dist) {
         if (zch == 9) hipLaunchKernelGGL((xr_step_queue_kernel<true, 9>), g, t, lds_bytes, st, *b, actions);
         else if (zch == 12) hipLaunchKernelGGL((xr_step_queue_kernel<true, 12>), g, t, lds_bytes, st, *b, actions);
