@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--dial-mult", type=int, default=0)
     ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0 default (queue form where it applies), 1 fused launch, 2 split, 3 queue")
     ap.add_argument("--writer-blocks", type=int, default=0)
+    ap.add_argument("--helper-blocks", type=int, default=0, help="xr_config.obs_helper_blocks (0 none = default)")
+    ap.add_argument("--quota", type=int, default=0, help="xr_config.obs_split_permille (queue form: units per route, per mille of the average)")
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
                          "synthetic generator; NOT the headline workload")
@@ -272,7 +274,7 @@ def main():
 
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
                         obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
-                        dial_mult=args.dial_mult)
+                        dial_mult=args.dial_mult, obs_helper_blocks=args.helper_blocks, obs_split_permille=args.quota)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()

@@ -107,11 +107,13 @@ typedef struct xr_config {
     int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = default (XR_ROUTER_DIAL where the
                                  region fits, else XR_ROUTER_SWEEP), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
                                  worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
-    int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 4) */
+    int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 8) */
     int32_t stream_per_region; /* 1: "one region per stream" (north_star's first partition): xr_batch_step / _step_observe (fused
                                   form) / _step_compact launch ONE single-workgroup kernel per env slot, round-robin over a pool of
                                   internal HIP streams, joined to the caller's stream by events.  For batches of <= 64 slots only
                                   (XR_ERR_RANGE above); measured against the default one-launch form in DESIGN.md */
+    int32_t obs_helper_blocks; /* XR_OBS_QUEUE: LDS-free helper-writer workgroups launched beside the persistent step kernel on an
+                                  internal stream, draining the same unit queue (0 = none, the default: measured no faster) */
     int32_t obs_split_permille; /* XR_OBS_SPLIT: per mille of every env's net planes (its highest-ranked nets) that the
                                    writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all).
                                    XR_OBS_QUEUE: units a workgroup writes after each route task, per mille of the average

@@ -6,6 +6,12 @@ import sys
 
 
 def main(path):
+    import glob, os
+    if os.path.isdir(path):                     # a rocprofv3 output directory: take its database
+        found = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
+        if not found:
+            raise SystemExit(f"no .db under {path}")
+        path = found[-1]
     db = sqlite3.connect(path)
     c = db.cursor()
     rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "

@@ -42,7 +42,7 @@ class RegionBatch:
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
                  obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0,
-                 stream_per_region: bool = False):
+                 stream_per_region: bool = False, obs_helper_blocks: int = 0):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -61,6 +61,7 @@ class RegionBatch:
         cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
         cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
         cfg.dial_mult = int(dial_mult)
+        cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (-1 default, 0 none)
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg
         self._h = C.c_void_p()

@@ -28,6 +28,7 @@ hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int
 hipError_t xr_launch_random_actions(const XrBatchDev*, int32_t*, uint64_t, hipStream_t);
 hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int, hipStream_t);
 hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
+hipError_t xr_launch_unit_helpers(const XrBatchDev*, int, hipStream_t);
 hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const int32_t*, int, float*, int64_t, int, hipStream_t);
 }
 
@@ -162,6 +163,7 @@ void xr_config_default(xr_config* c) {
     c->router = 0;
     c->dial_mult = 0;
     c->stream_per_region = 0;
+    c->obs_helper_blocks = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -510,7 +512,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.records = b->records.p;
-    d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 4;
+    d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
@@ -640,8 +642,21 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
             b->queue_blocks = std::max(1, per_cu) * b->n_cus;
         }
         const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : b->queue_blocks;
+        // helper writers (aligned planes only): LDS-free workgroups on the internal stream draining the same unit queue;
+        // forked after the plan, joined before the call returns the stream (events, no host wait)
+        const int helpers = d.obs_vec4 == 1 && b->cfg.obs_helper_blocks > 0 ? b->cfg.obs_helper_blocks : 0;
+        const bool use_helpers = helpers > 0 && b->cfg.n_envs >= 64;
+        if (use_helpers) {
+            XR_HIP(hipEventRecord(b->ev_fork, st));
+            XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
+        }
         XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads,
                                     std::min(blocks, 4 * b->cfg.n_envs), st));
+        if (use_helpers) {
+            XR_HIP(xr_launch_unit_helpers(&d, helpers, b->aux_stream));
+            XR_HIP(hipEventRecord(b->ev_join, b->aux_stream));
+            XR_HIP(hipStreamWaitEvent(st, b->ev_join, 0));
+        }
         return XR_OK;
     }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;

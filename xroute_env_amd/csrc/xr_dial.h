@@ -42,6 +42,9 @@
 #pragma once
 
 #define XR_DIAL_INF 0xFFFFFFFFu
+#ifndef XR_DIAL_ASTAR
+#define XR_DIAL_ASTAR 1          // LDS form: bucket keys f = d + h (0: plain Dijkstra order, keys = d) — A/B switch
+#endif
 #ifndef XR_DIAL_CHAIN
 #define XR_DIAL_CHAIN 1
 #endif
@@ -382,6 +385,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
         // h(v): distance to that box — coordinate differences + one via cost per layer (a consistent lower bound)
         auto heur = [&](int x, int y, int z) -> uint32_t {
+            if (!XR_DIAL_ASTAR) return 0u;
             const int xc = (int)s_xc[x + 1], yc = (int)s_yc[y + 1];
             const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
             const int hz = max(0, max(hb4 - z, z - hb5));
@@ -431,9 +435,11 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             if (q[j] < 0) continue;
-                            uint32_t cx, cr, cy, cz;
-                            xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx, cr);
-                            xr_divmod(cr, uZ, R.magic_z, cy, cz);
+                            uint32_t cx = 0, cr, cy = 0, cz = 0;
+                            if (XR_DIAL_ASTAR) {
+                                xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx, cr);
+                                xr_divmod(cr, uZ, R.magic_z, cy, cz);
+                            }
                             const uint32_t key = (w[j] >> 2) + heur((int)cx, (int)cy, (int)cz);
                             if (key >= hi) {
                                 keep |= 1ULL << q[j];

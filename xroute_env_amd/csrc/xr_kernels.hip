@@ -1403,6 +1403,23 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
     __syncthreads();
 }
 
+// Helper writers of the queue form: workgroups WITHOUT LDS that drain the same unit queue (queue[1]) as the persistent step
+// kernel, launched concurrently on an internal stream.  The step kernel's workgroups are capped at 4 per CU by the router's LDS
+// and spend ~45 % of their time routing, so on average only ~2.2 of them per CU are writing — not enough stores in flight for the
+// HBM write ceiling of this pattern (1024 pure writers reach it).  The helpers fill the wave slots the LDS cap leaves free.
+__global__ void __launch_bounds__(256) xr_unit_helper_kernel(XrBatchDev b) {
+    __shared__ int s_u;
+    const int total = (int)b.queue[2];
+    for (;;) {
+        if (threadIdx.x == 0) s_u = (int)atomicAdd(&b.queue[1], 1u);
+        __syncthreads();
+        const int u = s_u;
+        __syncthreads();
+        if (u >= total) break;
+        xr_unit_aligned(b, u);
+    }
+}
+
 __global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = (int)b.queue[2];
@@ -1418,8 +1435,11 @@ __global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
 // odd workgroups start with units so that the launch writes from its first microseconds.  No workgroup ever
 // waits for another one.
 // ------------------------------------------------------------------------------------------------
+#ifndef XR_QUEUE_WAVES_PER_SIMD
+#define XR_QUEUE_WAVES_PER_SIMD 4      // register budget of the persistent step kernel: 4 waves per SIMD = its own 4 workgroups per CU.
+#endif                                 // (6 = <= 80 VGPRs, room for helper-writer waves beside them: measured no faster)
 template <bool LDS_DIST, int ZCH>
-__global__ void xr_step_queue_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+__global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_task;
     const int tid = threadIdx.x;
@@ -1753,6 +1773,11 @@ hipError_t xr_launch_obs(const XrBatchDev* b, float* out, int64_t env_stride, in
             hipLaunchKernelGGL(xr_obs_kernel<1>, dim3(chunks, cnt), dim3(256), lds, st, *b, o, env_stride, lo);
         }
     }
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_unit_helpers(const XrBatchDev* b, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(xr_unit_helper_kernel, dim3(blocks), dim3(256), 0, st, *b);
     return hipGetLastError();
 }
 
