@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--learner", action="store_true",
+                    help="N > 1: BASELINE config 4's learner flow — records + legal bitmasks gathered, the (random net-order) policy runs on "
+                         "rank 0 for ALL envs, actions travel back as one i32 broadcast (default: every rank runs the policy for its own envs)")
     ap.add_argument("--agent", choices=["dqn", "ppo"], default=None,
                     help="agent-attached line (BASELINE configs 3 / 4) INSTEAD of the env-only headline: actions from the batched DQN / PPO "
                          "counterpart (random-init weights of the reference architecture), env in compact-consumer mode")
@@ -303,9 +306,27 @@ def main():
         stagger = (off, pre_seeds)
 
     fused = (obs is not None) and not args.no_fuse
+    learner = args.learner and world > 1 and rec_all is not None
+    if learner:
+        from xroute_env_amd.dist import random_legal_policy, unpack_records
+        Bg_all = rec_all.shape[0]
+        legal_local = torch.empty((B, batch.legal_words), dtype=torch.int64, device=dev)
+        legal_all = torch.empty((Bg_all, batch.legal_words), dtype=torch.int64, device=dev)
+        acts_all = torch.zeros(Bg_all, dtype=torch.int32, device=dev)
+        batch.fetch("record", rec_local)
+        batch.fetch("legal", legal_local)
+        dist.all_gather_into_tensor(rec_all, rec_local)
+        dist.all_gather_into_tensor(legal_all, legal_local)
 
     def one_step(i, ev=None):
-        batch.random_actions(args.seed + rank * 7919 + i, acts)
+        if learner:
+            # rank 0 chooses for every env from the gathered state; one broadcast carries the actions back
+            if rank == 0:
+                acts_all.copy_(random_legal_policy(unpack_records(rec_all), legal_all, args.seed + i))
+            dist.broadcast(acts_all, src=0)
+            acts.copy_(acts_all[first_env:first_env + B] if strong else acts_all[rank * B:(rank + 1) * B])
+        else:
+            batch.random_actions(args.seed + rank * 7919 + i, acts)
         if ev:
             ev[0].record()
         if fused:
@@ -323,6 +344,9 @@ def main():
         batch.fetch("nlegal", nlegal_log[i])
         batch.fetch("record", rec_local)
         if world > 1:
+            if learner:
+                batch.fetch("legal", legal_local)
+                dist.all_gather_into_tensor(legal_all, legal_local)
             if rec_all is not None:
                 gather_records_fixed(rec_local, rec_all)         # RCCL over xGMI: the batched-env gather
             else:
@@ -453,6 +477,7 @@ def main():
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
                                    + (" (one persistent launch after a planning kernel)" if fused and batch.observe_timing()[0] == 3 else " (fused launch)" if fused else "")
                                    + (", RCCL all_gather of per-env results" if world > 1 else "")
+                                   + (" + learner flow (policy on rank 0, i32 action broadcast)" if learner else "")
                                    + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
                        "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}",
                        "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (nst * B * world), 4),
@@ -590,6 +615,7 @@ def config5_leg(args, c5_regions, dev):
     s0 = b5.total_steps()
     sweeps = 0.0
     plen = 0.0
+    touched = 0.0
     for i, (e0, e1) in enumerate(evs):
         b5.random_actions(600 + i, a5)
         e0.record()
@@ -597,20 +623,26 @@ def config5_leg(args, c5_regions, dev):
         e1.record()
         sweeps += float(b5.fetch("sweeps").double().sum().item())
         plen += float(b5.fetch("path_len").double().sum().item())
+        touched += float(b5.fetch("touched").double().sum().item())
     torch.cuda.synchronize(dev)
     ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
     real = (b5.total_steps() - s0) / n_t
     N = float(c5_regions[0].n_nodes)
-    # SURVEY §8(d), HBM-resident maze route: 9·N·S per env-step (S relaxation sweeps) + back-trace 8·L + owner update 2·L,
-    # plus the state load 4·N.  S = the rounds / iterations the router reports (XR_FETCH_SWEEPS): a FULL-sweep algorithm would
-    # move these bytes; this router touches only the nodes near the wavefront, so `touched_bytes_estimate` is what it moves.
-    formula = (4.0 * N * Bc * n_t + 9.0 * N * sweeps + 10.0 * plen) / n_t
-    ent = kernel_entry("xr_route_kernel (BASELINE config 5: 256x256x12)", ms, formula, real, "l2-latency",
-                       f"{Bc} env slots over {len(c5_regions)} distinct regions, K = 32, route-only (compact state); bytes = SURVEY §8(d) formula "
-                       "4·N + 9·N·S + 10·L with S = router rounds: what a full-sweep router would move — the work-efficient router moves far "
-                       "less, so `frac` here is an upper-bound style figure, not HBM utilisation; env_steps_per_s is the figure of merit")
+    # SURVEY §8(d) prices an HBM-resident maze route as FULL sweeps: 4·N state load + 9·N·S + 10·L per env-step.  The frontier
+    # router does no sweep at all: it creates the field word of a node when a neighbour first relaxes it and resets exactly
+    # those words afterwards.  Its algorithmic bytes per touched node: node_net + owner read (4), field word created, read for
+    # classification, lowered by an atomic (read + write) and reset (4 x 4 + 4) = 24 B; per path node 10 B as in §8(d).
+    formula_8d = (4.0 * N * Bc * n_t + 9.0 * N * sweeps + 10.0 * plen) / n_t
+    nbytes = (24.0 * touched + 10.0 * plen) / n_t if touched > 0 else formula_8d
+    ent = kernel_entry("xr_route_kernel (BASELINE config 5: 256x256x12)", ms, nbytes, real, "l2-latency",
+                       f"{Bc} env slots over {len(c5_regions)} distinct regions, K = 32, route-only (compact state). Bound by the latency of "
+                       "dependent L2 atomics, not by bandwidth: bytes = 24 B per node the route touched + 10 B per path node (the frontier "
+                       "router's algorithmic bytes); `bytes_8d_full_sweep_formula` = what SURVEY §8(d)'s full-sweep form (4·N + 9·N·S + 10·L, "
+                       "S = rounds) would move for the same routes; env_steps_per_s is the figure of merit")
+    ent["bytes_8d_full_sweep_formula"] = formula_8d
     ent["mean_rounds"] = sweeps / (n_t * Bc)
     ent["mean_path_nodes"] = plen / (n_t * Bc)
+    ent["mean_touched_nodes"] = touched / (n_t * Bc)
     ent["envs"] = Bc
     b5.close()
     return ent

@@ -149,6 +149,8 @@ typedef struct xr_region_desc {
 #define XR_FETCH_SWEEPS   13   /* int32 [B]     relaxation sweeps used by the last step */
 #define XR_FETCH_RECORD   15   /* xr_step_record[B]  everything a caller needs after a step or a reset, one 48-byte
                                                  record per env (written by the kernels themselves: one copy, one sync) */
+#define XR_FETCH_TOUCHED  16   /* int32 [B]     nodes whose field word the last route created (HBM-scratch form of the frontier
+                                                 router: the work it really did; 0 for the other forms) */
 #define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
                                                  built with -DXR_PHASE_TIMING) */
 

@@ -91,6 +91,14 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["global_envs"] == 256 and d["config"]["envs_per_gpu"] == 128
+    # BASELINE config 4's learner flow: gather records + legal sets, policy on rank 0, i32 action broadcast
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--global-envs", "256", "--learner"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert "learner flow" in d["config"]["workload"] and d["value"] > 0 and d["config"]["slots_stepped_per_batch_step"] > 0.5
 
 
 def test_bench_value_is_stationary_in_warmup():

@@ -19,7 +19,7 @@ XR_OWNER_FOREIGN = 0x7FFF
 
 (XR_FETCH_CUM, XR_FETCH_DELTA, XR_FETCH_REWARD, XR_FETCH_DONE, XR_FETCH_NLEGAL, XR_FETCH_STATUS,
  XR_FETCH_LEGAL, XR_FETCH_PATH_LEN, XR_FETCH_PATH, XR_FETCH_OWNER, XR_FETCH_HASH, XR_FETCH_REGION,
- XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD) = range(16)
+ XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD, XR_FETCH_TOUCHED) = range(17)
 
 # every symbol include/xroute_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [

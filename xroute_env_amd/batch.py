@@ -262,6 +262,7 @@ class RegionBatch:
         "steps": (_lib.XR_FETCH_STEPS, torch.int64, lambda s: (1,)),
         "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
         "phases": (_lib.XR_FETCH_PHASES, torch.int64, lambda s: (s.n_envs, 8)),
+        "touched": (_lib.XR_FETCH_TOUCHED, torch.int32, lambda s: (s.n_envs,)),
         "record": (_lib.XR_FETCH_RECORD, torch.uint8, lambda s: (s.n_envs, _lib.RECORD_BYTES)),
     }
 

@@ -105,7 +105,7 @@ struct xr_batch {
     DevBuf<int16_t> ap_pin;
     DevBuf<uint64_t> legal0;
     // envs
-    DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps;
+    DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps, touched;
     DevBuf<int16_t> owner;
     DevBuf<uint64_t> legal, hash;
     DevBuf<double> reward;
@@ -443,6 +443,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->path, (size_t)B * b->path_cap);
     XR_ALLOC(b->path_len, B);
     XR_ALLOC(b->sweeps, B);
+    XR_ALLOC(b->touched, B);
     XR_ALLOC(b->owner, (size_t)B * b->n_max);
     XR_ALLOC(b->legal, (size_t)B * legal_words);
     XR_ALLOC(b->hash, B);
@@ -486,6 +487,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemsetAsync(b->total_steps.p, 0, sizeof(unsigned long long), st));
     XR_HIP(hipMemsetAsync(b->phase_cycles.p, 0, (size_t)B * 8 * sizeof(long long), st));
     XR_HIP(hipMemsetAsync(b->nlegal.p, 0, (size_t)B * sizeof(int32_t), st));
+    XR_HIP(hipMemsetAsync(b->touched.p, 0, (size_t)B * sizeof(int32_t), st));
     XR_HIP(hipMemsetAsync(b->records.p, 0, (size_t)B * sizeof(XrStepRecord), st));
     XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
     XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
@@ -511,7 +513,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
-    d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.records = b->records.p;
+    d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.touched = b->touched.p; d.records = b->records.p;
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
@@ -791,6 +793,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_TOUCHED: src = b->touched.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;
     case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;
     default: return fail(XR_ERR_INVALID, "xr_batch_fetch: unknown selector %d", what);

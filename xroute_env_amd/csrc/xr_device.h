@@ -83,6 +83,7 @@ struct XrBatchDev {
     int64_t* env_steps;
     unsigned long long* total_steps;
     int32_t* sweeps;
+    int32_t* touched;        // [B] nodes whose field word the last route created (HBM-scratch form of the frontier router; else 0)
     XrStepRecord* records;   // [B]
     uint32_t* dist_scratch;  // [B][n_max] only when the distance field does not fit LDS, else null
     uint8_t* cls_scratch;

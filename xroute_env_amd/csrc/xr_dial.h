@@ -106,7 +106,7 @@ __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int 
 
 // Game.step bookkeeping (reference baseline/baseline_utils.py:412, :426-438) + reward, by thread 0
 __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int e, const int a, int d_vio, int d_wl, int d_via,
-                                                 int plen, int status, int nrounds, uint64_t h) {
+                                                 int plen, int status, int nrounds, uint64_t h, int ntouched = 0) {
     if (plen > b.path_cap) status |= XR_ENV_PATH_TRUNC;
     b.cum[3 * e + 0] += d_vio; b.cum[3 * e + 1] += d_wl; b.cum[3 * e + 2] += d_via;
     b.delta[3 * e + 0] = d_vio; b.delta[3 * e + 1] = d_wl; b.delta[3 * e + 2] = d_via;
@@ -120,6 +120,7 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
     b.status[e] = status;
     b.path_len[e] = plen;
     b.sweeps[e] = nrounds;
+    b.touched[e] = ntouched;
     fnv_mix(h, (uint32_t)a);
     fnv_mix(h, (uint32_t)d_vio); fnv_mix(h, (uint32_t)d_wl); fnv_mix(h, (uint32_t)d_via);
     fnv_mix(h, (uint32_t)plen);
@@ -1121,7 +1122,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     }
     if (tid == 0) {
         if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
-        xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h);
+        xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h, s_ntouched);
     }
     XR_LAP(5);
     XR_TDUMP();

@@ -113,6 +113,7 @@ __device__ void xr_env_reset(const XrBatchDev& b, int e, int rotate, int extra_s
         b.status[e] = extra_status;
         b.path_len[e] = 0;
         b.sweeps[e] = 0;
+        b.touched[e] = 0;
         xr_publish_record(b, e);
     }
 }
