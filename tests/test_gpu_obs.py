@@ -267,3 +267,45 @@ def test_compact_mode_logits_equal_full_observation_logits():
                                                    planes_fn=batch.net_planes)
         assert torch.equal(e1, e2) and torch.equal(id1, id2)
         assert torch.allclose(lg_full, lg_cmp, atol=2e-3, rtol=0)
+
+
+def test_helper_writers_and_stream_per_region_are_byte_identical():
+    """Launch-structure options never change a byte: the queue form with LDS-free helper writers draining the same unit queue
+    (obs_helper_blocks), and the north star's one-region-per-stream partition (stream_per_region: one single-workgroup launch
+    per slot on a pool of HIP streams), against the default launch — observations, records, hash chains, 12 steps with
+    auto-reset."""
+    import torch
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+    regions = config_regions(3, 64)                     # helpers need >= 64 slots, stream_per_region <= 64
+    variants = {"default": {}, "helpers": {"obs_helper_blocks": 96}, "streams": {"stream_per_region": True},
+                "streams_fused": {"stream_per_region": True, "obs_mode": 1}}
+    out = {}
+    for name, kw in variants.items():
+        batch = RegionBatch(regions, device="cuda:0", auto_reset=True, **kw)
+        batch.reset(rotate=True)
+        obs = batch.alloc_observation()
+        obs.fill_(-7.0)
+        acts = torch.empty(len(regions), dtype=torch.int32, device="cuda:0")
+        recs = []
+        for it in range(12):
+            batch.random_actions(100 + it, acts)
+            batch.step(acts, obs)
+            recs.append(batch.fetch("record").cpu().clone())
+        nl = batch.fetch("nlegal").cpu().numpy()
+        valid = [obs[e, : (2 + 7 * int(nl[e])) * regions[e].n_nodes].cpu().clone() for e in range(len(regions))]
+        out[name] = (recs, valid, batch.fetch("hash").cpu().clone(), batch.observe_timing()[0])
+        # route-only and compact steps take the same launch structure
+        batch.random_actions(999, acts)
+        batch.step(acts)
+        out[name] += (batch.fetch("record").cpu().clone(),)
+    assert out["default"][3] == 3 and out["helpers"][3] == 3 and out["streams"][3] == 1      # queue / queue + helpers / fused per slot
+    for name in ("helpers", "streams", "streams_fused"):
+        for a, b in zip(out["default"][0], out[name][0]):
+            assert torch.equal(a, b), name
+        for a, b in zip(out["default"][1], out[name][1]):
+            assert torch.equal(a, b), name
+        assert torch.equal(out["default"][2], out[name][2]) and torch.equal(out["default"][4], out[name][4]), name
+    from xroute_env_amd._lib import XRouteError
+    with pytest.raises(XRouteError):
+        RegionBatch(config_regions(3, 65), device="cuda:0", stream_per_region=True)          # more than 64 slots
