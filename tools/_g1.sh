@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_obs.py -x -q -m gpu -k "helper_writers" 2>&1 | tail -8
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python tools/config5_probe.py 1024 64 2>&1 | tail -2

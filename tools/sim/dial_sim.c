@@ -55,7 +55,24 @@ int dial_route(int X, int Y, int Z, const int32_t* xs, const int32_t* ys, const 
             if (ys[y] < by0) by0 = ys[y]; if (ys[y] > by1) by1 = ys[y];
             if (z < bz0) bz0 = z; if (z > bz1) bz1 = z;
         }
-#define HEUR(f) (g_astar ? (uint32_t)(({ int _x = (f) / YZ, _y = ((f) / Z) % Y, _z = (f) % Z; \
+        /* per-pin boxes (g_astar == 2): h = min over the unconnected pins of the distance to the pin's own box */
+        int npb = 0; int pbx0[64], pbx1[64], pby0[64], pby1[64], pbz0[64], pbz1[64], pbpin[64];
+        for (int i = 0; i < nap; i++) if (!conn[i]) {
+            int k = -1; for (int q = 0; q < npb; q++) if (pbpin[q] == ap_pin[i]) k = q;
+            if (k < 0 && npb < 64) { k = npb++; pbpin[k] = ap_pin[i]; pbx0[k] = pby0[k] = pbz0[k] = 1 << 30; pbx1[k] = pby1[k] = -(1 << 30); pbz1[k] = -1; }
+            if (k < 0) continue;
+            int f = ap_node[i], x = f / YZ, y = (f / Z) % Y, z = f % Z;
+            if (xs[x] < pbx0[k]) pbx0[k] = xs[x]; if (xs[x] > pbx1[k]) pbx1[k] = xs[x];
+            if (ys[y] < pby0[k]) pby0[k] = ys[y]; if (ys[y] > pby1[k]) pby1[k] = ys[y];
+            if (z < pbz0[k]) pbz0[k] = z; if (z > pbz1[k]) pbz1[k] = z;
+        }
+#define HEUR2(f) ({ int _x = (f) / YZ, _y = ((f) / Z) % Y, _z = (f) % Z; uint32_t _best = 0xFFFFFFFFu; \
+            for (int _q = 0; _q < npb; _q++) { \
+            int _hx = xs[_x] < pbx0[_q] ? pbx0[_q] - xs[_x] : (xs[_x] > pbx1[_q] ? xs[_x] - pbx1[_q] : 0); \
+            int _hy = ys[_y] < pby0[_q] ? pby0[_q] - ys[_y] : (ys[_y] > pby1[_q] ? ys[_y] - pby1[_q] : 0); \
+            int _hz = _z < pbz0[_q] ? pbz0[_q] - _z : (_z > pbz1[_q] ? _z - pbz1[_q] : 0); \
+            uint32_t _h = _hx + _hy + _hz * via_cost; if (_h < _best) _best = _h; } _best == 0xFFFFFFFFu ? 0u : _best; })
+#define HEUR(f) (g_astar == 2 ? HEUR2(f) : g_astar ? (uint32_t)(({ int _x = (f) / YZ, _y = ((f) / Z) % Y, _z = (f) % Z; \
             int _hx = xs[_x] < bx0 ? bx0 - xs[_x] : (xs[_x] > bx1 ? xs[_x] - bx1 : 0); \
             int _hy = ys[_y] < by0 ? by0 - ys[_y] : (ys[_y] > by1 ? ys[_y] - by1 : 0); \
             int _hz = _z < bz0 ? bz0 - _z : (_z > bz1 ? _z - bz1 : 0); _hx + _hy + _hz * via_cost; })) : 0u)

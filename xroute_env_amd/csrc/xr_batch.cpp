@@ -389,7 +389,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         const size_t mw_max = (size_t)b->n_max / 32 + 1;
         const size_t dial_lds = (size_t)b->n_max * 4 + 4 * mw_max * 4 + el_bytes + 16;
         // HBM-scratch form (regions too large for LDS, or force_scratch_field): groups of 1024 nodes must fit the LDS group table
-        const size_t big_lds = 1024 * 4 + 1024 * 2 + 256 * 4 + 1024 * 4 + 2 * 512 * 8 + el_bytes + 16;
+        const size_t big_lds = (size_t)XR_BIG_MAXG * 6 + (size_t)XR_BIG_CA * 4 + (size_t)XR_BIG_CN * 4 + 2 * (size_t)XR_BIG_CE * 8 + el_bytes + 16;
         const bool big_ok = ((size_t)b->n_max / 1024 + 2) <= 1024;
         b->dial_big = false;
         if (b->cfg.router != XR_ROUTER_SWEEP && !b->cfg.force_scratch_field && dial_lds + kLdsStatic <= kLdsLimit) {
@@ -402,7 +402,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             b->lds_dist = false;
             b->dial_big = true;
             b->route_lds = big_lds;
-            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 256;
+            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 512;       // (256: 4.2-4.7 ms, 512: 3.7-3.9 ms, config 5)
         } else if (b->cfg.router == XR_ROUTER_DIAL) {
             return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL: the largest region (%d nodes) exceeds the frontier router's limits", b->n_max);
         }
@@ -462,7 +462,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         XR_ALLOC(b->dg_field, (size_t)B * b->n_max);
         XR_ALLOC(b->dg_masks, (size_t)B * 2 * mwg);
         XR_ALLOC(b->dg_touch, (size_t)B * b->n_max);
-        XR_ALLOC(b->dg_path, (size_t)B * b->n_max);
+        XR_ALLOC(b->dg_path, (size_t)B * b->n_max * 2);
     } else if (!b->lds_dist) {
         XR_ALLOC(b->dist_scratch, (size_t)B * b->n_lds);
         XR_ALLOC(b->cls_scratch, (size_t)B * b->n_lds);

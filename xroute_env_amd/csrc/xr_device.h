@@ -7,6 +7,17 @@
 #define XR_CLS_FREE 0
 #define XR_CLS_PEN 1
 #define XR_CLS_BLOCK 2
+// work-list capacities of the frontier router's HBM-scratch form (xr_dial.h); capacity never affects results
+#ifndef XR_BIG_CA
+#define XR_BIG_CA 2048         // active words per chunk
+#endif
+#ifndef XR_BIG_CN
+#define XR_BIG_CN 4096         // nodes per chunk
+#endif
+#ifndef XR_BIG_CE
+#define XR_BIG_CE 2048         // (node, distance) pairs per expansion pass
+#endif
+#define XR_BIG_MAXG 1024       // groups (1024 nodes each): regions up to 1 M nodes
 #define XR_MAX_AP_PER_NET 128   // access points of one net staged in LDS by the route kernel
 
 // One region (static after xr_batch_load_regions). Node arrays are in the reference observation's
@@ -92,7 +103,7 @@ struct XrBatchDev {
     uint32_t* dg_field;      // [B][n_max]
     uint32_t* dg_masks;      // [B][2][n_max/32 + 1]  open bits, cached word minima
     uint32_t* dg_touch;      // [B][n_max]  nodes touched by the current route
-    uint32_t* dg_path;       // [B][n_max]  first half: path of the current trace; second half: deferred nodes
+    uint32_t* dg_path;       // [B][2][n_max]  path of the current trace; deferred nodes
     long long* phase_cycles; // [B][8] thread-0 cycle counts per kernel phase (only written with -DXR_PHASE_TIMING)
     // fused observation output of the step kernel (null: route only)
     float* obs_out;

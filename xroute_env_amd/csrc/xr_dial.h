@@ -694,10 +694,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 // the next chunk / round — capacity never affects the result.
 // ------------------------------------------------------------------------------------------------
 #define XR_BIG_CLEAN 0xFFFFFFFEu
-#define XR_BIG_CA 256          // words per chunk
-#define XR_BIG_CN 1024         // nodes per chunk
-#define XR_BIG_CE 512          // (node, distance) pairs per expansion wave
-#define XR_BIG_MAXG 1024       // groups (1024 nodes each): regions up to 1 M nodes
+// list capacities XR_BIG_CA / _CN / _CE / _MAXG: xr_device.h (the host sizes the LDS from them)
 
 __device__ __forceinline__ uint32_t xr_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xr_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -731,9 +728,9 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     uint32_t* __restrict__ openg = b.dg_masks + (int64_t)e * 2 * mwg;
     uint32_t* __restrict__ wming = openg + mwg;
     uint32_t* __restrict__ touchg = b.dg_touch + (int64_t)e * b.n_max;
-    uint32_t* __restrict__ pathg = b.dg_path + (int64_t)e * b.n_max;          // first half: path of the current trace
-    const int defer_cap = b.n_max >> 1;
-    uint32_t* __restrict__ deferl = pathg + defer_cap;                        // second half: deferred nodes
+    uint32_t* __restrict__ pathg = b.dg_path + (int64_t)e * b.n_max * 2;      // [0, n_max): path of the current trace (a path is simple)
+    const int defer_cap = b.n_max;
+    uint32_t* __restrict__ deferl = pathg + b.n_max;                          // [n_max, 2 n_max): deferred nodes
 
     // LDS carve: gmin u32[MAXG] | G u16[MAXG] | A u32[CA] | N u32[CN] | E0, E1 uint2[CE] | el4x | el4y
     uint32_t* s_gmin = reinterpret_cast<uint32_t*>(smem);
