@@ -93,3 +93,47 @@ def test_config5_32_envs_10_steps_match_oracle(router):
         assert np.array_equal(owner[e, : env.n], env.owner()), e
         assert int(hashes[e]) == env.hash() and rec["cum"][e].tolist() == env.cum().tolist()
     assert int(batch.fetch("sweeps").cpu().max()) > 0
+
+
+def test_frontier_router_work_list_overflow_paths():
+    """`libxroute_hip_tinylists.so` is the same source built with work lists of 64 words / 80 nodes / 24 expansions
+    (`make tinylists`): every overflow path of the HBM-scratch form — a word that does not fit the node list is put back, a
+    node that does not fit the expansion list stays open, run-ahead that does not fit takes the open mask — runs on every
+    route.  Capacity must never change a result: full episodes on mid-sized regions against the oracle, in a subprocess
+    (the library is chosen at import time)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "xroute_env_amd", "libxroute_hip_tinylists.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(root, "xroute_env_amd", "csrc"), "tinylists"])
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import xr_oracle as orc
+from xroute_env_amd.batch import RegionBatch
+from xroute_env_amd.regions import generate_region
+regs = [generate_region(7700 + i, dims=(40, 48, 6), k_range=(6, 10), net_span=30, blockage=(0.25, 0.35)) for i in range(12)]
+batch = RegionBatch(regs, device="cuda:0", auto_reset=True, force_scratch_field=True)
+batch.reset()
+ob = orc.OracleBatch(regs)
+acts = torch.empty(len(regs), dtype=torch.int32, device="cuda:0")
+real = 0
+for it in range(14):
+    batch.random_actions(40 + it, acts)
+    ref = ob.step(acts.cpu().numpy(), threads=ob.max_threads(), auto_reset=True)
+    batch.step(acts)
+    rec = batch.records()
+    assert np.array_equal(rec["delta"], ref["delta"]) and np.array_equal(rec["done"], ref["done"]), it
+    real += ref["real_steps"]
+h = batch.fetch("hash").cpu().numpy().view(np.uint64)
+assert [int(v) for v in h] == [e.hash() for e in ob.envs]
+owner = batch.fetch("owner").cpu().numpy()
+for e, env in enumerate(ob.envs):
+    assert np.array_equal(owner[e, :env.n], env.owner())
+print("tinylists ok", real)
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, XR_LIB="libxroute_hip_tinylists.so"))
+    assert out.returncode == 0 and "tinylists ok" in out.stdout, out.stderr[-3000:]

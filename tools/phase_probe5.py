@@ -10,11 +10,13 @@ from xroute_env_amd.regions import config_regions
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 router = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 mult = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-regions = config_regions(5, min(B, 32))
+cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+regions = config_regions(cfg, min(B, 32) if cfg == 5 else B)
 batch = RegionBatch(regions, n_envs=B, auto_reset=True, router=router, dial_mult=mult)
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
-batch.random_actions(11, acts); batch.step(acts)
+for w in range(6 if cfg != 5 else 1):
+    batch.random_actions(11 + 100 * w, acts); batch.step(acts)
 ph0 = batch.fetch("phases").clone()
 batch.random_actions(12, acts)
 torch.cuda.synchronize()
