@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_config5.py -x -q -m gpu -k overflow 2>&1 | tail -8
+mkdir -p gpurun_out/r02soak
+python tools/soak.py 4096 300 3 obs 2>&1 | tail -2 | tee gpurun_out/r02soak/soak3.txt
+python tools/soak.py 4096 300 3 2>&1 | tail -1 | tee -a gpurun_out/r02soak/soak3.txt
+python tools/soak.py 256 40 5 2>&1 | tail -1 | tee gpurun_out/r02soak/soak5.txt
