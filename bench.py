@@ -428,6 +428,35 @@ def main():
                                             "env_steps_per_s is the figure of merit"))
         except Exception as ex:          # a leg must never take the headline down
             kernels.append({"kernel": "xr_route_kernel", "error": str(ex)})
+        if fused:
+            try:        # in-place form: the same step into the same (persistent) buffer, only the planes that change are written
+                n_leg = max(args.steps, 5)
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_leg)]
+                batch.observation(obs)
+                units = torch.zeros(n_leg, dtype=torch.int32, device=dev)
+                s0 = batch.total_steps()
+                for i, (e0, e1) in enumerate(evs):
+                    batch.random_actions(args.seed + 200000 + i, acts)
+                    e0.record()
+                    batch.step(acts, obs, inplace=True)
+                    e1.record()
+                    batch.fetch("units", units[i:i + 1])
+                torch.cuda.synchronize(dev)
+                ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_leg
+                real = (batch.total_steps() - s0) / n_leg
+                N0 = float(regions[0].n_nodes)
+                # bytes that MUST change: state load 4·N + planes 0..1 (8·N) per slot + 28·N per planned unit (nets above the routed one;
+                # all nets of a slot that re-initialises)
+                nb = 12.0 * float(n_nodes.sum().item()) + 28.0 * N0 * float(units.double().mean().item())
+                ent = kernel_entry("xr_step_queue_kernel (in-place: xr_batch_step_observe_inplace)", ms, nb, real, "hbm-write (routing phase: lds-latency)",
+                                   "the full step into the caller's persistent observation buffer: net planes are static and the channel order is "
+                                   "'nets ascending', so only planes 0..1 and the planes of the remaining nets ABOVE the routed one change — the buffer "
+                                   "ends up byte-identical to the full write (tests/test_gpu_obs.py); bytes = the planes that change, NOT 4·N·(2+7K)")
+                ent["mean_units_per_env_step"] = float(units.double().mean().item()) / B
+                ent["full_rewrite_bytes"] = obs_bytes + state_bytes
+                kernels.append(ent)
+            except Exception as ex:
+                kernels.append({"kernel": "xr_step_queue_kernel (in-place)", "error": str(ex)})
         if c5_regions:
             try:
                 kernels.append(config5_leg(args, c5_regions, dev))

@@ -151,6 +151,7 @@ typedef struct xr_region_desc {
                                                  record per env (written by the kernels themselves: one copy, one sync) */
 #define XR_FETCH_TOUCHED  16   /* int32 [B]     nodes whose field word the last route created (HBM-scratch form of the frontier
                                                  router: the work it really did; 0 for the other forms) */
+#define XR_FETCH_UNITS    17   /* uint32[1]     net-plane units (7 planes of one net of one env) the last xr_batch_step_observe* planned */
 #define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
                                                  built with -DXR_PHASE_TIMING) */
 
@@ -220,6 +221,18 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream);
  *                 fine-grained pure-write drain instead of a tail of whole envs.  Same requirements as XR_OBS_SPLIT. */
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                               void* stream);
+
+/* In-place form of xr_batch_step_observe for a caller that keeps ONE observation buffer for the batch (the vector env): the
+ * planes of a net are static (baseline/build_3Dgrid.py:106-142) and the channel order is "nets ascending" (:177-179), so removing
+ * the routed net shifts only the nets ABOVE it down by one 7-plane slot — the nets below keep their slot and their bytes.
+ * When out_dev / env_stride are the buffer that received this batch's previous full observation (the last xr_batch_observation
+ * over all slots, xr_batch_step_observe or xr_batch_step_observe_inplace, with no other state-changing call in between) and
+ * the caller has not written to it, only planes 0..1 and the planes of the remaining nets above the routed one are written
+ * (a slot that re-initialises writes everything, a rejected action planes 0..1 only): the buffer ends up byte-identical to
+ * what xr_batch_step_observe writes, with about half the HBM traffic under a uniform net choice.  Any other buffer: a full
+ * write, exactly xr_batch_step_observe.  xr_batch_observe_timing reports mode | 16 when the in-place path ran. */
+int32_t xr_batch_step_observe_inplace(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
+                                      void* stream);
 
 /* Compact-consumer mode.  The reference consumer re-encodes every net's 7 planes at every step (baseline/DQN/DQN.py:138-155),
  * but those planes are functions of the region's static access points only (baseline/build_3Dgrid.py:106-142): a consumer

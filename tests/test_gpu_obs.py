@@ -309,3 +309,68 @@ def test_helper_writers_and_stream_per_region_are_byte_identical():
     from xroute_env_amd._lib import XRouteError
     with pytest.raises(XRouteError):
         RegionBatch(config_regions(3, 65), device="cuda:0", stream_per_region=True)          # more than 64 slots
+
+
+def test_inplace_step_observe_is_byte_identical_and_falls_back():
+    """xr_batch_step_observe_inplace: only planes 0..1 and the planes of the remaining nets ABOVE the routed one are written
+    into the caller's persistent buffer — which must end up byte-identical to the full write (and to the oracle), through
+    auto-resets with region rotation, rejected actions, and every fallback (another buffer, a state change in between)."""
+    import torch
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+    B, R = 96, 64
+    regions = config_regions(3, R)
+    batch = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
+    twin = RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, max_route_count=2)
+    for b in (batch, twin):
+        b.reset(rotate=True)
+    obs = batch.alloc_observation()
+    ref = twin.alloc_observation()
+    obs.fill_(-3.0)
+    batch.observation(obs)                                     # the buffer now holds every slot's observation
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    modes = set()
+    for it in range(45):
+        batch.random_actions(500 + it, acts)
+        if it % 7 == 3:
+            acts[::5] = 0                                      # rejected actions: nothing but planes 0..1 may be touched
+        if it == 20:                                           # a route-only step in between invalidates the buffer ...
+            batch.step(acts); twin.step(acts)
+            batch.random_actions(9000, acts)
+        if it == 30:                                           # ... and so does handing in another buffer
+            other = batch.alloc_observation()
+            batch.step(acts, other, inplace=True)
+            assert batch.observe_timing()[0] == 3              # full write
+            twin.step(acts, ref)
+            nl = twin.fetch("nlegal").cpu().numpy(); rg = twin.fetch("region").cpu().numpy()
+            for e in range(B):
+                n = (2 + 7 * int(nl[e])) * regions[rg[e]].n_nodes
+                assert torch.equal(other[e, :n], ref[e, :n])
+            batch.observation(obs)                             # re-validate the persistent buffer
+            continue
+        batch.step(acts, obs, inplace=True)
+        modes.add(batch.observe_timing()[0])
+        if it == 20:
+            assert batch.observe_timing()[0] == 3              # fell back to the full write
+        twin.step(acts, ref)
+        nl = twin.fetch("nlegal").cpu().numpy(); rg = twin.fetch("region").cpu().numpy()
+        assert np.array_equal(nl, batch.fetch("nlegal").cpu().numpy())
+        for e in range(B):
+            n = (2 + 7 * int(nl[e])) * regions[rg[e]].n_nodes
+            assert torch.equal(obs[e, :n], ref[e, :n]), (it, e)
+    assert 19 in modes and 3 in modes                          # both the in-place path (3 | 16) and the fallback ran
+    # and against the oracle at the end of the run
+    envs_checked = 0
+    rg = batch.fetch("region").cpu().numpy()
+    legal = batch.legal_sets()
+    owner = batch.fetch("owner").cpu().numpy()
+    for e in range(0, B, 9):
+        reg = regions[rg[e]]
+        from xroute_env_amd.regions import unpack_records, pack_records
+        ntype, _, net, pin = unpack_records(reg.nodes)
+        rec = pack_records(ntype, (owner[e, :reg.n_nodes] != 0).astype(np.int64), net, pin)
+        want = orc.build_observation(reg.dims, rec, np.array(sorted(legal[e]), np.int32)).ravel()
+        assert np.array_equal(obs[e, :want.size].cpu().numpy(), want), e
+        envs_checked += 1
+    assert envs_checked >= 10

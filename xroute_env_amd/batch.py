@@ -124,10 +124,11 @@ class RegionBatch:
         with torch.cuda.device(self.device):
             _lib.check(self.L.xr_batch_reset(self._h, ptr, int(rotate), _stream_ptr(self.device)))
 
-    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, inplace: bool = False):
         """Game.step for every env: actions int32[B] on the device, 1-based net ids.  With `obs_out`
         ([n_envs, stride] fp32) the same launch also writes every env's observation of the new state
-        (xr_batch_step_observe)."""
+        (xr_batch_step_observe).  `inplace=True` (xr_batch_step_observe_inplace): `obs_out` is the buffer that received this
+        batch's previous observation and has not been written to since — only the planes that change are written."""
         if actions.device != self.device or actions.dtype != torch.int32 or not actions.is_contiguous() \
                 or actions.numel() != self.n_envs:
             raise ValueError("actions must be a contiguous int32 tensor of n_envs entries on the batch device")
@@ -138,9 +139,9 @@ class RegionBatch:
                 if obs_out.device != self.device or obs_out.dtype != torch.float32 or not obs_out.is_contiguous() \
                         or obs_out.dim() != 2 or obs_out.shape[0] < self.n_envs:
                     raise ValueError("obs_out must be a contiguous fp32 [n_envs, stride] tensor on the batch device")
-                _lib.check(self.L.xr_batch_step_observe(self._h, C.c_void_p(actions.data_ptr()),
-                                                        C.c_void_p(obs_out.data_ptr()), obs_out.shape[1],
-                                                        _stream_ptr(self.device)))
+                fn = self.L.xr_batch_step_observe_inplace if inplace else self.L.xr_batch_step_observe
+                _lib.check(fn(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs_out.data_ptr()), obs_out.shape[1],
+                              _stream_ptr(self.device)))
         return obs_out
 
     def alloc_head(self) -> torch.Tensor:
@@ -262,6 +263,7 @@ class RegionBatch:
         "steps": (_lib.XR_FETCH_STEPS, torch.int64, lambda s: (1,)),
         "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
         "phases": (_lib.XR_FETCH_PHASES, torch.int64, lambda s: (s.n_envs, 8)),
+        "units": (_lib.XR_FETCH_UNITS, torch.int32, lambda s: (1,)),
         "touched": (_lib.XR_FETCH_TOUCHED, torch.int32, lambda s: (s.n_envs,)),
         "record": (_lib.XR_FETCH_RECORD, torch.uint8, lambda s: (s.n_envs, _lib.RECORD_BYTES)),
     }

@@ -126,6 +126,9 @@ struct xr_batch {
     std::vector<hipEvent_t> region_events;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
     int last_obs_mode = 0;
+    int last_obs_inplace = 0;
+    const float* obs_valid_ptr = nullptr;       // buffer that holds the current observation of ALL env slots (in-place form)
+    int64_t obs_valid_stride = 0;
     XrBatchDev dev{};
     ~xr_batch() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -223,6 +226,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     // a reload invalidates the batch until it has completed: a failure midway must not leave `loaded` set over
     // freed or partly reallocated device buffers
     b->loaded = false;
+    b->obs_valid_ptr = nullptr;
     b->n_cus = 0;
     memset(&b->dev, 0, sizeof(b->dev));
 
@@ -518,7 +522,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
-    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000;
+    d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000; d.obs_incremental = 0;
     d.env_base = 0; d.env_count = 0;
     d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
     if (!b->aux_stream) {
@@ -566,6 +570,7 @@ int32_t xr_batch_reset(xr_batch* b, const uint8_t* mask_dev, int32_t rotate, voi
     if (!b) return fail(XR_ERR_INVALID, "xr_batch_reset: null batch");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_reset: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
+    b->obs_valid_ptr = nullptr;
     XR_HIP(xr_launch_reset(&b->dev, mask_dev, rotate ? 1 : 0, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
@@ -608,10 +613,24 @@ int32_t xr_batch_step(xr_batch* b, const int32_t* actions_dev, void* stream) {
     if (!b || !actions_dev) return fail(XR_ERR_INVALID, "xr_batch_step: null argument");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
+    b->obs_valid_ptr = nullptr;
     return launch_route_form(b, b->dev, actions_dev, static_cast<hipStream_t>(stream));
 }
 
+namespace {
+int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream, bool inplace);
+}
+
 int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream) {
+    return step_observe_impl(b, actions_dev, out_dev, env_stride, stream, false);
+}
+
+int32_t xr_batch_step_observe_inplace(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream) {
+    return step_observe_impl(b, actions_dev, out_dev, env_stride, stream, true);
+}
+
+namespace {
+int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride, void* stream, bool inplace) {
     if (!b || !actions_dev || !out_dev) return fail(XR_ERR_INVALID, "xr_batch_step_observe: null argument");
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_step_observe: load regions first");
     if (env_stride < (int64_t)(2 + 7 * (int64_t)b->k_max) * b->n_max_nodes)
@@ -632,6 +651,10 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
         b->last_obs_mode = XR_OBS_QUEUE;
         d.obs_head_only = 1;
         d.obs_split_pm = 1000;
+        // in-place form: only when THIS buffer holds the observation of the state before the step (else: a full write)
+        d.obs_incremental = (inplace && b->obs_valid_ptr == out_dev && b->obs_valid_stride == env_stride) ? 1 : 0;
+        b->last_obs_inplace = d.obs_incremental;
+        b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
         XR_HIP(xr_launch_plan(&d, actions_dev, st));
         if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel
@@ -662,6 +685,8 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
         return XR_OK;
     }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
+    b->last_obs_inplace = 0;                                  // the fused and split forms always write the whole observation
+    b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
     if (!split) return launch_route_form(b, d, actions_dev, st);
     // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
     // caller's stream -> join.  Everything is ordered by events; the host never waits.
@@ -678,6 +703,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
     XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
     return XR_OK;
 }
+}  // namespace
 
 int32_t xr_batch_step_compact(xr_batch* b, const int32_t* actions_dev, float* head_out_dev, int64_t head_stride, void* stream) {
     if (!b || !actions_dev || !head_out_dev) return fail(XR_ERR_INVALID, "xr_batch_step_compact: null argument");
@@ -693,6 +719,7 @@ int32_t xr_batch_step_compact(xr_batch* b, const int32_t* actions_dev, float* he
     d.obs_vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     if (d.obs_vec4 == 0)        // (the scalar epilogue has no head-only form)
         return fail(XR_ERR_INVALID, "xr_batch_step_compact: head_out_dev must be 16-byte aligned and head_stride a multiple of 4");
+    b->obs_valid_ptr = nullptr;
     d.obs_head_only = 1;          // the epilogue writes planes 0..1 and the net planes of the lowest XR_SPLIT_KEEP ranks: none
     d.obs_split_pm = 1000;
     b->last_obs_mode = XR_OBS_FUSED;
@@ -727,7 +754,7 @@ int32_t xr_batch_route_occupancy(xr_batch* b, int32_t* workgroups_per_cu, int64_
 
 int32_t xr_batch_observe_timing(xr_batch* b, int32_t* mode_out, float* writer_ms) {
     if (!b || !mode_out || !writer_ms) return fail(XR_ERR_INVALID, "xr_batch_observe_timing: null argument");
-    *mode_out = b->last_obs_mode;
+    *mode_out = b->last_obs_mode + (b->last_obs_mode == XR_OBS_QUEUE && b->last_obs_inplace ? 16 : 0);    // bit 4: the in-place form ran
     *writer_ms = 0.f;
     if (b->last_obs_mode == XR_OBS_SPLIT) {
         XR_HIP(hipSetDevice(b->cfg.device));
@@ -743,6 +770,7 @@ int32_t xr_batch_route_order(xr_batch* b, const int32_t* orders_dev, int32_t str
     if (stride < b->k_max)
         return fail(XR_ERR_RANGE, "xr_batch_route_order: stride %d < k_max %d", stride, b->k_max);
     XR_HIP(hipSetDevice(b->cfg.device));
+    b->obs_valid_ptr = nullptr;
     XR_HIP(xr_launch_order(&b->dev, orders_dev, stride, net_stats_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds,
                            b->route_threads, static_cast<hipStream_t>(stream)));
     return XR_OK;
@@ -769,6 +797,9 @@ int32_t xr_batch_observation(xr_batch* b, float* out_dev, int64_t env_stride, in
     const int vec4 = aligned ? (b->all_n_mult4 ? 1 : (b->stream_ok ? 2 : 0)) : 0;
     XR_HIP(xr_launch_obs(&b->dev, out_dev, env_stride, env_lo, env_hi, b->n_max_nodes, vec4,
                          static_cast<hipStream_t>(stream)));
+    if (env_lo == 0 && env_hi == b->cfg.n_envs && env_stride >= (int64_t)(2 + 7 * (int64_t)b->k_max) * b->n_max_nodes) {
+        b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;      // this buffer now holds every slot's observation
+    }
     return XR_OK;
 }
 
@@ -793,6 +824,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_UNITS: src = b->queue.p + 2; bytes = sizeof(uint32_t); break;
     case XR_FETCH_TOUCHED: src = b->touched.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;
     case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;

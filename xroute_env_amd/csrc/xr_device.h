@@ -111,6 +111,7 @@ struct XrBatchDev {
     int32_t obs_vec4;        // float4 stores allowed (all N % 4 == 0, aligned planes)
     int32_t obs_head_only;   // 1: split form: the step kernel writes planes 0..1 and the net planes of the lowest ranks,
                              //    xr_netplane_kernel the net planes of the highest floor(K * obs_split_pm / 1000) ranks
+    int32_t obs_incremental; // 1: the output buffer holds the previous observation: only planes that change are written (in-place form)
     int32_t obs_split_pm;    // per mille of every env's net planes that go to the writer kernel (1..1000)
     // split observation (xr_plan_kernel -> xr_netplane_kernel): the state every env will have AFTER this step
     int32_t* plan_region;    // [B]

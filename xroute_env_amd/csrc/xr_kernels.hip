@@ -1158,9 +1158,11 @@ __global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_
     int k = 0, r = 0;
     const uint64_t* lsrc = nullptr;        // where the post-step legal words come from
     int clear_bit = -1;
+    bool was_reset = false;
     if (e < b.n_envs) {
         const int nl = b.nlegal[e];
         r = b.env_region[e];
+        was_reset = (nl == 0);
         if (nl == 0) {
             if (b.auto_reset) {            // xr_env_reset(rotate = 1), examples/launch_training.py:37-46
                 if (b.env_replay[e] == b.max_route_count) r = (int)(((int64_t)r + b.n_envs) % b.n_regions);
@@ -1180,8 +1182,24 @@ __global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_
         }
         b.plan_region[e] = r;
     }
-    // the step kernel keeps the lowest XR_SPLIT_KEEP ranks of every env, the writer takes the rest
-    const int kskip = XR_SPLIT_KEEP(b, k);
+    // the step kernel keeps the lowest XR_SPLIT_KEEP ranks of every env, the writer takes the rest.
+    // In-place form (xr_batch_step_observe_inplace: the caller's buffer still holds the previous observation): the planes of a
+    // net are static, and removing net a from the ascending net list shifts only the nets ABOVE it down by one slot — the
+    // nets below keep their slot and their bytes.  So only the remaining nets above the routed one are units; a slot that
+    // re-initialises writes all of them, a rejected action none.
+    int kskip = XR_SPLIT_KEEP(b, k);
+    if (b.obs_incremental && e < b.n_envs && !was_reset) {
+        if (clear_bit < 0) kskip = k;
+        else {
+            int below = 0;
+            for (int w = 0; w <= (clear_bit >> 6); w++) {
+                uint64_t m = lsrc[w];
+                if (w == (clear_bit >> 6)) m &= (1ULL << (clear_bit & 63)) - 1ULL;
+                below += __popcll(m);
+            }
+            kskip = below;
+        }
+    }
     const int kw = k - kskip;
     int incl = kw;
 #pragma unroll

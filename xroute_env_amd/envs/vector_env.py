@@ -50,7 +50,9 @@ class XRouteVectorEnv:
 
     def step(self, actions: torch.Tensor):
         if self.with_observation:
-            self.batch.step(actions, self.obs)          # one fused launch: route + observation of every env
+            # route + observation of every env; self.obs is this env's own persistent buffer, so the in-place form applies:
+            # only the planes that change are written (byte-identical to a full write; do not write into `obs` yourself)
+            self.batch.step(actions, self.obs, inplace=True)
             return self._collect(observe=False)
         self.batch.step(actions)
         return self._collect(observe=False)
