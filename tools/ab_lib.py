@@ -1,0 +1,14 @@
+"""Interleaved A/B of two library builds on ONE box: python tools/ab_lib.py libA.so libB.so [envs] -> (step, route-only, in-place) ms."""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+libs = sys.argv[1:3]
+B = sys.argv[3] if len(sys.argv) > 3 else "4096"
+res = {}
+for rep in range(3):
+    for lib in libs:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", B, "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                              "--c5-envs", "0"], capture_output=True, text=True, env=dict(os.environ, XR_LIB=lib))
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        res.setdefault(lib, []).append(tuple(round(k["ms"], 4) for k in d["kernels"]))
+for k, v in res.items():
+    print(f"{k:28s} {v}")

@@ -101,7 +101,7 @@ struct xr_batch {
     DevBuf<XrRegionDev> regions;
     DevBuf<uint32_t> rg_rec;
     DevBuf<int16_t> rg_node_net, rg_owner0;
-    DevBuf<int32_t> coords, net_csr, ap_node;
+    DevBuf<int32_t> coords, net_csr, ap_node, ap_feat;
     DevBuf<int16_t> ap_pin;
     DevBuf<uint64_t> legal0;
     // envs
@@ -232,7 +232,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     std::vector<XrRegionDev> hreg(n_regions);
     std::vector<uint32_t> hrec;
-    std::vector<int32_t> hcoords, hcsr, hap_node;
+    std::vector<int32_t> hcoords, hcsr, hap_node, hap_feat;
     std::vector<int16_t> hap_pin;
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
@@ -311,6 +311,23 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                 hap_node[base + cur[net1]] = f;
                 hap_pin[base + cur[net1]] = (int16_t)XR_REC_PIN1(rec);
                 cur[net1]++;
+            }
+        }
+        // per access point: does it have an in-bounds axis neighbour that is an access point of the same net, any pin
+        // (the reference's aliased direction planes, baseline/build_3Dgrid.py:125-138); static, so decided once here
+        hap_feat.resize(hap_node.size());
+        {
+            const int Yd = d.dim_y, Zd = d.dim_z, YZd = Yd * Zd;
+            auto net_of = [&](int f) -> int {
+                const uint32_t rr = d.nodes_host[f];
+                return XR_REC_TYPE(rr) == XR_TYPE_ACCESS ? (int)XR_REC_NET1(rr) : 0;
+            };
+            for (size_t i = base; i < hap_node.size(); i++) {
+                const int f = hap_node[i], n = net_of(f);
+                const int z = f % Zd, y = (f / Zd) % Yd, x = f / YZd;
+                const bool adj = (x + 1 < d.dim_x && net_of(f + YZd) == n) || (y > 0 && net_of(f - Zd) == n) || (x > 0 && net_of(f - YZd) == n) ||
+                                 (y + 1 < Yd && net_of(f + Zd) == n) || (z + 1 < Zd && net_of(f + 1) == n) || (z > 0 && net_of(f - 1) == n);
+                hap_feat[i] = f | (adj ? (int32_t)0x80000000 : 0);
             }
         }
         n_max_nodes = std::max(n_max_nodes, N);
@@ -437,6 +454,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->net_csr, hcsr.size());
     XR_ALLOC(b->ap_node, std::max<size_t>(1, hap_node.size()));
     XR_ALLOC(b->ap_pin, std::max<size_t>(1, hap_pin.size()));
+    XR_ALLOC(b->ap_feat, std::max<size_t>(1, hap_feat.size()));
     XR_ALLOC(b->legal0, hlegal0.size());
     XR_ALLOC(b->env_region, B);
     XR_ALLOC(b->env_replay, B);
@@ -481,6 +499,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     if (!hap_node.empty()) {
         XR_HIP(hipMemcpyAsync(b->ap_node.p, hap_node.data(), hap_node.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         XR_HIP(hipMemcpyAsync(b->ap_pin.p, hap_pin.data(), hap_pin.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+        XR_HIP(hipMemcpyAsync(b->ap_feat.p, hap_feat.data(), hap_feat.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     XR_HIP(hipMemcpyAsync(b->legal0.p, hlegal0.data(), hlegal0.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     std::vector<int32_t> henv(B);
@@ -511,7 +530,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     XrBatchDev& d = b->dev;
     d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
-    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p;
+    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
     d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.lw_max = (int)lw_max; d.lines_max = lines_max; d.x_max = x_max; d.y_max = y_max; d.legal_words = legal_words; d.path_cap = b->path_cap;
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;

@@ -67,6 +67,7 @@ struct XrBatchDev {
     const int32_t* net_csr;
     const int32_t* ap_node;
     const int16_t* ap_pin;   // pin + 1
+    const int32_t* ap_feat;  // node index | (the access point has an axis neighbour that is an access point of the same net) << 31
     const uint64_t* legal0;
     int32_t n_regions;
     // envs (mutable)
