@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-legs", action="store_true", help="skip the extra per-kernel legs (route-only, config 5)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="two launches (xr_batch_step, xr_batch_observation) instead of xr_batch_step_observe")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extras` of the default N = 1 line (batch-1 Game.step latency = BASELINE config 1; DQN counterpart attached on 1024 envs = config 3)")
     ap.add_argument("--c5-envs", type=int, default=1024, help="env slots of the BASELINE config 5 leg (256x256x12 regions)")
     ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -520,6 +522,8 @@ def main():
                 out["parity"] = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum)
             except Exception as ex:
                 out["parity"] = {"error": str(ex)}
+        if do_legs and not args.no_extras:
+            out["extras"] = extras_leg(args, regions, dev, batch, obs)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=obs is not None)
@@ -536,6 +540,47 @@ def bench_args_key(args, world):
     return {"gpus": world, "steps": args.steps, "warmup": args.warmup, "envs": args.envs, "global_envs": args.global_envs,
             "config": args.config, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
             "no_stagger": bool(args.no_stagger)}
+
+
+def extras_leg(args, regions, dev, batch, obs):
+    """Driver-visible side numbers of the default run (never part of `value`): BASELINE config 1 (batch-1 `Game.step` latency through
+    the reference-shaped API, host observation) and config 3 (DQN counterpart attached, 1024 envs, compact-consumer mode)."""
+    import copy
+    import torch
+    ex = {}
+    try:
+        from xroute_env_amd.game import Game
+        del obs
+        batch.close()
+        torch.cuda.empty_cache()
+        g = Game(regions=regions[:8], device=dev)
+        g.reset()
+        ts = []
+        for ep in range(5):
+            g.reset()
+            done = False
+            while not done:
+                a = min(g.legal_action_set)
+                t0 = time.perf_counter()
+                o, done, *_ = g.step(a)
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        ex["config1_game_step"] = {"ms_median": round(ts[len(ts) // 2] * 1e3, 4), "ms_p10": round(ts[len(ts) // 10] * 1e3, 4),
+                                   "ms_p90": round(ts[9 * len(ts) // 10] * 1e3, 4), "steps": len(ts),
+                                   "what": "BASELINE config 1: Game.step on one ispd18_test1-sized region through the reference-shaped API, "
+                                           "in-process simulator, observation returned as a CPU tensor like the reference's (PCIe-inclusive)"}
+        del g
+    except Exception as exn:
+        ex["config1_game_step"] = {"error": str(exn)}
+    try:
+        a2 = copy.copy(args)
+        a2.agent, a2.agent_full_obs, a2.steps, a2.warmup = "dqn", False, 5, 3
+        r = agent_leg(a2, regions[:1024], dev, 1)
+        ex["config3_dqn_attached"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step")}
+        ex["config3_dqn_attached"]["what"] = r["config"]["workload"]
+    except Exception as exn:
+        ex["config3_dqn_attached"] = {"error": str(exn)}
+    return ex
 
 
 def agent_leg(args, regions, dev, world):

@@ -40,8 +40,12 @@ def test_bench_json_contract(extra):
     if not extra:
         # per-kernel lines: the step kernel, the route-only kernel and the BASELINE config 5 route, each with its own numbers
         assert names[0] == "xr_step_queue_kernel" and "xr_route_kernel" in names and any("config 5" in n for n in names)
+        assert any("in-place" in n for n in names)
         for k in d["kernels"]:
             assert k["ms"] > 0 and k["bytes"] > 0 and abs(k["frac"] - k["achieved"] / 8000.0) < 1e-3 and k["env_steps_per_s"] > 0
+        # driver-visible side numbers: BASELINE config 1 latency and config 3 with the DQN counterpart attached
+        ex = d["extras"]
+        assert ex["config1_game_step"]["ms_median"] > 0 and ex["config3_dqn_attached"]["value"] > 0, ex
     p = d["parity"]                                  # the checker leg: oracle replay of the run's own actions
     assert p["hash_chains_equal"] is True and p["cumulative_metrics_equal"] is True and p["env_steps"] > 0 and p["envs"] == 256
     # value is consistent with the reported step time: real env-steps <= slots

@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_obs.py tests/test_lefdef.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -3
-python bench.py --region-pack tests/golden/ispd18_test1_regions.npz --steps 10 --warmup 3 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], [(k['kernel'][:30], round(k['ms'],4)) for k in d['kernels']])"
-XR_LIB=libxroute_hip_prev.so python bench.py --region-pack tests/golden/ispd18_test1_regions.npz --steps 10 --warmup 3 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], [(k['kernel'][:30], round(k['ms'],4)) for k in d['kernels']])"
+SECONDS=0
+python bench.py > gpurun_out/default_bench.json 2> gpurun_out/default_bench.err; echo "default bench wall seconds: $SECONDS"
+python -c "
+import json; d=json.loads(open('gpurun_out/default_bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])
+print(json.dumps(d['extras'])[:1200])"
