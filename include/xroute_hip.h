@@ -108,6 +108,13 @@ typedef struct xr_config {
                                  region fits, else XR_ROUTER_SWEEP), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
                                  worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
     int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 8) */
+    int32_t guide_cost;       /* XR-Maze v2 (all three neutral by default = XR-Maze v1): entering a node outside the net's guide costs this
+                                 much extra, DBU-equivalent (the role of `-follow_guide 1`, run-net-ordering-training.tcl:3); the guide of
+                                 a net = bounding box of all its access points in track indices, inflated by guide_margin, every layer */
+    int32_t guide_margin;
+    int32_t maze_end_iter;    /* >= 1 (`-maze_end_iter 3 -ripup_mode 1` of the same line): attempt t routes the net with the penalty
+                                 drc_cost*drc_unit << t; an attempt whose path uses a node held by another net is ripped up unless it is
+                                 the last one.  Frontier router, LDS form only (XR_ERR_RANGE otherwise) */
     int32_t stream_per_region; /* 1: "one region per stream" (north_star's first partition): xr_batch_step / _step_observe (fused
                                   form) / _step_compact launch ONE single-workgroup kernel per env slot, round-robin over a pool of
                                   internal HIP streams, joined to the caller's stream by events.  For batches of <= 64 slots only

@@ -137,6 +137,10 @@ struct xro_env {
     uint32_t* rec0;        /* initial records */
     int32_t m0[3];
     int via_cost, pen_cost;
+    /* XR-Maze v2 knobs, all neutral by default: guide_cost 0, maze_end_iter 1 */
+    int guide_cost, guide_margin, maze_end_iter;
+    int pen_now;           /* penalty of the current attempt: pen_cost << attempt */
+    int gx0, gx1, gy0, gy1; /* guide box of the net being routed (track indices) */
     /* static derived */
     int16_t* node_net;     /* Net of handle_messange: -1 / 0 / net id (1-based) */
     int* net_off;          /* [n_nets+2] CSR into ap_node/ap_pin, by 1-based net id */
@@ -175,6 +179,8 @@ xro_env* xro_env_create(int X, int Y, int Z, const int32_t* xs, const int32_t* y
     for (int i = 0; i < 3; i++) e->m0[i] = metrics0 ? metrics0[i] : 0;
     e->via_cost = via_cost;
     e->pen_cost = drc_cost * drc_unit;
+    e->guide_cost = 0; e->guide_margin = 0; e->maze_end_iter = 1;
+    e->pen_now = e->pen_cost;
     e->node_net = (int16_t*)malloc(sizeof(int16_t) * (N > 0 ? N : 1));
     e->owner = (int16_t*)malloc(sizeof(int16_t) * (N > 0 ? N : 1));
     e->legal = (unsigned char*)calloc(n_nets + 2, 1);
@@ -294,6 +300,20 @@ static int node_pen(const xro_env* e, int v, int net) {
     return (ow != 0 && ow != net) || (nn > 0 && nn != net);
 }
 
+/* XR-Maze v2: entering a node outside the net's guide box costs guide_cost extra (no violation).  The guide of a net is the
+ * bounding box of ALL its access points in track indices, inflated by guide_margin tracks in x and y, on every layer
+ * (the role of `-follow_guide 1`, ispd/ispd18_test1/run-net-ordering-training.tcl:3: out-of-guide routing is expensive,
+ * not forbidden). */
+static uint32_t node_guide(const xro_env* e, int v) {
+    if (e->guide_cost == 0) return 0u;
+    int y = (v / e->Z) % e->Y, x = v / (e->Y * e->Z);
+    return (x < e->gx0 || x > e->gx1 || y < e->gy0 || y > e->gy1) ? (uint32_t)e->guide_cost : 0u;
+}
+
+void xro_env_set_v2(xro_env* e, int guide_cost, int guide_margin, int maze_end_iter) {
+    e->guide_cost = guide_cost; e->guide_margin = guide_margin; e->maze_end_iter = maze_end_iter < 1 ? 1 : maze_end_iter;
+}
+
 static void heap_push(xro_env* e, uint32_t key, int node) {
     int i = e->heap_n++;
     while (i > 0) {
@@ -339,7 +359,7 @@ static void dijkstra(xro_env* e, int net) {
             uint32_t len; int is_via;
             int v = graph_nbr(e, u, d, &len, &is_via);
             if (v < 0 || node_blocked(e, v) || e->comp[v]) continue;
-            uint64_t nd = (uint64_t)du + len + (node_pen(e, v, net) ? (uint32_t)e->pen_cost : 0u);
+            uint64_t nd = (uint64_t)du + len + (node_pen(e, v, net) ? (uint32_t)e->pen_now : 0u) + node_guide(e, v);
             if (nd >= DIST_CAP) continue;   /* spec: such a node is unreachable */
             if ((uint32_t)nd < e->dist[v]) {
                 e->dist[v] = (uint32_t)nd;
@@ -384,6 +404,24 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
         for (int j = 0; j < npins; j++) if (pins[j] == p) { seen = 1; break; }
         if (!seen) pins[npins++] = p;
     }
+    /* guide box of the net (v2) */
+    e->gx0 = e->gy0 = 1 << 30; e->gx1 = e->gy1 = -1;
+    for (int i = lo; i < hi; i++) {
+        int f = e->ap_node[i], y = (f / e->Z) % e->Y, x = f / (e->Y * e->Z);
+        if (x < e->gx0) e->gx0 = x; if (x > e->gx1) e->gx1 = x;
+        if (y < e->gy0) e->gy0 = y; if (y > e->gy1) e->gy1 = y;
+    }
+    e->gx0 -= e->guide_margin; e->gx1 += e->guide_margin; e->gy0 -= e->guide_margin; e->gy1 += e->guide_margin;
+    /* XR-Maze v2 rip-up and reroute (`-maze_end_iter`, `-ripup_mode 1`): attempt t routes the whole net with the penalty
+     * pen_cost << t; an attempt whose path uses a node held by another net is ripped up (owners restored, nothing
+     * recorded) unless it is the last one.  maze_end_iter 1 = XR-Maze v1. */
+    int16_t* owner0 = NULL;
+    const uint64_t hash0 = e->hash;
+    if (e->maze_end_iter > 1) { owner0 = (int16_t*)malloc(sizeof(int16_t) * (e->N > 0 ? e->N : 1)); memcpy(owner0, e->owner, sizeof(int16_t) * e->N); }
+    for (int attempt = 0;; attempt++) {
+    e->pen_now = e->pen_cost << attempt;
+    int held_vio = 0;
+    memset(connected, 0, hi - lo + 1);
     /* component starts as every access point of the lowest pin id */
     int first = pins[0], first_idx = 0;
     for (int j = 1; j < npins; j++) if (pins[j] < first) { first = pins[j]; first_idx = j; }
@@ -416,7 +454,7 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
         while (e->dist[v] > 0) {
             int pred = -1; uint32_t plen_e = 0; int pvia = 0;
             const int held = node_pen(e, v, net);     /* a violation even when drc_cost is 0 */
-            uint32_t pen_v = held ? (uint32_t)e->pen_cost : 0u;
+            uint32_t pen_v = (held ? (uint32_t)e->pen_now : 0u) + node_guide(e, v);
             for (int d = 0; d < 6; d++) {
                 uint32_t len; int is_via;
                 int u = graph_nbr(e, v, d, &len, &is_via);
@@ -427,7 +465,7 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
             }
             if (pred < 0) { status |= 0x100; break; }   /* cannot happen on a consistent field */
             /* claim v */
-            if (held) d_vio += 1;
+            if (held) { d_vio += 1; held_vio += 1; }
             if (e->owner[v] == 0) e->owner[v] = (int16_t)net;
             e->comp[v] = 1;
             if (plen < path_cap && path) path[plen] = v;
@@ -448,6 +486,14 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
         remaining--;
         for (int i = lo; i < hi; i++) if (e->ap_pin[i] == pins[best_pin_idx]) e->comp[e->ap_node[i]] = 1;
     }
+    if (held_vio == 0 || attempt + 1 >= e->maze_end_iter) break;
+    /* rip up */
+    memcpy(e->owner, owner0, sizeof(int16_t) * e->N);
+    e->hash = hash0;
+    status = 0; plen = 0; d_vio = 0; d_wl = 0; d_via = 0;
+    }
+    e->pen_now = e->pen_cost;
+    free(owner0);
     free(pins); free(connected);
     if (plen > path_cap) status |= ENV_PATH_TRUNC;
 

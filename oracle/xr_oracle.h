@@ -39,6 +39,8 @@ double xro_reward(int64_t d_violation, int64_t d_wirelength, int64_t d_via);
 xro_env* xro_env_create(int X, int Y, int Z, const int32_t* xs, const int32_t* ys,
                         const uint8_t* layer_dir, const uint32_t* rec, int n_nets,
                         const int32_t* metrics0, int via_cost, int drc_cost, int drc_unit);
+/* XR-Maze v2 knobs: guide cost / margin, rip-up-and-reroute attempts; (0, 0, 1) = XR-Maze v1 */
+void xro_env_set_v2(xro_env* e, int guide_cost, int guide_margin, int maze_end_iter);
 void xro_env_destroy(xro_env* e);
 void xro_env_reset(xro_env* e);   /* reference Game.reset bookkeeping, baseline_utils.py:466-473 */
 /* reference Game.step bookkeeping (baseline_utils.py:409-438) around the XR-Maze v1 router.

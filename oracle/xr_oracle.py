@@ -38,6 +38,8 @@ def lib():
     L.xro_reward.restype = C.c_double
     L.xro_env_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.xro_env_create.restype = vp
+    L.xro_env_set_v2.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.xro_env_set_v2.restype = None
     L.xro_env_destroy.argtypes = [vp]
     L.xro_env_destroy.restype = None
     L.xro_env_reset.argtypes = [vp]
@@ -103,7 +105,7 @@ def reward(dv, dw, dvia):
 class OracleEnv:
     """One env on the CPU oracle (Game bookkeeping + XR-Maze v1)."""
 
-    def __init__(self, region, via_cost=800, drc_cost=8, drc_unit=400):
+    def __init__(self, region, via_cost=800, drc_cost=8, drc_unit=400, guide_cost=0, guide_margin=0, maze_end_iter=1):
         self.region = region
         X, Y, Z = region.dims
         self._keep = [np.ascontiguousarray(region.xs, np.int32), np.ascontiguousarray(region.ys, np.int32),
@@ -115,6 +117,8 @@ class OracleEnv:
                                       via_cost, drc_cost, drc_unit)
         if not self.h:
             raise MemoryError("xro_env_create failed")
+        if guide_cost or maze_end_iter != 1:
+            lib().xro_env_set_v2(self.h, int(guide_cost), int(guide_margin), int(maze_end_iter))
         self.n = lib().xro_env_n_nodes(self.h)
 
     def __del__(self):
@@ -179,8 +183,8 @@ class OracleEnv:
 class OracleBatch:
     """Many oracle envs stepped with OpenMP over envs (the timed CPU baseline)."""
 
-    def __init__(self, regions, via_cost=800, drc_cost=8, drc_unit=400):
-        self.envs = [OracleEnv(r, via_cost, drc_cost, drc_unit) for r in regions]
+    def __init__(self, regions, via_cost=800, drc_cost=8, drc_unit=400, **v2):
+        self.envs = [OracleEnv(r, via_cost, drc_cost, drc_unit, **v2) for r in regions]
         self.handles = (C.c_void_p * len(self.envs))(*[e.h for e in self.envs])
         self.n = len(self.envs)
 

@@ -226,3 +226,52 @@ def test_scratch_field_variant_full_parity_on_ispd_sized_regions():
     same bit-exact parity as the LDS-resident path."""
     regions = [generate_region(5100 + i) for i in range(12)]
     _run_episode_parity(regions, policy="random", force_scratch_field=True)
+
+
+@pytest.mark.parametrize("v2", [dict(maze_end_iter=3), dict(guide_cost=800, guide_margin=2), dict(guide_cost=1200, guide_margin=0, maze_end_iter=4)])
+def test_xr_maze_v2_matches_the_oracle(v2):
+    """XR-Maze v2 (guide cost, rip-up-and-reroute with a doubling penalty; `-follow_guide 1 -maze_end_iter 3
+    -ripup_mode 1` of run-net-ordering-training.tcl:3 given a meaning) on the GPU == the oracle's v2, bit for bit — and the
+    knobs really change routes relative to v1."""
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(3300 + i) for i in range(16)]
+    batch = RegionBatch(regions, device="cuda:0", **v2)
+    envs = [orc.OracleEnv(r, **v2) for r in regions]
+    v1 = [orc.OracleEnv(r) for r in regions]
+    batch.reset()
+    differs = 0
+    for _ in range(40):
+        legal = batch.legal_sets()
+        if not any(legal):
+            break
+        acts = [max(s) if s else 0 for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+        rec = batch.records()
+        plen = batch.fetch("path_len").cpu().numpy()
+        path = batch.fetch("path").cpu().numpy()
+        owner = batch.fetch("owner").cpu().numpy()
+        for i, env in enumerate(envs):
+            if not acts[i]:
+                continue
+            ref = env.step(acts[i])
+            ref1 = v1[i].step(acts[i])
+            assert rec["delta"][i].tolist() == ref["delta"].tolist(), (i, acts[i], rec["delta"][i], ref["delta"])
+            assert rec["status"][i] == ref["status"] and plen[i] == ref["path_len"]
+            assert path[i, :plen[i]].tolist() == ref["path"].tolist()
+            assert np.array_equal(owner[i, :env.n], env.owner())
+            differs += int(ref["path"].tolist() != ref1["path"].tolist())
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    assert [int(h) for h in hashes] == [e.hash() for e in envs]
+    assert differs > 0
+
+
+def test_xr_maze_v2_refused_where_unsupported():
+    from xroute_env_amd._lib import XRouteError
+    from xroute_env_amd.batch import RegionBatch
+    regs = [generate_region(1, dims=(12, 10, 5), k_range=(2, 3))]
+    for kw in (dict(router=1), dict(force_scratch_field=True)):
+        with pytest.raises(XRouteError):
+            RegionBatch(regs, device="cuda:0", maze_end_iter=2, **kw)
+    with pytest.raises(XRouteError):
+        RegionBatch(regs, device="cuda:0", maze_end_iter=9)

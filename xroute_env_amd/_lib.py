@@ -37,6 +37,7 @@ class XrConfig(C.Structure):
                 ("block_threads", C.c_int32), ("force_scratch_field", C.c_int32), ("obs_mode", C.c_int32),
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
                 ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
+                ("guide_cost", C.c_int32), ("guide_margin", C.c_int32), ("maze_end_iter", C.c_int32),
                 ("stream_per_region", C.c_int32), ("obs_helper_blocks", C.c_int32), ("obs_split_permille", C.c_int32)]
 
 

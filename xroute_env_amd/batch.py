@@ -42,7 +42,8 @@ class RegionBatch:
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
                  obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0,
-                 stream_per_region: bool = False, obs_helper_blocks: int = 0):
+                 stream_per_region: bool = False, obs_helper_blocks: int = 0,
+                 guide_cost: int = 0, guide_margin: int = 0, maze_end_iter: int = 1):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -62,6 +63,7 @@ class RegionBatch:
         cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
         cfg.dial_mult = int(dial_mult)
         cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (-1 default, 0 none)
+        cfg.guide_cost, cfg.guide_margin, cfg.maze_end_iter = int(guide_cost), int(guide_margin), int(maze_end_iter)   # XR-Maze v2
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg
         self._h = C.c_void_p()

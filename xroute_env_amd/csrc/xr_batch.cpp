@@ -165,6 +165,9 @@ void xr_config_default(xr_config* c) {
     c->obs_split_permille = 0;
     c->router = 0;
     c->dial_mult = 0;
+    c->guide_cost = 0;
+    c->guide_margin = 0;
+    c->maze_end_iter = 1;      // ispd/ispd18_test1/run-net-ordering-training.tcl:3 runs 3; XR-Maze v1 = 1
     c->stream_per_region = 0;
     c->obs_helper_blocks = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
@@ -195,6 +198,9 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL || cfg->dial_mult < 0 || cfg->dial_mult > 64)
         return fail(XR_ERR_INVALID, "xr_batch_create: router must be 0, XR_ROUTER_SWEEP or XR_ROUTER_DIAL; dial_mult in 0..64");
+    if (cfg->guide_cost < 0 || cfg->guide_cost >= (1 << 22) || cfg->guide_margin < 0 || cfg->maze_end_iter < 1 || cfg->maze_end_iter > 8 ||
+        ((int64_t)cfg->drc_cost * cfg->drc_unit << (cfg->maze_end_iter - 1)) >= (1 << 22))
+        return fail(XR_ERR_RANGE, "xr_batch_create: guide_cost in [0, 2^22), guide_margin >= 0, maze_end_iter in 1..8 with drc_cost*drc_unit << (maze_end_iter-1) < 2^22");
     if (cfg->stream_per_region < 0 || cfg->stream_per_region > 1 || (cfg->stream_per_region && cfg->n_envs > 64))
         return fail(XR_ERR_RANGE, "xr_batch_create: stream_per_region is 0 or 1 and needs n_envs <= 64");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
@@ -424,7 +430,13 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             b->dial_big = true;
             b->route_lds = big_lds;
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 512;       // (256: 4.2-4.7 ms, 512: 3.7-3.9 ms, config 5)
-        } else if (b->cfg.router == XR_ROUTER_DIAL) {
+        }
+        const bool v2 = b->cfg.guide_cost > 0 || b->cfg.maze_end_iter > 1;
+        if (v2 && b->kzch == -1 && b->lds_dist) b->kzch = -2;          // the instantiation with the XR-Maze v2 knobs compiled in
+        if (v2 && b->kzch != -2)
+            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR-Maze v2 (guide_cost / maze_end_iter) needs the frontier router's LDS form "
+                                      "(regions up to ~9 k nodes, router != XR_ROUTER_SWEEP, no force_scratch_field)");
+        if (b->kzch >= 0 && b->cfg.router == XR_ROUTER_DIAL) {
             return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL: the largest region (%d nodes) exceeds the frontier router's limits", b->n_max);
         }
     }
@@ -539,6 +551,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.touched = b->touched.p; d.records = b->records.p;
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
+    d.guide_cost = b->cfg.guide_cost; d.guide_margin = b->cfg.guide_margin; d.maze_end_iter = b->cfg.maze_end_iter;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000; d.obs_incremental = 0;

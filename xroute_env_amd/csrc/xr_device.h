@@ -123,6 +123,7 @@ struct XrBatchDev {
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     int32_t env_base, env_count;   // route kernel: envs [env_base, env_base + env_count) (env_count 0 = all); stream-per-region mode
+    int32_t guide_cost, guide_margin, maze_end_iter;   // XR-Maze v2 knobs (0, 0, 1 = XR-Maze v1)
     int32_t dial_mult_big;   // the same for the HBM-scratch form
     int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
     double w_violation, w_via, w_wirelength;

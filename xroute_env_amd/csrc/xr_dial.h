@@ -223,6 +223,8 @@ __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_o
 //   wmin[w]  lower bound of the distances of the open nodes of word w (XR_DIAL_INF: none): a round reads ONE word per
 //            lane to know whether any of its ~32 nodes falls into the bucket; only those words are taken and classified.
 // ------------------------------------------------------------------------------------------------
+// V2: XR-Maze v2 knobs compiled in (guide cost, rip-up-and-reroute); the default instantiation carries none of their cost
+template <bool V2>
 __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int e, const int a, char* smem) {
     __shared__ unsigned short s_ap_f[XR_MAX_AP_PER_NET];      // flat node index (the LDS form holds < 64 k nodes)
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
@@ -232,6 +234,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     __shared__ int s_hb[6];                                   // bounding box of the unconnected targets: x, y (coordinates x4), z
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
+    __shared__ int s_gb[4], s_retry;                          // XR-Maze v2: guide box of the net (track indices), rip-up decision
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -270,6 +273,8 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 
     // ---- grid build: field word of every node for THIS net.  node_net / owner rows are padded to multiples of 8
     // elements (16-byte loads); pad slots and blockages become 0.  Loads of four chunks are issued before the first use.
+    // (a lambda: XR-Maze v2 rebuilds the field for every rip-up-and-reroute attempt)
+    auto build_field = [&]() {
     {
         const int nchunk = (N + 7) >> 3;
         for (int c0 = tid; c0 < nchunk; c0 += 4 * nthr) {
@@ -302,7 +307,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
             }
         }
     }
-    for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_claim[i] = 0; s_wmin[i] = XR_DIAL_INF; }
+        for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_claim[i] = 0; s_wmin[i] = XR_DIAL_INF; }
+    };
+    build_field();
     if (tid <= X + 1) s_xc[tid] = my_xc;
     if (tid <= Y + 1) s_yc[tid] = my_yc;
     for (int i = tid + nthr; i <= X + 1; i += nthr)
@@ -311,14 +318,22 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         s_yc[i] = (uint32_t)(b.coords[R.ys_off + min(i - 1, Y - 1)] - b.coords[R.ys_off]) << 2;
     auto el4x = [&](int i) { return s_xc[i + 1] - s_xc[i]; };
     auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
-    if (tid == 0) { s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0; }
+    if (tid == 0) {
+        s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0;
+        s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1;
+    }
     __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
-        s_ap_f[i] = (unsigned short)(i < nthr ? my_ap_f : b.ap_node[R.ap_off + ap_lo + i]);
+        const int apf = i < nthr ? my_ap_f : b.ap_node[R.ap_off + ap_lo + i];
+        s_ap_f[i] = (unsigned short)apf;
         s_ap_pin[i] = (short)pin;
         s_ap_conn[i] = 0;
         atomicMin(&s_first_pin, pin);
+        if (V2 && b.guide_cost) {                // XR-Maze v2: the net's guide = bounding box of all its access points (+ margin)
+            const int gy = (apf / Z) % Y, gx = apf / YZ;
+            atomicMin(&s_gb[0], gx); atomicMax(&s_gb[1], gx); atomicMin(&s_gb[2], gy); atomicMax(&s_gb[3], gy);
+        }
     }
     __syncthreads();
     // a node becomes a source: distance 0, open
@@ -350,14 +365,26 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     XR_LAP(0);
 
     const uint32_t via4 = (uint32_t)b.via_cost << 2;
-    const uint32_t pen4 = (uint32_t)b.pen_cost << 2;
+    uint32_t pen4 = (uint32_t)b.pen_cost << 2;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
     const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;
     const uint32_t uYZ = (uint32_t)YZ, uZ = (uint32_t)Z;
-    int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK;   // thread 0 only
+    int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0;   // thread 0 only
     int nrounds = 0;
-    uint64_t h = (tid == 0) ? b.hash[e] : 0;
+    const uint64_t h0 = (tid == 0) ? b.hash[e] : 0;
+    uint64_t h = h0;
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
+    // XR-Maze v2, neutral by default.  Guide: entering a node outside the net's guide box costs guide_cost.
+    const uint32_t guide4 = V2 ? (uint32_t)b.guide_cost << 2 : 0u;
+    const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
+    auto guide_of = [&](int x, int y) -> uint32_t {
+        if (!V2) return 0u;
+        return (guide4 != 0u && (x < gx0 || x > gx1 || y < gy0 || y > gy1)) ? guide4 : 0u;
+    };
+    // Rip-up and reroute: claims of an attempt are tentative (owner = -a) until the attempt stands
+    const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
+    int attempt = 0;
 
+    for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     for (;;) {
         // ---- new search: sources are open with distance 0; deferred nodes are looked at again ------------
         if (tid == 0) {
@@ -479,9 +506,12 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 #pragma unroll
                         for (int k = 0; k < 4; k++) wn[k] = nf[k] >= 0 ? field[nf[k]] : XR_W_BLOCK;
                         bool refused = false;
-                        uint32_t key[4];
+                        uint32_t key[4], gcost[4];
                         {   // h of the four neighbours (coordinates differ from f's in one component)
                             const int ix = (int)x, iy = (int)y, iz = (int)z;
+                            gcost[0] = vert ? guide_of(ix, iy + 1) : guide_of(ix + 1, iy);
+                            gcost[1] = vert ? guide_of(ix, iy - 1) : guide_of(ix - 1, iy);
+                            gcost[2] = gcost[3] = guide_of(ix, iy);
                             key[0] = vert ? heur(ix, min(iy + 1, Y - 1), iz) : heur(min(ix + 1, X - 1), iy, iz);
                             key[1] = vert ? heur(ix, max(iy - 1, 0), iz) : heur(max(ix - 1, 0), iy, iz);
                             key[2] = heur(ix, iy, min(iz + 1, Z - 1));
@@ -489,7 +519,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         }
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const uint32_t cand4 = d4 + len4[k] + ((wn[k] & 2u) ? pen4 : 0u);
+                            const uint32_t cand4 = d4 + len4[k] + ((wn[k] & 2u) ? pen4 : 0u) + gcost[k];
                             cw[k] = cand4 | (wn[k] & 3u);
                             key[k] += cand4 >> 2;                                 // f = d + h
                             // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
@@ -575,7 +605,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 xr_divmod(ur, uZ, R.magic_z, uy, uz);
                 int x = (int)ux, y = (int)uy, z = (int)uz;
                 while ((vw >> 2) > 0) {
-                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);   // pred distance + edge, x4
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);   // pred distance + edge, x4
                     const bool vert = (ldir >> z) & 1u;
                     int u = -1;
                     uint32_t len4 = 0;
@@ -603,7 +633,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     if (tid == 0) {                 // claim v
                         uint32_t cq, cr;
                         xr_divmod((uint32_t)v, umw, magic_mw, cq, cr);
-                        if (vw & 2u) d_vio += 1;
+                        if (vw & 2u) { d_vio += 1; d_held += 1; }
                         atomicOr(&s_claim[cr], 1u << cq);
                         if (plen < b.path_cap) path[plen] = v;
                         plen++;
@@ -620,7 +650,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 } else if (tid == 0) {
                     // terminal node of the component: claimed (and recorded) only if nobody holds it yet
                     if (owner[v] == 0) {
-                        owner[v] = (int16_t)a;
+                        owner[v] = claim_val;
                         if (plen < b.path_cap) path[plen] = v;
                         plen++;
                         fnv_mix(h, (uint32_t)v);
@@ -650,7 +680,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                             field[f] &= 3u;
                             // claim the path node if nobody holds it (by many threads at once, instead of one dependent
                             // HBM load per node inside the serial back-trace)
-                            if (owner[f] == 0) owner[f] = (int16_t)a;
+                            if (owner[f] == 0) owner[f] = claim_val;
                         }
                     }
                 }
@@ -658,6 +688,29 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         }
         XR_LAP(4);
         // (the barrier at the top of the loop orders these writes before the next search / the exit test)
+    }
+    if (!V2 || b.maze_end_iter <= 1) break;
+    // ---- XR-Maze v2: does the attempt stand?  Its path uses a node held by another net and attempts are left: rip it up ----
+    if (tid == 0) s_retry = (d_held > 0 && attempt + 1 < b.maze_end_iter) ? 1 : 0;
+    __syncthreads();
+    const bool retry = s_retry != 0;
+    for (int f = tid; f < N; f += nthr)                       // tentative claims: accepted (-a -> a) or undone (-a -> 0)
+        if (owner[f] == (int16_t)-a) owner[f] = retry ? (int16_t)0 : (int16_t)a;
+    if (!retry) break;
+    attempt++;
+    pen4 = ((uint32_t)b.pen_cost << 2) << attempt;
+    if (tid == 0) { d_vio = 0; d_wl = 0; d_via = 0; plen = 0; d_held = 0; status = XR_ENV_OK; h = h0; }
+    __syncthreads();                                          // the owner grid is clean again before the field is rebuilt
+    build_field();
+    __syncthreads();
+    for (int i = tid; i < nap; i += nthr) {
+        const bool iso = s_ap_conn[i] == 2;
+        const bool first = s_ap_pin[i] == (short)s_first_pin;
+        s_ap_conn[i] = iso ? 2 : (first ? 1 : 0);
+        if (first && !iso) make_source(s_ap_f[i]);
+    }
+    if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
+    // (the barrier at the top of the search loop orders all of this)
     }
 
     if (tid == 0) {
