@@ -20,14 +20,18 @@ batch = RegionBatch(regions, n_envs=B, auto_reset=True, obs_mode=3, obs_split_pe
 batch.reset(rotate=True)
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
 obs = batch.alloc_observation()
-for i in range(6):
-    batch.random_actions(2024 + i, acts); batch.step(acts, obs)
+inplace = "inplace" in sys.argv
+nsteps = 24                                   # (past the first episode ends: nets-left spread out)
+batch.observation(obs)
+for i in range(nsteps):
+    batch.random_actions(2024 + i, acts); batch.step(acts, obs, inplace=inplace)
 torch.cuda.synchronize()
 ph = batch.fetch("phases").cpu().numpy().astype(np.int64)
 ph = ph[ph[:, 7] == 1]
 k = batch.fetch("nlegal").cpu().numpy().astype(np.float64)
 nn = np.array([regions[int(r)].n_nodes for r in batch.fetch("region").cpu().numpy()], dtype=np.float64)
-nbytes = (4.0 * (2.0 + 7.0 * k) * nn).sum()
+nbytes = (4.0 * (2.0 + 7.0 * k) * nn).sum() if not inplace else (12.0 * nn.sum() + 28.0 * nn.mean() * float(batch.fetch("units").item()))
+print("in-place form" if inplace else "full rewrite", "quota", pm or 750)
 t0 = ph[:, 0].min()
 start, end, last_route = (ph[:, 0] - t0) / 100.0, (ph[:, 1] - t0) / 100.0, (ph[:, 6] - t0) / 100.0
 span = end.max()
