@@ -100,15 +100,25 @@ def _gen_chunk(args):
 
 
 def gen_regions(config, n, first_env=0):
-    """Synthetic regions of a BASELINE config, generated on the host cores (fork pool: call BEFORE touching the GPU)."""
+    """Synthetic regions of a BASELINE config, generated on the host cores (fork pool: call BEFORE touching the GPU).
+    Under a profiler (rocprofv3 preloads its tool into every child and a pool worker that is torn down can hang in the
+    tool's signal handler) the regions are generated in this process."""
     workers = min(os.cpu_count() or 1, 32, max(1, n // 16))
-    if workers <= 1:
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if workers <= 1 or profiled or os.environ.get("XR_BENCH_NO_FORK") == "1":
         return _gen_chunk((config, first_env, first_env + n))
     import multiprocessing as mp
     step = (n + workers - 1) // workers
     chunks = [(config, first_env + lo, first_env + min(lo + step, n)) for lo in range(0, n, step)]
-    with mp.get_context("fork").Pool(workers) as pool:
+    pool = mp.get_context("fork").Pool(workers)
+    try:
         parts = pool.map(_gen_chunk, chunks)
+        pool.close()                      # workers exit on their own (no SIGTERM)
+    except BaseException:
+        pool.terminate()
+        raise
+    finally:
+        pool.join()
     return [r for p in parts for r in p]
 
 

@@ -13,7 +13,7 @@ P3="SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INST_LEVEL_LDS SQ_INSTS_LDS_ATOMIC SQ_
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $R/tools/route_only.py $ENVS $N "$@" > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $R/tools/route_only.py $ENVS $N "$@" > $OUT/p$i.log 2>&1
 done
 python3 $R/tools/pmc_sq_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
