@@ -2,7 +2,7 @@
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = sys.argv[1] if len(sys.argv) > 1 else "4096"
-variants = [(0, 0, 0), (0, 0, 500), (0, 0, 1000), (0, 4, 0), (0, 16, 0), (1, 0, 0), (1, 0, 1000)]
+variants = [(0, 0, 0), (0, 0, 300), (0, 0, 400), (0, 0, 500), (0, 0, 600), (1, 0, 0), (1, 0, 600), (1, 0, 500)]
 res = {}
 for rep in range(2):
     for router, mult, q in variants:

@@ -5,8 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
-tail -3 $OUT/pytest_gpu.log
+if [ -z "$SKIP_PROFILE" ]; then timeout 1400 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
 python - <<PY > $OUT/strong_scaling_one_gpu.json
 import json, subprocess, sys
 rows = []
@@ -21,9 +20,9 @@ python bench.py --agent dqn --envs 1024 --steps 10 --warmup 3 > $OUT/agent_dqn_1
 python bench.py --agent dqn --envs 1024 --steps 10 --warmup 3 --agent-full-obs > $OUT/agent_dqn_1024_full_obs.json 2>/dev/null
 python bench.py --agent ppo --envs 4096 --steps 10 --warmup 3 > $OUT/agent_ppo_4096.json 2>/dev/null
 python tools/config1_probe.py > $OUT/config1_probe.txt 2>&1
-python tools/ab_router.py 4096 > $OUT/ab_router.txt 2>&1
-python tools/ab_step.py 4096 > $OUT/ab_step.txt 2>&1
-bash tools/pmc_sq.sh ${TAG}_sq 4096 6 > $OUT/sq_route.txt 2>&1
+timeout 600 python tools/ab_router.py 4096 > $OUT/ab_router.txt 2>&1
+timeout 600 python tools/ab_step.py 4096 > $OUT/ab_step.txt 2>&1
+XR_BENCH_NO_FORK=1 timeout 900 bash tools/pmc_sq.sh ${TAG}_sq 4096 6 > $OUT/sq_route.txt 2>&1
 python tools/phase_probe.py 1024 0 0 0 > $OUT/phase_probe.txt 2>&1
 python tools/config5_probe.py 1024 64 > $OUT/config5_probe.txt 2>&1
 python tools/phase_probe5.py 256 0 > $OUT/phase_probe5.txt 2>&1
