@@ -480,9 +480,12 @@ def main():
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            same = pj.get("source_sha") == source_sha() and pj.get("bench_args") == bench_args_key(args, world)
-            if same and isinstance(pj.get(dom["kernel"]), dict):
-                traffic = pj[dom["kernel"]].get("hbm_total_bytes")
+            # one entry per measured command (`runs`); the file's top level is the first of them
+            for run in [pj] + list(pj.get("runs", [])):
+                same = run.get("source_sha") == source_sha() and run.get("bench_args") == bench_args_key(args, world)
+                if same and isinstance(run.get(dom["kernel"]), dict):
+                    traffic = run[dom["kernel"]].get("hbm_total_bytes")
+                    break
         except Exception:
             traffic = None
     roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK_GBPS,
