@@ -104,8 +104,9 @@ typedef struct xr_config {
     double  w_wirelength;     /* 0.5  */
     int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer; XR_OBS_QUEUE: workgroups of the
                                   persistent launch (0 = default: 512 / as many as are resident on the chip) */
-    int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = default (XR_ROUTER_DIAL where the
-                                 region fits, else XR_ROUTER_SWEEP), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
+    int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = auto (XR_ROUTER_DIAL wherever it applies;
+                                 only the full-rewrite queue launch of a batch of >= 2048 slots takes XR_ROUTER_SWEEP, measured
+                                 1-2 % faster there), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
                                  worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
     int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 8) */
     int32_t guide_cost;       /* XR-Maze v2 (all three neutral by default = XR-Maze v1): entering a node outside the net's guide costs this

@@ -120,7 +120,9 @@ struct xr_batch {
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net;
     DevBuf<uint32_t> plan_units, queue;
-    int n_cus = 0, queue_blocks = 0;
+    int n_cus = 0, queue_blocks = 0, queue_blocks_sweep = 0;
+    bool sweep_full = false;     // auto router: the full-rewrite queue launch of a large batch takes the line-segment sweeps
+    size_t sweep_lds = 0;
     hipStream_t aux_stream = nullptr;
     std::vector<hipStream_t> region_streams;        // stream-per-region mode
     std::vector<hipEvent_t> region_events;
@@ -406,6 +408,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     const size_t lds_need = (size_t)b->n_lds * 4 + el_bytes + 3 * lw_max * 4 + list_bytes + 16;
     b->lds_dist = lds_need + kLdsStatic <= kLdsLimit && !b->cfg.force_scratch_field;
     b->route_lds = b->lds_dist ? lds_need : el_bytes + 3 * lw_max * 4;
+    const bool sweep_lds_ok = b->lds_dist;
     // workgroup size of the step kernel unless the caller asks: 256 with the field in LDS (4 waves; 4 workgroups per CU
     // resident at 24x40x9), 1024 with the field in HBM scratch (latency-bound on memory: more items in flight per env)
     b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : (b->lds_dist ? 256 : 1024);
@@ -446,9 +449,16 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     const size_t stream_bytes = (size_t)(legal_words * 64 + ((legal_words + 1 + 3) & ~3)) * 4 + (size_t)b->n_max * 2;
     b->stream_ok = stream_bytes <= 60 * 1024;
     b->route_lds = std::max(b->route_lds, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
+    // router = 0 (auto) picks per entry point the scheme measured faster for it: the frontier router everywhere, except the
+    // FULL-rewrite queue launch of a large batch, where the line-segment sweeps are 1-2 % ahead (same box, DESIGN.md §5.1:
+    // 1.74-1.755 ms against 1.77-1.795 ms per 4096-env step; at 512 envs the frontier router wins 0.466 against 0.502 ms)
+    b->sweep_lds = std::max(lds_need, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
+    b->sweep_full = b->cfg.router == 0 && b->kzch == -1 && b->lds_dist && sweep_lds_ok && b->cfg.block_threads == 0 &&
+                    b->cfg.n_envs >= 2048 && b->sweep_lds + kLdsStatic <= kLdsLimit;
     if (b->route_lds + kLdsStatic > kLdsLimit)
         return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
-    if (b->route_lds > 64 * 1024) XR_HIP(xr_route_set_max_lds(b->route_lds));
+    if (std::max(b->route_lds, b->sweep_full ? b->sweep_lds : 0) > 64 * 1024)
+        XR_HIP(xr_route_set_max_lds(std::max(b->route_lds, b->sweep_full ? b->sweep_lds : 0)));
 
     // ---- device allocations ------------------------------------------------------------------
 #define XR_ALLOC(buf, count)                                                                        \
@@ -689,7 +699,11 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
         XR_HIP(xr_launch_plan(&d, actions_dev, st));
-        if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel
+        // which router runs the route tasks of this launch (auto: sweeps for the full rewrite of a large batch, see load)
+        const bool use_sweep = b->sweep_full && !d.obs_incremental;
+        const int kz = use_sweep ? b->zch : b->kzch;
+        const size_t klds = use_sweep ? b->sweep_lds : b->route_lds;
+        if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel (both variants)
             hipDeviceProp_t prop;
             XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
             int per_cu = 0;
@@ -697,8 +711,12 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
             XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, &per_cu, &stat));
             b->n_cus = prop.multiProcessorCount;
             b->queue_blocks = std::max(1, per_cu) * b->n_cus;
+            if (b->sweep_full) {
+                XR_HIP(xr_route_occupancy(1, b->zch, b->sweep_lds, b->route_threads, &per_cu, &stat));
+                b->queue_blocks_sweep = std::max(1, per_cu) * b->n_cus;
+            }
         }
-        const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : b->queue_blocks;
+        const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : (use_sweep ? b->queue_blocks_sweep : b->queue_blocks);
         // helper writers (aligned planes only): LDS-free workgroups on the internal stream draining the same unit queue;
         // forked after the plan, joined before the call returns the stream (events, no host wait)
         const int helpers = d.obs_vec4 == 1 && b->cfg.obs_helper_blocks > 0 ? b->cfg.obs_helper_blocks : 0;
@@ -707,7 +725,7 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
             XR_HIP(hipEventRecord(b->ev_fork, st));
             XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
         }
-        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads,
+        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, kz, klds, b->route_threads,
                                     std::min(blocks, 4 * b->cfg.n_envs), st));
         if (use_helpers) {
             XR_HIP(xr_launch_unit_helpers(&d, helpers, b->aux_stream));
