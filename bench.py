@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--obs-mode", type=int, default=0, help="xr_config.obs_mode: 0 default (queue form where it applies), 1 fused launch, 2 split, 3 queue")
     ap.add_argument("--writer-blocks", type=int, default=0)
     ap.add_argument("--helper-blocks", type=int, default=0, help="xr_config.obs_helper_blocks (0 none = default)")
+    ap.add_argument("--launch-order", type=int, default=0, help="xr_config.launch_order (route-only launches: 0 auto, 1 slot order, 2 longest predicted route first)")
     ap.add_argument("--quota", type=int, default=0, help="xr_config.obs_split_permille (queue form: units per route, per mille of the average)")
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
@@ -289,7 +290,8 @@ def main():
 
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
                         obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
-                        dial_mult=args.dial_mult, obs_helper_blocks=args.helper_blocks, obs_split_permille=args.quota)
+                        dial_mult=args.dial_mult, obs_helper_blocks=args.helper_blocks, obs_split_permille=args.quota,
+                        launch_order=args.launch_order)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()
@@ -437,7 +439,8 @@ def main():
                 kernels.append(kernel_entry("xr_route_kernel", ms, state_bytes, real, "lds-latency",
                                             f"route-only step (xr_batch_step) on the same {B} envs at the same stationary nets-left distribution: "
                                             "the distance field never leaves LDS, so the HBM fraction is ~1 % by construction; "
-                                            "env_steps_per_s is the figure of merit"))
+                                            "the time covers the ordering kernel (longest predicted route first, xr_config.launch_order) "
+                                            "ahead of the route launch; env_steps_per_s is the figure of merit"))
         except Exception as ex:          # a leg must never take the headline down
             kernels.append({"kernel": "xr_route_kernel", "error": str(ex)})
         if fused:
@@ -607,7 +610,8 @@ def agent_leg(args, regions, dev, world):
     B = len(regions)
     torch.manual_seed(0)
     model = (agents.RepActor() if args.agent == "dqn" else agents.ActorCritic(64)).to(dev).eval()
-    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult)
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
+                        launch_order=args.launch_order)
     batch.reset(rotate=True)
     dims = regions[0].dims
     full = args.agent_full_obs
@@ -691,7 +695,8 @@ def config5_leg(args, c5_regions, dev):
     import torch
     from xroute_env_amd.batch import RegionBatch
     Bc = args.c5_envs
-    b5 = RegionBatch(c5_regions, n_envs=Bc, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult)
+    b5 = RegionBatch(c5_regions, n_envs=Bc, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
+                     launch_order=args.launch_order)
     b5.reset()
     a5 = torch.empty(Bc, dtype=torch.int32, device=dev)
     for i in range(2):

@@ -126,6 +126,12 @@ typedef struct xr_config {
                                    writer kernel streams; the step kernel writes the rest after routing (0 = 1000 = all).
                                    XR_OBS_QUEUE: units a workgroup writes after each route task, per mille of the average
                                    number of units per env (0 = 750) */
+    int32_t launch_order;     /* route-only launches (xr_batch_step, xr_batch_step_compact, fused xr_batch_step_observe): order in
+                                 which the env slots are handed to workgroups.  0 = default: longest predicted route first when
+                                 the batch has more slots than the chip holds workgroups (a ~10 us ordering kernel ahead of the
+                                 launch; the prediction is the chosen net's bounding box and pin count), slot order otherwise;
+                                 1 = slot order always; 2 = longest first always.  Results do not depend on it.  (Takes the
+                                 struct's former tail padding: sizeof(xr_config) is unchanged.) */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */
@@ -160,6 +166,7 @@ typedef struct xr_region_desc {
 #define XR_FETCH_TOUCHED  16   /* int32 [B]     nodes whose field word the last route created (HBM-scratch form of the frontier
                                                  router: the work it really did; 0 for the other forms) */
 #define XR_FETCH_UNITS    17   /* uint32[1]     net-plane units (7 planes of one net of one env) the last xr_batch_step_observe* planned */
+#define XR_FETCH_ROUTE_ORDER 18 /* int32[B]     env slots in the order the last longest-first route-only launch handed them out (xr_config.launch_order) */
 #define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
                                                  built with -DXR_PHASE_TIMING) */
 
@@ -238,7 +245,8 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
  * the caller has not written to it, only planes 0..1 and the planes of the remaining nets above the routed one are written
  * (a slot that re-initialises writes everything, a rejected action planes 0..1 only): the buffer ends up byte-identical to
  * what xr_batch_step_observe writes, with about half the HBM traffic under a uniform net choice.  Any other buffer: a full
- * write, exactly xr_batch_step_observe.  xr_batch_observe_timing reports mode | 16 when the in-place path ran. */
+ * write, exactly xr_batch_step_observe.  xr_batch_observe_timing reports mode | 16 when the in-place path ran (and mode | 32
+ * when the auto router ran the line-segment sweeps in the queue launch: full rewrite of a batch of >= 2048 slots). */
 int32_t xr_batch_step_observe_inplace(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                                       void* stream);
 

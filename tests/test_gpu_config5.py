@@ -74,7 +74,7 @@ def test_config5_32_envs_10_steps_match_oracle(router):
     from xroute_env_amd.batch import RegionBatch
     B, STEPS = 32, 10
     regs = config_regions(5, B)
-    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router)
+    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router, launch_order=2 if router == 0 else 0)
     batch.reset()
     ob = orc.OracleBatch(regs)
     threads = ob.max_threads()

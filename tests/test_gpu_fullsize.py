@@ -140,3 +140,61 @@ def test_queue_form_observation_bytes_vs_oracle_with_rotation():
             checked += 1
     assert checked == STEPS * 32
     assert len(set(cur_region)) > 1 and any(cur_region[e] != e % R for e in range(B))     # rotation really happened
+
+
+def test_auto_router_selection_is_invisible_in_the_results():
+    """`router = 0` runs the line-segment sweeps in the full-rewrite queue launch of a batch of >= 2048 slots and the frontier
+    router in every other launch (xr_batch_observe_timing: mode | 32 when the sweeps ran).  Both implement XR-Maze v1 bit for
+    bit, so the selection must not show anywhere: against forced `router = 2` (frontier) and `router = 1` (sweeps) twins, on
+    the same actions — records, hash chains and the full observation buffers are byte-identical over full steps, in-place
+    steps (frontier router again) and route-only steps; the first envs are also replayed on the oracle."""
+    import torch
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import config_regions
+    B, R = 2048, 128
+    regions = config_regions(3, R)
+    twins = {r: RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, router=r) for r in (0, 2, 1)}
+    obs = {}
+    for r, bt in twins.items():
+        bt.reset()
+        obs[r] = bt.alloc_observation()
+    envs = [orc.OracleEnv(regions[e % R]) for e in range(24)]
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    seen = set()
+    for it in range(12):
+        twins[0].random_actions(4242 + it, acts)
+        kind = ("full", "full", "inplace", "route")[it % 4]
+        for r, bt in twins.items():
+            if kind == "route":
+                bt.step(acts)
+            else:
+                bt.step(acts, obs[r], inplace=(kind == "inplace"))
+        if kind != "route":
+            m = {r: bt.observe_timing()[0] for r, bt in twins.items()}
+            seen.add((kind, m[0]))
+            assert m[2] & 32 == 0 and m[1] & 32 == 0              # a forced router never reports the selection bit
+            assert bool(m[0] & 32) == (not (m[0] & 16))            # sweeps <=> the launch rewrote everything
+        rec0 = twins[0].fetch("record").cpu()
+        for r in (2, 1):
+            assert torch.equal(rec0, twins[r].fetch("record").cpu()), (it, r)
+            if kind != "route":
+                assert torch.equal(obs[0], obs[r]), (it, r, kind)
+        rec = twins[0].records()
+        a = acts.cpu().numpy()
+        for e, env in enumerate(envs):
+            if rec["status"][e] & 8:
+                env.reset()
+                continue
+            ref = env.step(int(a[e]))
+            assert list(rec["delta"][e]) == ref["delta"].tolist() and bool(rec["done"][e]) == ref["done"]
+    assert ("full", 3 + 32) in seen                                # the sweeps did run in the full-rewrite launches of router 0
+    assert any(k == "inplace" and m & 16 and not m & 32 for k, m in seen)
+    h0 = twins[0].fetch("hash").cpu()
+    assert torch.equal(h0, twins[2].fetch("hash").cpu()) and torch.equal(h0, twins[1].fetch("hash").cpu())
+    small = RegionBatch(regions, n_envs=512, device="cuda:0", auto_reset=True)       # below the threshold: frontier router
+    small.reset()
+    o = small.alloc_observation()
+    small.random_actions(1, acts[:512])
+    small.step(acts[:512].contiguous(), o)
+    assert small.observe_timing()[0] == 3

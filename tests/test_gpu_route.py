@@ -275,3 +275,79 @@ def test_xr_maze_v2_refused_where_unsupported():
             RegionBatch(regs, device="cuda:0", maze_end_iter=2, **kw)
     with pytest.raises(XRouteError):
         RegionBatch(regs, device="cuda:0", maze_end_iter=9)
+
+
+def _predicted_work(reg, net, via_cost=800):
+    """The launch-order prediction of xr_batch_load_regions for net `net` (1-based) of a region: extent of the net's access
+    points (DBU; a layer of span counted as half a via; + the smallest edge length) times (6 + pins)."""
+    from xroute_env_amd.regions import unpack_records
+    ntype, _, nn, pin = unpack_records(reg.nodes)
+    idx = np.nonzero((ntype == ACCESS) & (nn == net - 1))[0]
+    if len(idx) == 0:
+        return 0.0
+    x, y, z = reg.unflat(idx)
+    xs, ys = np.asarray(reg.xs, np.int64), np.asarray(reg.ys, np.int64)
+    w_min = min([via_cost] + np.diff(xs).tolist() + np.diff(ys).tolist())
+    ext = (xs[x].max() - xs[x].min()) + (ys[y].max() - ys[y].min()) + 0.5 * via_cost * (z.max() - z.min()) + w_min
+    return float(ext) * (6 + len(set(pin[idx].tolist())))
+
+
+def test_longest_first_launch_order_parity_and_order():
+    """xr_config.launch_order = 2: an ordering kernel hands the env slots to the route kernel longest-predicted-first.  Results
+    are the oracle's as before (whole episodes, every field), the order is a permutation of the slots, predicted work is
+    non-increasing along it (within one of the 255 classes), and slots with nothing to route come last."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(3100 + i) for i in range(24)]
+    assert _run_episode_parity(regions, policy="random", launch_order=2) > 150
+    batch = RegionBatch(regions, device="cuda:0", launch_order=2)
+    batch.reset()
+    legal = batch.legal_sets()
+    rng = np.random.default_rng(9)
+    acts = [int(rng.choice(sorted(s))) for s in legal]
+    acts[3] = 0                                                    # nothing to route: out of range
+    acts[7] = 1 + max(r.n_nets for r in regions)                  # out of range for its region
+    batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+    order = batch.fetch("route_order").cpu().numpy()
+    assert sorted(order.tolist()) == list(range(24))
+    assert set(order[-2:].tolist()) == {3, 7}
+    wmax = max(_predicted_work(r, n) for r in regions for n in range(1, r.n_nets + 1))
+    w = [_predicted_work(regions[e], acts[e]) for e in order[:-2]]
+    for i in range(len(w) - 1):
+        assert w[i] >= w[i + 1] - 1.01 * wmax / 254, (i, w[i], w[i + 1])
+    assert w[0] > w[-1]
+    # the default (0) keeps slot order for a batch the chip holds at once: same results, order buffer untouched
+    plain = RegionBatch(regions, device="cuda:0")
+    plain.reset()
+    plain.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+    assert torch.equal(plain.fetch("hash"), batch.fetch("hash")) and torch.equal(plain.fetch("record"), batch.fetch("record"))
+    assert plain.fetch("route_order").abs().sum().item() == 0
+
+
+def test_longest_first_order_on_a_multi_round_batch():
+    """Default launch order on a batch with more slots than resident workgroups (8192 small envs): longest-first is on by
+    itself; records, hash chains and compact head planes equal the slot-order twin over steps with resets and rejected actions."""
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(3300 + i, dims=(12, 10, 4), k_range=(2, 6)) for i in range(64)]
+    B = 8192
+    twins = [RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, launch_order=lo) for lo in (0, 1)]
+    heads = []
+    for t in twins:
+        t.reset()
+        heads.append(t.alloc_head())
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    for it in range(14):
+        twins[1].random_actions(77 + it, acts)
+        if it % 5 == 4:
+            acts[::7] = 99                                         # rejected
+        for t, h in zip(twins, heads):
+            if it % 2:
+                t.step_compact(acts, h)
+            else:
+                t.step(acts)
+        assert torch.equal(twins[0].fetch("record"), twins[1].fetch("record")), it
+        if it % 2:
+            assert torch.equal(heads[0], heads[1]), it
+    assert torch.equal(twins[0].fetch("hash"), twins[1].fetch("hash"))
+    order = twins[0].fetch("route_order").cpu().numpy()
+    assert sorted(order.tolist()) == list(range(B)) and not np.array_equal(order, np.arange(B))
+    assert twins[1].fetch("route_order").abs().sum().item() == 0

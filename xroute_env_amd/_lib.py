@@ -19,7 +19,8 @@ XR_OWNER_FOREIGN = 0x7FFF
 
 (XR_FETCH_CUM, XR_FETCH_DELTA, XR_FETCH_REWARD, XR_FETCH_DONE, XR_FETCH_NLEGAL, XR_FETCH_STATUS,
  XR_FETCH_LEGAL, XR_FETCH_PATH_LEN, XR_FETCH_PATH, XR_FETCH_OWNER, XR_FETCH_HASH, XR_FETCH_REGION,
- XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD, XR_FETCH_TOUCHED, XR_FETCH_UNITS) = range(18)
+ XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD, XR_FETCH_TOUCHED, XR_FETCH_UNITS,
+ XR_FETCH_ROUTE_ORDER) = range(19)
 
 # every symbol include/xroute_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -38,7 +39,8 @@ class XrConfig(C.Structure):
                 ("w_violation", C.c_double), ("w_via", C.c_double), ("w_wirelength", C.c_double),
                 ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
                 ("guide_cost", C.c_int32), ("guide_margin", C.c_int32), ("maze_end_iter", C.c_int32),
-                ("stream_per_region", C.c_int32), ("obs_helper_blocks", C.c_int32), ("obs_split_permille", C.c_int32)]
+                ("stream_per_region", C.c_int32), ("obs_helper_blocks", C.c_int32), ("obs_split_permille", C.c_int32),
+                ("launch_order", C.c_int32)]
 
 
 class XrStepRecord(C.Structure):          # include/xroute_hip.h xr_step_record (48 bytes)

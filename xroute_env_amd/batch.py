@@ -42,7 +42,7 @@ class RegionBatch:
                  max_route_count: int = 10, path_cap: int = 0, block_threads: int = 0,
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
                  obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0,
-                 stream_per_region: bool = False, obs_helper_blocks: int = 0,
+                 stream_per_region: bool = False, obs_helper_blocks: int = 0, launch_order: int = 0,
                  guide_cost: int = 0, guide_margin: int = 0, maze_end_iter: int = 1):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
@@ -62,6 +62,7 @@ class RegionBatch:
         cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
         cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
         cfg.dial_mult = int(dial_mult)
+        cfg.launch_order = int(launch_order)             # route-only launches: 0 auto, 1 slot order, 2 longest predicted route first
         cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (-1 default, 0 none)
         cfg.guide_cost, cfg.guide_margin, cfg.maze_end_iter = int(guide_cost), int(guide_margin), int(maze_end_iter)   # XR-Maze v2
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
@@ -266,6 +267,7 @@ class RegionBatch:
         "sweeps": (_lib.XR_FETCH_SWEEPS, torch.int32, lambda s: (s.n_envs,)),
         "phases": (_lib.XR_FETCH_PHASES, torch.int64, lambda s: (s.n_envs, 8)),
         "units": (_lib.XR_FETCH_UNITS, torch.int32, lambda s: (1,)),
+        "route_order": (_lib.XR_FETCH_ROUTE_ORDER, torch.int32, lambda s: (s.n_envs,)),
         "touched": (_lib.XR_FETCH_TOUCHED, torch.int32, lambda s: (s.n_envs,)),
         "record": (_lib.XR_FETCH_RECORD, torch.uint8, lambda s: (s.n_envs, _lib.RECORD_BYTES)),
     }

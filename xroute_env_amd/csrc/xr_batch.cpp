@@ -22,6 +22,7 @@ hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_route_occupancy(int, int, size_t, int, int*, size_t*);
 hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
+hipError_t xr_launch_route_order(const XrBatchDev*, const int32_t*, int32_t*, hipStream_t);
 hipError_t xr_launch_step_queue(const XrBatchDev*, const int32_t*, int, int, size_t, int, int, hipStream_t);
 hipError_t xr_launch_netplanes(const XrBatchDev*, int, int, hipStream_t);
 hipError_t xr_launch_order(const XrBatchDev*, const int32_t*, int, int32_t*, int, int, size_t, int, hipStream_t);
@@ -105,7 +106,9 @@ struct xr_batch {
     DevBuf<int16_t> ap_pin;
     DevBuf<uint64_t> legal0;
     // envs
-    DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps, touched;
+    DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps, touched, route_order;
+    DevBuf<uint8_t> net_work;
+    int route_slots = 0;         // workgroups of the route kernel the chip holds at once (0: not asked yet)
     DevBuf<int16_t> owner;
     DevBuf<uint64_t> legal, hash;
     DevBuf<double> reward;
@@ -129,6 +132,7 @@ struct xr_batch {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
     int last_obs_mode = 0;
     int last_obs_inplace = 0;
+    int last_obs_sweeps = 0;
     const float* obs_valid_ptr = nullptr;       // buffer that holds the current observation of ALL env slots (in-place form)
     int64_t obs_valid_stride = 0;
     XrBatchDev dev{};
@@ -172,6 +176,7 @@ void xr_config_default(xr_config* c) {
     c->maze_end_iter = 1;      // ispd/ispd18_test1/run-net-ordering-training.tcl:3 runs 3; XR-Maze v1 = 1
     c->stream_per_region = 0;
     c->obs_helper_blocks = 0;
+    c->launch_order = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -196,6 +201,7 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_INVALID, "xr_batch_create: via_cost >= 1, drc_cost/drc_unit >= 0, max_route_count >= 1");
     if ((int64_t)cfg->drc_cost * cfg->drc_unit >= (1 << 22) || cfg->via_cost >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: via_cost and drc_cost*drc_unit must be < 2^22");
+    if (cfg->launch_order < 0 || cfg->launch_order > 2) return fail(XR_ERR_INVALID, "xr_batch_create: launch_order must be 0, 1 or 2");
     if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_QUEUE || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
     if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL || cfg->dial_mult < 0 || cfg->dial_mult > 64)
@@ -242,6 +248,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<uint32_t> hrec;
     std::vector<int32_t> hcoords, hcsr, hap_node, hap_feat;
     std::vector<int16_t> hap_pin;
+    std::vector<float> hwork;            // per (region, net): predicted route work (launch order of route-only launches)
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
@@ -336,6 +343,29 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                 const bool adj = (x + 1 < d.dim_x && net_of(f + YZd) == n) || (y > 0 && net_of(f - Zd) == n) || (x > 0 && net_of(f - YZd) == n) ||
                                  (y + 1 < Yd && net_of(f + Zd) == n) || (z + 1 < Zd && net_of(f + 1) == n) || (z > 0 && net_of(f - 1) == n);
                 hap_feat[i] = f | (adj ? (int32_t)0x80000000 : 0);
+            }
+        }
+        // predicted work of routing net n: extent of its access points (DBU; a layer of span counted as half a via) times
+        // (6 + pins) — the shape tools/lpt_probe.py fitted; only the ORDER of these numbers matters
+        hwork.resize(hcsr.size(), 0.0f);
+        {
+            const int Yd = d.dim_y, Zd = d.dim_z, YZd = Yd * Zd;
+            for (int n = 1; n <= d.n_nets; n++) {
+                const int lo = cnt[n], hi = cnt[n + 1];
+                if (hi <= lo) continue;
+                int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1, z0 = 1 << 30, z1 = -1;
+                uint64_t pins[4] = {0, 0, 0, 0};
+                int npins = 0;
+                for (int i = lo; i < hi; i++) {
+                    const int f = hap_node[base + i], z = f % Zd, y = (f / Zd) % Yd, x = f / YZd;
+                    x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y);
+                    z0 = std::min(z0, z); z1 = std::max(z1, z);
+                    const int pn = hap_pin[base + i] & 255;
+                    if (!((pins[pn >> 6] >> (pn & 63)) & 1)) { pins[pn >> 6] |= 1ull << (pn & 63); npins++; }
+                }
+                const double ext = (double)(d.xs_host[x1] - d.xs_host[x0]) + (double)(d.ys_host[y1] - d.ys_host[y0]) +
+                                   0.5 * b->cfg.via_cost * (z1 - z0) + R.w_min;
+                hwork[R.net_off + n] = (float)(ext * (6 + npins));
             }
         }
         n_max_nodes = std::max(n_max_nodes, N);
@@ -488,6 +518,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->path_len, B);
     XR_ALLOC(b->sweeps, B);
     XR_ALLOC(b->touched, B);
+    XR_ALLOC(b->route_order, B);
+    XR_ALLOC(b->net_work, hcsr.size());
     XR_ALLOC(b->owner, (size_t)B * b->n_max);
     XR_ALLOC(b->legal, (size_t)B * legal_words);
     XR_ALLOC(b->hash, B);
@@ -518,6 +550,14 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemcpyAsync(b->rg_rec.p, hrec.data(), hrec.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     XR_HIP(hipMemcpyAsync(b->coords.p, hcoords.data(), hcoords.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     XR_HIP(hipMemcpyAsync(b->net_csr.p, hcsr.data(), hcsr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    std::vector<uint8_t> hclass(hcsr.size(), 0);        // work classes 1..255 relative to the batch's largest prediction
+    {
+        float wmax = 1.0f;
+        for (float w : hwork) wmax = std::max(wmax, w);
+        for (size_t i = 0; i < hwork.size(); i++)
+            if (hwork[i] > 0.0f) hclass[i] = (uint8_t)(1 + std::min(254, (int)(254.0f * hwork[i] / wmax)));
+    }
+    XR_HIP(hipMemcpyAsync(b->net_work.p, hclass.data(), hclass.size(), hipMemcpyHostToDevice, st));
     if (!hap_node.empty()) {
         XR_HIP(hipMemcpyAsync(b->ap_node.p, hap_node.data(), hap_node.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         XR_HIP(hipMemcpyAsync(b->ap_pin.p, hap_pin.data(), hap_pin.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
@@ -533,6 +573,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_HIP(hipMemsetAsync(b->phase_cycles.p, 0, (size_t)B * 8 * sizeof(long long), st));
     XR_HIP(hipMemsetAsync(b->nlegal.p, 0, (size_t)B * sizeof(int32_t), st));
     XR_HIP(hipMemsetAsync(b->touched.p, 0, (size_t)B * sizeof(int32_t), st));
+    XR_HIP(hipMemsetAsync(b->route_order.p, 0, (size_t)B * sizeof(int32_t), st));
     XR_HIP(hipMemsetAsync(b->records.p, 0, (size_t)B * sizeof(XrStepRecord), st));
     XR_HIP(hipMemsetAsync(b->owner.p, 0, (size_t)B * b->n_max * sizeof(int16_t), st));
     XR_HIP(hipMemsetAsync(b->path.p, 0, (size_t)B * b->path_cap * sizeof(int32_t), st));
@@ -552,7 +593,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     XrBatchDev& d = b->dev;
     d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
-    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p;
+    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p; d.net_work = b->net_work.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
     d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.lw_max = (int)lw_max; d.lines_max = lines_max; d.x_max = x_max; d.y_max = y_max; d.legal_words = legal_words; d.path_cap = b->path_cap;
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
@@ -622,7 +663,27 @@ namespace {
 // (fork from / join to the caller's stream with events; the host never waits).
 int32_t launch_route_form(xr_batch* b, const XrBatchDev& d, const int32_t* actions_dev, hipStream_t st) {
     if (!b->cfg.stream_per_region) {
-        XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
+        // launch order: longest predicted route first when the launch runs in more than one round of workgroups
+        bool lpt = b->cfg.launch_order == 2;
+        if (b->cfg.launch_order == 0) {
+            if (b->route_slots == 0) {
+                hipDeviceProp_t prop;
+                XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
+                int per_cu = 0;
+                size_t stat = 0;
+                XR_HIP(xr_route_occupancy(b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, &per_cu, &stat));
+                b->route_slots = std::max(1, per_cu) * prop.multiProcessorCount;
+            }
+            lpt = b->cfg.n_envs > b->route_slots;
+        }
+        if (!lpt) {
+            XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
+            return XR_OK;
+        }
+        XrBatchDev dl = d;
+        XR_HIP(xr_launch_route_order(&dl, actions_dev, b->route_order.p, st));
+        dl.route_order = b->route_order.p;
+        XR_HIP(xr_launch_route(&dl, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
         return XR_OK;
     }
     const int B = b->cfg.n_envs;
@@ -699,8 +760,11 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
         XR_HIP(xr_launch_plan(&d, actions_dev, st));
+        // (route tasks in slot order: longest-first measured SLOWER in the queue forms, full rewrite 1.72 -> 1.83 ms, in-place
+        //  1.06 -> 1.09 ms — the launch is bound by its write stream, and long routes up front delay the first units)
         // which router runs the route tasks of this launch (auto: sweeps for the full rewrite of a large batch, see load)
         const bool use_sweep = b->sweep_full && !d.obs_incremental;
+        b->last_obs_sweeps = use_sweep ? 1 : 0;
         const int kz = use_sweep ? b->zch : b->kzch;
         const size_t klds = use_sweep ? b->sweep_lds : b->route_lds;
         if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel (both variants)
@@ -804,7 +868,8 @@ int32_t xr_batch_route_occupancy(xr_batch* b, int32_t* workgroups_per_cu, int64_
 
 int32_t xr_batch_observe_timing(xr_batch* b, int32_t* mode_out, float* writer_ms) {
     if (!b || !mode_out || !writer_ms) return fail(XR_ERR_INVALID, "xr_batch_observe_timing: null argument");
-    *mode_out = b->last_obs_mode + (b->last_obs_mode == XR_OBS_QUEUE && b->last_obs_inplace ? 16 : 0);    // bit 4: the in-place form ran
+    *mode_out = b->last_obs_mode + (b->last_obs_mode == XR_OBS_QUEUE && b->last_obs_inplace ? 16 : 0)     // bit 4: the in-place form ran
+                + (b->last_obs_mode == XR_OBS_QUEUE && b->last_obs_sweeps ? 32 : 0);                // bit 5: auto router took the sweeps
     *writer_ms = 0.f;
     if (b->last_obs_mode == XR_OBS_SPLIT) {
         XR_HIP(hipSetDevice(b->cfg.device));
@@ -875,6 +940,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_UNITS: src = b->queue.p + 2; bytes = sizeof(uint32_t); break;
+    case XR_FETCH_ROUTE_ORDER: src = b->route_order.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_TOUCHED: src = b->touched.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;
     case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;

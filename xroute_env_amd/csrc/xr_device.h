@@ -69,6 +69,7 @@ struct XrBatchDev {
     const int16_t* ap_pin;   // pin + 1
     const int32_t* ap_feat;  // node index | (the access point has an axis neighbour that is an access point of the same net) << 31
     const uint64_t* legal0;
+    const uint8_t* net_work; // [like net_csr] predicted route work class of net n of a region (1..255; 0 = no access points), static
     int32_t n_regions;
     // envs (mutable)
     int32_t n_envs;
@@ -122,6 +123,7 @@ struct XrBatchDev {
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
+    const int32_t* route_order;   // route kernel: workgroup i routes env route_order[i] (null: env_base + i); longest predicted first
     int32_t env_base, env_count;   // route kernel: envs [env_base, env_base + env_count) (env_count 0 = all); stream-per-region mode
     int32_t guide_cost, guide_margin, maze_end_iter;   // XR-Maze v2 knobs (0, 0, 1 = XR-Maze v1)
     int32_t dial_mult_big;   // the same for the HBM-scratch form
