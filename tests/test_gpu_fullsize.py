@@ -144,7 +144,7 @@ def test_queue_form_observation_bytes_vs_oracle_with_rotation():
 
 def test_auto_router_selection_is_invisible_in_the_results():
     """`router = 0` runs the line-segment sweeps in the full-rewrite queue launch of a batch of >= 2048 slots and the frontier
-    router in every other launch (xr_batch_observe_timing: mode | 32 when the sweeps ran).  Both implement XR-Maze v1 bit for
+    router in every other launch (xr_batch_observe_timing: mode | 32 when the sweeps ran; RegionBatch.observe_info).  Both implement XR-Maze v1 bit for
     bit, so the selection must not show anywhere: against forced `router = 2` (frontier) and `router = 1` (sweeps) twins, on
     the same actions — records, hash chains and the full observation buffers are byte-identical over full steps, in-place
     steps (frontier router again) and route-only steps; the first envs are also replayed on the oracle."""
@@ -171,10 +171,11 @@ def test_auto_router_selection_is_invisible_in_the_results():
             else:
                 bt.step(acts, obs[r], inplace=(kind == "inplace"))
         if kind != "route":
-            m = {r: bt.observe_timing()[0] for r, bt in twins.items()}
-            seen.add((kind, m[0]))
-            assert m[2] & 32 == 0 and m[1] & 32 == 0              # a forced router never reports the selection bit
-            assert bool(m[0] & 32) == (not (m[0] & 16))            # sweeps <=> the launch rewrote everything
+            m = {r: bt.observe_info() for r, bt in twins.items()}
+            seen.add((kind, m[0]["inplace"], m[0]["sweeps"]))
+            assert not m[2]["sweeps"] and not m[1]["sweeps"]       # a forced router never reports the selection
+            assert m[0]["sweeps"] == (not m[0]["inplace"])         # sweeps <=> the launch rewrote everything
+            assert all(v["form"] == 3 for v in m.values())
         rec0 = twins[0].fetch("record").cpu()
         for r in (2, 1):
             assert torch.equal(rec0, twins[r].fetch("record").cpu()), (it, r)
@@ -188,8 +189,8 @@ def test_auto_router_selection_is_invisible_in_the_results():
                 continue
             ref = env.step(int(a[e]))
             assert list(rec["delta"][e]) == ref["delta"].tolist() and bool(rec["done"][e]) == ref["done"]
-    assert ("full", 3 + 32) in seen                                # the sweeps did run in the full-rewrite launches of router 0
-    assert any(k == "inplace" and m & 16 and not m & 32 for k, m in seen)
+    assert ("full", False, True) in seen                           # the sweeps did run in the full-rewrite launches of router 0
+    assert ("inplace", True, False) in seen
     h0 = twins[0].fetch("hash").cpu()
     assert torch.equal(h0, twins[2].fetch("hash").cpu()) and torch.equal(h0, twins[1].fetch("hash").cpu())
     small = RegionBatch(regions, n_envs=512, device="cuda:0", auto_reset=True)       # below the threshold: frontier router
@@ -197,4 +198,4 @@ def test_auto_router_selection_is_invisible_in_the_results():
     o = small.alloc_observation()
     small.random_actions(1, acts[:512])
     small.step(acts[:512].contiguous(), o)
-    assert small.observe_timing()[0] == 3
+    assert small.observe_info() == {"form": 3, "inplace": False, "sweeps": False, "writer_ms": 0.0}

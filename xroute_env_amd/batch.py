@@ -192,7 +192,15 @@ class RegionBatch:
         net-plane writer running concurrently); writer_ms = HIP-event duration of the writer kernel (0 when fused)."""
         mode, ms = C.c_int32(0), C.c_float(0.0)
         _lib.check(self.L.xr_batch_observe_timing(self._h, C.byref(mode), C.byref(ms)))
-        return int(mode.value), float(ms.value)
+        return int(mode.value) & ~32, float(ms.value)       # (form | 16 when the in-place path ran; bit 5: see observe_info)
+
+    def observe_info(self) -> dict:
+        """The last step(actions, obs_out) in words: form (1 fused, 2 split, 3 queue), whether the in-place path ran, and
+        whether the auto router ran the line-segment sweeps in that launch (full rewrite of a batch of >= 2048 slots)."""
+        mode, ms = C.c_int32(0), C.c_float(0.0)
+        _lib.check(self.L.xr_batch_observe_timing(self._h, C.byref(mode), C.byref(ms)))
+        m = int(mode.value)
+        return {"form": m & 15, "inplace": bool(m & 16), "sweeps": bool(m & 32), "writer_ms": float(ms.value)}
 
     def route_order(self, orders: torch.Tensor, net_stats: Optional[torch.Tensor] = None):
         """Whole-order re-route (xr_batch_route_order): every env restarts its region and routes
