@@ -1,8 +1,8 @@
-"""Interleaved A/B of two library builds on ONE box: python tools/ab_lib.py libA.so libB.so [envs] -> (step, route-only, in-place) ms."""
+"""Interleaved A/B of library builds on ONE box: python tools/ab_lib.py libA.so libB.so ... [envs] -> (step, route-only, in-place) ms."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = sys.argv[1:3]
-B = sys.argv[3] if len(sys.argv) > 3 else "4096"
+libs = [a for a in sys.argv[1:] if not a.isdigit()]
+B = ([a for a in sys.argv[1:] if a.isdigit()] or ["4096"])[0]
 res = {}
 for rep in range(3):
     for lib in libs:
