@@ -11,8 +11,9 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 regions = config_regions(cfg, 128 if cfg == 5 else 512)
 res = {}
 mults = [int(v) for v in os.environ.get("XR_MULTS", "0").split(",")]
+threads = int(os.environ.get("XR_THREADS", "0"))
 for order, mult in [(o, m) for m in mults for o in ((1, 2, 0, 1, 2) if len(mults) == 1 else (2, 1, 2))]:
-    batch = RegionBatch(regions, n_envs=B, auto_reset=True, launch_order=order, dial_mult=mult)
+    batch = RegionBatch(regions, n_envs=B, auto_reset=True, launch_order=order, dial_mult=mult, block_threads=threads)
     batch.reset()
     acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
     n_warm, n = (3, 10) if cfg == 5 else (12, 30)
@@ -27,5 +28,5 @@ for order, mult in [(o, m) for m in mults for o in ((1, 2, 0, 1, 2) if len(mults
     h = batch.fetch("hash").cpu()
     res.setdefault("hash", h)
     assert torch.equal(h, res["hash"]), "launch order changed results"
-    print(f"config {cfg} {B} envs launch_order={order} dial_mult={mult}: median {ms[n // 2]:.4f} ms  min {ms[0]:.4f}  mean {sum(ms) / n:.4f}  -> {B / ms[n // 2] * 1e3:.0f} env-slots/s")
+    print(f"config {cfg} {B} envs launch_order={order} dial_mult={mult} threads={threads}: median {ms[n // 2]:.4f} ms  min {ms[0]:.4f}  mean {sum(ms) / n:.4f}  -> {B / ms[n // 2] * 1e3:.0f} env-slots/s")
     del batch
