@@ -324,11 +324,11 @@ def test_longest_first_launch_order_parity_and_order():
 
 
 def test_longest_first_order_on_a_multi_round_batch():
-    """Default launch order on a batch with more slots than resident workgroups (8192 small envs): longest-first is on by
-    itself; records, hash chains and compact head planes equal the slot-order twin over steps with resets and rejected actions."""
+    """Default launch order on a batch with more slots than resident workgroups (9000 small envs; more than the 8 slots per
+    thread the ordering kernel keeps in registers): longest-first is on by itself; records, hash chains and compact head planes equal the slot-order twin over steps with resets and rejected actions."""
     from xroute_env_amd.batch import RegionBatch
     regions = [generate_region(3300 + i, dims=(12, 10, 4), k_range=(2, 6)) for i in range(64)]
-    B = 8192
+    B = 9000
     twins = [RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, launch_order=lo) for lo in (0, 1)]
     heads = []
     for t in twins:
