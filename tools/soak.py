@@ -2,10 +2,11 @@
 CPU oracle stepped with the same actions; compares deltas, done flags and rewards every step and every env's hash
 chain (every path node of every step) at the end.
 
-    python tools/soak.py [B=4096] [STEPS=300] [config=3] [obs]
+    python tools/soak.py [B=4096] [STEPS=300] [config=3] [obs|inplace]
 
 With `obs` the GPU steps with its observation (xr_batch_step_observe, default form) and the observations of 32 envs
-(a different set every step) are compared byte for byte with the oracle's.
+(a different set every step) are compared byte for byte with the oracle's; `inplace` does the same through the in-place
+form (xr_batch_step_observe_inplace: only the planes that change are written into the persistent buffer).
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +17,9 @@ from xroute_env_amd.regions import config_regions
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-with_obs = len(sys.argv) > 4 and sys.argv[4] == "obs"
+with_obs = len(sys.argv) > 4 and sys.argv[4] in ("obs", "inplace")
+inplace = len(sys.argv) > 4 and sys.argv[4] == "inplace"
+n_inplace = 0
 regions = config_regions(cfg, B)
 batch = RegionBatch(regions, n_envs=B, auto_reset=True)
 ob = orc.OracleBatch(regions)
@@ -29,7 +32,11 @@ t0 = time.time(); real = 0
 for it in range(STEPS):
     batch.random_actions(4242 + it, acts)
     a = acts.cpu().numpy()
-    batch.step(acts, obs)
+    if inplace:
+        batch.step(acts, obs, inplace=True)
+        n_inplace += batch.observe_info()["inplace"]
+    else:
+        batch.step(acts, obs)
     r = ob.step(a, threads=threads, auto_reset=True)
     if with_obs:
         for e in range((it * 37) % 128, B, 128):
@@ -47,5 +54,5 @@ ref = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
 ok = np.array_equal(hashes, ref) and batch.total_steps() == real
 print(f"soak config {cfg}: {B} envs x {STEPS} steps = {real} env-steps in {time.time()-t0:.0f}s, {threads} oracle threads: "
       f"deltas/done/reward equal every step, hash chains equal: {ok}"
-      + (f", {obs_checked} observations byte-equal (form {batch.observe_timing()[0]})" if with_obs else ""))
+      + (f", {obs_checked} observations byte-equal (form {batch.observe_timing()[0] & 15}" + (f", in-place path in {n_inplace} of {STEPS} steps" if inplace else "") + ")" if with_obs else ""))
 sys.exit(0 if ok else 1)
