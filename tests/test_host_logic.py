@@ -66,3 +66,21 @@ def test_reward_formula_matches_reference_values():
     for t in load_json("g4_reward.json"):
         r = reward_from_deltas(t["violation"], t["wirelength"], t["via"])
         assert float(r).hex() == t["reward_hex"]
+
+
+def test_recorded_pmc_traffic_file_is_quotable():
+    """bench.py quotes profiles/pmc_traffic.json as `roofline.traffic` only for the same kernel sources AND the same command:
+    every recorded run (top level + `runs`) must carry both identities and the step kernel's byte counts, and traffic must
+    stay close to the algorithmic bytes it is compared with."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pj = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    runs = [pj] + list(pj.get("runs", []))
+    assert len({json.dumps(r["bench_args"], sort_keys=True) for r in runs}) == len(runs)       # one entry per command
+    for r in runs:
+        assert isinstance(r.get("source_sha"), str) and len(r["source_sha"]) == 16
+        assert set(r["bench_args"]) >= {"gpus", "steps", "warmup", "envs", "global_envs", "config", "seed", "router", "obs_mode", "no_stagger"}
+        k = r["xr_step_queue_kernel"]
+        assert k["hbm_total_bytes"] == pytest.approx(k["hbm_read_bytes"] + k["hbm_write_bytes"])
+        assert 0.98 < k["hbm_total_bytes"] / k["algorithmic_bytes"] < 1.10
