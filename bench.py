@@ -422,6 +422,28 @@ def main():
     dom = max(kernels, key=lambda k: k["ms"])
 
     # ---- extra legs (rank 0, N = 1): route-only kernel and BASELINE config 5, each with its own numbers ---------------
+    sustained = None
+    if do_legs and fused and not args.no_extras:
+        try:        # the timed region is tens of milliseconds: the same step for ~1 s more, so that clocks / thermals show
+            n_s = 500
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_s // 100 + 1)]
+            torch.cuda.synchronize(dev)
+            s0, t_s = batch.total_steps(), time.perf_counter()
+            for i in range(n_s):
+                if i % 100 == 0:
+                    marks[i // 100].record()
+                batch.random_actions(args.seed + 200000 + i, acts)
+                batch.step(acts, obs)
+            marks[-1].record()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t_s
+            sustained = {"steps": n_s, "seconds": round(el, 4), "value": round((batch.total_steps() - s0) / el, 1), "unit": "env-steps/s",
+                         "ms_per_step": round(el / n_s * 1e3, 4),
+                         "ms_per_step_by_100": [round(marks[j].elapsed_time(marks[j + 1]) / 100, 4) for j in range(n_s // 100)],
+                         "what": "the headline step (random actions + xr_batch_step_observe, full rewrite) for 500 more batched steps right after "
+                                 "the timed region, host wall clock; never part of `value`"}
+        except Exception as ex:
+            sustained = {"error": str(ex)}
     if do_legs:
         try:
             n_leg = max(args.steps, 5)
@@ -540,6 +562,8 @@ def main():
                 out["parity"] = {"error": str(ex)}
         if do_legs and not args.no_extras:
             out["extras"] = extras_leg(args, regions, dev, batch, obs)
+            if sustained is not None:
+                out["extras"]["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=obs is not None)

@@ -46,6 +46,9 @@ def test_bench_json_contract(extra):
         # driver-visible side numbers: BASELINE config 1 latency and config 3 with the DQN counterpart attached
         ex = d["extras"]
         assert ex["config1_game_step"]["ms_median"] > 0 and ex["config3_dqn_attached"]["value"] > 0, ex
+        # ~1 s of the same step after the timed region (clocks / thermals visible); never part of `value`
+        su = ex["sustained"]
+        assert su["steps"] == 500 and su["value"] > 0 and len(su["ms_per_step_by_100"]) == 5 and min(su["ms_per_step_by_100"]) > 0
     p = d["parity"]                                  # the checker leg: oracle replay of the run's own actions
     assert p["hash_chains_equal"] is True and p["cumulative_metrics_equal"] is True and p["env_steps"] > 0 and p["envs"] == 256
     # value is consistent with the reported step time: real env-steps <= slots
