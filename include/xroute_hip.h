@@ -115,7 +115,7 @@ typedef struct xr_config {
     int32_t guide_margin;
     int32_t maze_end_iter;    /* >= 1 (`-maze_end_iter 3 -ripup_mode 1` of the same line): attempt t routes the net with the penalty
                                  drc_cost*drc_unit << t; an attempt whose path uses a node held by another net is ripped up unless it is
-                                 the last one.  Frontier router, LDS form only (XR_ERR_RANGE otherwise) */
+                                 the last one.  Frontier router only (XR_ROUTER_SWEEP: XR_ERR_RANGE) */
     int32_t stream_per_region; /* 1: "one region per stream" (north_star's first partition): xr_batch_step / _step_observe (fused
                                   form) / _step_compact launch ONE single-workgroup kernel per env slot, round-robin over a pool of
                                   internal HIP streams, joined to the caller's stream by events.  For batches of <= 64 slots only

@@ -228,20 +228,27 @@ def test_scratch_field_variant_full_parity_on_ispd_sized_regions():
     _run_episode_parity(regions, policy="random", force_scratch_field=True)
 
 
+@pytest.mark.parametrize("form", ["lds", "scratch", "large"])
 @pytest.mark.parametrize("v2", [dict(maze_end_iter=3), dict(guide_cost=800, guide_margin=2), dict(guide_cost=1200, guide_margin=0, maze_end_iter=4)])
-def test_xr_maze_v2_matches_the_oracle(v2):
+def test_xr_maze_v2_matches_the_oracle(v2, form):
     """XR-Maze v2 (guide cost, rip-up-and-reroute with a doubling penalty; `-follow_guide 1 -maze_end_iter 3
     -ripup_mode 1` of run-net-ordering-training.tcl:3 given a meaning) on the GPU == the oracle's v2, bit for bit — and the
-    knobs really change routes relative to v1."""
+    knobs really change routes relative to v1.  Both forms of the frontier router: field in LDS, and the HBM-scratch form
+    (forced on ispd18_test1-sized regions; by itself on 72x64x10 regions that do not fit LDS), whose persistent scratch must be
+    left CLEAN by every ripped-up attempt."""
     from oracle import xr_oracle as orc
     from xroute_env_amd.batch import RegionBatch
-    regions = [generate_region(3300 + i) for i in range(16)]
-    batch = RegionBatch(regions, device="cuda:0", **v2)
+    if form == "large":
+        regions = [generate_region(3400 + i, dims=(72, 64, 10), k_range=(40, 48), blockage=(0.3, 0.4), prerouted=(0.10, 0.15), net_span=24)
+                   for i in range(6)]
+    else:
+        regions = [generate_region(3300 + i) for i in range(16)]
+    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), **v2)
     envs = [orc.OracleEnv(r, **v2) for r in regions]
     v1 = [orc.OracleEnv(r) for r in regions]
     batch.reset()
     differs = 0
-    for _ in range(40):
+    for _ in range(50):
         legal = batch.legal_sets()
         if not any(legal):
             break
@@ -270,9 +277,8 @@ def test_xr_maze_v2_refused_where_unsupported():
     from xroute_env_amd._lib import XRouteError
     from xroute_env_amd.batch import RegionBatch
     regs = [generate_region(1, dims=(12, 10, 5), k_range=(2, 3))]
-    for kw in (dict(router=1), dict(force_scratch_field=True)):
-        with pytest.raises(XRouteError):
-            RegionBatch(regs, device="cuda:0", maze_end_iter=2, **kw)
+    with pytest.raises(XRouteError):                     # the line-segment sweeps have no v2
+        RegionBatch(regs, device="cuda:0", maze_end_iter=2, router=1)
     with pytest.raises(XRouteError):
         RegionBatch(regs, device="cuda:0", maze_end_iter=9)
 

@@ -465,10 +465,10 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 512;       // (256: 4.2-4.7 ms, 512: 3.7-3.9 ms, config 5)
         }
         const bool v2 = b->cfg.guide_cost > 0 || b->cfg.maze_end_iter > 1;
-        if (v2 && b->kzch == -1 && b->lds_dist) b->kzch = -2;          // the instantiation with the XR-Maze v2 knobs compiled in
+        if (v2 && b->kzch == -1) b->kzch = -2;          // the instantiations with the XR-Maze v2 knobs compiled in (LDS and HBM-scratch form)
         if (v2 && b->kzch != -2)
-            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR-Maze v2 (guide_cost / maze_end_iter) needs the frontier router's LDS form "
-                                      "(regions up to ~9 k nodes, router != XR_ROUTER_SWEEP, no force_scratch_field)");
+            return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR-Maze v2 (guide_cost / maze_end_iter) needs the frontier router "
+                                      "(router != XR_ROUTER_SWEEP, regions within its limits)");
         if (b->kzch >= 0 && b->cfg.router == XR_ROUTER_DIAL) {
             return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL: the largest region (%d nodes) exceeds the frontier router's limits", b->n_max);
         }

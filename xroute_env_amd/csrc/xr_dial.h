@@ -752,6 +752,8 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
 __device__ __forceinline__ uint32_t xr_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xr_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// V2: XR-Maze v2 knobs compiled in (guide cost, rip-up-and-reroute), as in the LDS form
+template <bool V2>
 __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const int e, const int a, char* smem) {
     __shared__ int s_ap_f[XR_MAX_AP_PER_NET];
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
@@ -762,6 +764,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
     __shared__ int s_nG, s_nA, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
+    __shared__ int s_gb[4], s_retry;                          // XR-Maze v2: guide box of the net (track indices), rip-up decision
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -804,7 +807,10 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
     const int nap = ap_hi - ap_lo;
-    if (tid == 0) { s_first_pin = 0x7FFFFFFF; s_npins = 0; s_ntouched = 0; s_ndefer = 0; s_niso = 0; s_src_iso = 0; }
+    if (tid == 0) {
+        s_first_pin = 0x7FFFFFFF; s_npins = 0; s_ntouched = 0; s_ndefer = 0; s_niso = 0; s_src_iso = 0;
+        s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1;
+    }
     __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = b.ap_pin[R.ap_off + ap_lo + i];
@@ -812,13 +818,18 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         s_ap_pin[i] = (short)pin;
         s_ap_conn[i] = 0;
         atomicMin(&s_first_pin, pin);
+        if (V2 && b.guide_cost) {                // XR-Maze v2: the net's guide = bounding box of all its access points (+ margin)
+            const int apf = s_ap_f[i];
+            const int gy = (apf / Z) % Y, gx = apf / YZ;
+            atomicMin(&s_gb[0], gx); atomicMax(&s_gb[1], gx); atomicMin(&s_gb[2], gy); atomicMax(&s_gb[3], gy);
+        }
     }
     __syncthreads();
     // flags of a node for THIS net: 0 = blockage, else 1 | held << 1
     auto node_flags = [&](int f) -> uint32_t {
         const int nn = node_net[f], ow = owner[f];
         if (nn == -1) return 0u;
-        return 1u | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
+        return 1u | (((ow != 0 && ow != a && !(V2 && ow == -a)) || (nn > 0 && nn != a)) ? 2u : 0u);     // (-a: a tentative claim of this very route)
     };
     // first touch of a node in this route: remember it for the final reset
     auto touch = [&](uint32_t f) { const int k = atomicAdd(&s_ntouched, 1); touchg[k] = f; };
@@ -851,12 +862,13 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     XR_LAP(0);
 
     const uint32_t via4 = (uint32_t)b.via_cost << 2;
-    const uint32_t pen4 = (uint32_t)b.pen_cost << 2;
+    uint32_t pen4 = (uint32_t)b.pen_cost << 2;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
     const uint32_t delta = R.w_min * (uint32_t)b.dial_mult_big;
     const uint32_t uYZ = (uint32_t)YZ, uZ = (uint32_t)Z;
-    int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK;   // thread 0 only
+    int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0;   // thread 0 only
     int nrounds = 0;
-    uint64_t h = (tid == 0) ? b.hash[e] : 0;
+    const uint64_t h0 = (tid == 0) ? b.hash[e] : 0;
+    uint64_t h = h0;
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
 
     // put a node (back) into the open structure with distance d
@@ -866,6 +878,18 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         atomicMin(&s_gmin[f >> 10], d);
     };
 
+    // XR-Maze v2, neutral by default: guide cost outside the net's guide box; tentative claims (owner = -a) until
+    // the attempt stands
+    const uint32_t guide4 = V2 ? (uint32_t)b.guide_cost << 2 : 0u;
+    const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
+    auto guide_of = [&](int x, int y) -> uint32_t {
+        if (!V2) return 0u;
+        return (guide4 != 0u && (x < gx0 || x > gx1 || y < gy0 || y > gy1)) ? guide4 : 0u;
+    };
+    const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
+    int attempt = 0;
+
+    for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     for (;;) {
         // ---- new search ---------------------------------------------------------------------------------
         if (tid == 0) {
@@ -1013,7 +1037,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                         uint32_t fl;
                         if (wn == XR_BIG_CLEAN) { fl = node_flags(nf); if (fl == 0u) continue; }     // first touch: derive the flags
                         else fl = wn & 3u;
-                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u);
+                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + guide_of(nx, ny);
                         if (cand4 >= XR_W_USABLE_END) continue;
                         const uint32_t cw = cand4 | fl;
                         if (cw >= wn) continue;
@@ -1088,7 +1112,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 int x = (int)ux, y = (int)uy, z = (int)uz;
                 int np = 0;
                 while ((vw >> 2) > 0) {
-                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);
                     const bool vert = (ldir >> z) & 1u;
                     int u = -1;
                     uint32_t len4 = 0;
@@ -1114,7 +1138,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw, src);
                     const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len4, src);
                     if (tid == 0) {
-                        if (vw & 2u) d_vio += 1;
+                        if (vw & 2u) { d_vio += 1; d_held += 1; }
                         pathg[np] = (uint32_t)v;
                         if (plen < b.path_cap) path[plen] = v;
                         plen++;
@@ -1131,7 +1155,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     s_remaining = 0;
                 } else if (tid == 0) {
                     if (owner[v] == 0) {
-                        owner[v] = (int16_t)a;
+                        owner[v] = claim_val;
                         if (plen < b.path_cap) path[plen] = v;
                         plen++;
                         fnv_mix(h, (uint32_t)v);
@@ -1153,14 +1177,13 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 for (int i = tid; i < np; i += nthr) {
                     const int f = (int)pathg[i];
                     make_source(f);
-                    if (owner[f] == 0) owner[f] = (int16_t)a;
+                    if (owner[f] == 0) owner[f] = claim_val;
                 }
             }
         }
         XR_LAP(4);
     }
-
-    // ---- leave the scratch CLEAN: reset exactly what this route touched -------------------------------------
+    // ---- leave the scratch CLEAN: reset exactly what this route (attempt) touched ----------------------------
     {
         const int nt = s_ntouched;
         for (int i = tid; i < nt; i += nthr) {
@@ -1169,6 +1192,28 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             xr_st(&openg[f >> 5], 0u);
             xr_st(&wming[f >> 5], XR_DIAL_INF);
         }
+    }
+    if (!V2 || b.maze_end_iter <= 1) break;
+    // ---- XR-Maze v2: does the attempt stand?  Its path uses a node held by another net and attempts are left: rip it up ----
+    if (tid == 0) s_retry = (d_held > 0 && attempt + 1 < b.maze_end_iter) ? 1 : 0;
+    __syncthreads();
+    const bool retry = s_retry != 0;
+    for (int f = tid; f < N; f += nthr)                       // tentative claims: accepted (-a -> a) or undone (-a -> 0)
+        if (owner[f] == (int16_t)-a) owner[f] = retry ? (int16_t)0 : (int16_t)a;
+    if (!retry) break;
+    attempt++;
+    pen4 = ((uint32_t)b.pen_cost << 2) << attempt;
+    if (tid == 0) { d_vio = 0; d_wl = 0; d_via = 0; plen = 0; d_held = 0; status = XR_ENV_OK; h = h0; s_ntouched = 0; s_ndefer = 0; }
+    for (int i = tid; i < ng; i += nthr) s_gmin[i] = XR_DIAL_INF;
+    __syncthreads();                                          // scratch CLEAN, owner grid restored: start over from the first pin
+    for (int i = tid; i < nap; i += nthr) {
+        const bool iso = s_ap_conn[i] == 2;
+        const bool first = s_ap_pin[i] == (short)s_first_pin;
+        s_ap_conn[i] = iso ? 2 : (first ? 1 : 0);
+        if (first && !iso) make_source(s_ap_f[i]);
+    }
+    if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
+    // (the barriers at the top of the search loop order all of this)
     }
     if (tid == 0) {
         if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }

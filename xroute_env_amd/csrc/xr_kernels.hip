@@ -822,15 +822,15 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
 // router selection of the step kernels: ZCH == XR_ZCH_DIAL -> the bucketed-frontier router (xr_dial.h, the default),
 // else the line-segment sweeps above (xr_config.router = XR_ROUTER_SWEEP)
 #define XR_ZCH_DIAL (-1)
-#define XR_ZCH_DIAL2 (-2)      // the frontier router's LDS form with the XR-Maze v2 knobs compiled in
+#define XR_ZCH_DIAL2 (-2)      // the frontier router (either form) with the XR-Maze v2 knobs compiled in
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int e, const int a, char* smem) {
     if constexpr (ZCH == XR_ZCH_DIAL2) {
-        static_assert(LDS_DIST, "XR-Maze v2: LDS form only");
-        xr_dial_route_env<true>(b, e, a, smem);
+        if constexpr (LDS_DIST) xr_dial_route_env<true>(b, e, a, smem);
+        else xr_dial_route_env_big<true>(b, e, a, smem);
     } else if constexpr (ZCH == XR_ZCH_DIAL) {
         if constexpr (LDS_DIST) xr_dial_route_env<false>(b, e, a, smem);
-        else xr_dial_route_env_big(b, e, a, smem);
+        else xr_dial_route_env_big<false>(b, e, a, smem);
     } else {
         xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
     }
@@ -1700,10 +1700,13 @@ hipError_t xr_launch_reset(const XrBatchDev* b, const uint8_t* mask, int rotate,
 }
 
 hipError_t xr_route_set_max_lds(size_t bytes) {
-    const void* d2fns[3] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>),
+    const void* d2fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>),
                             reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL2>),
-                            reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL2>)};
-    for (int i = 0; i < 3; i++) {
+                            reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL2>),
+                            reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL2>),
+                            reinterpret_cast<const void*>(&xr_step_queue_kernel<false, XR_ZCH_DIAL2>),
+                            reinterpret_cast<const void*>(&xr_order_kernel<false, XR_ZCH_DIAL2>)};
+    for (int i = 0; i < 6; i++) {
         hipError_t e = hipFuncSetAttribute(d2fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
@@ -1742,7 +1745,8 @@ hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_
                            int threads, hipStream_t st) {
     const dim3 g(b->env_count > 0 ? b->env_count : b->n_envs), t(threads);
     if (zch == XR_ZCH_DIAL2) {
-        hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
+        if (lds_dist) hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_route_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
     } else if (zch == XR_ZCH_DIAL) {
         if (lds_dist) hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_route_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
@@ -1762,7 +1766,8 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
                            size_t lds_bytes, int threads, hipStream_t st) {
     const dim3 g(b->n_envs), t(threads);
     if (zch == XR_ZCH_DIAL2) {
-        hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        if (lds_dist) hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+        else hipLaunchKernelGGL((xr_order_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     } else if (zch == XR_ZCH_DIAL) {
         if (lds_dist) hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else hipLaunchKernelGGL((xr_order_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
@@ -1780,7 +1785,8 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
 
 // resident workgroups per CU of the step kernel as the runtime would place it, and its static LDS
 hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threads, int* wg_per_cu, size_t* static_lds) {
-    const void* fn = zch == XR_ZCH_DIAL2 ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>)
+    const void* fn = zch == XR_ZCH_DIAL2 ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>)
+                                                     : reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL2>))
                      : zch == XR_ZCH_DIAL ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>)
                                                     : reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL>))
                      : lds_dist ? (zch == 9 ? reinterpret_cast<const void*>(&xr_route_kernel<true, 9>)
@@ -1800,7 +1806,8 @@ hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int
                                 int threads, int blocks, hipStream_t st) {
     const dim3 g(blocks), t(threads);
     if (zch == XR_ZCH_DIAL2) {
-        hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
+        if (lds_dist) hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
+        else hipLaunchKernelGGL((xr_step_queue_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
     } else if (zch == XR_ZCH_DIAL) {
         if (lds_dist) hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_step_queue_kernel<false, XR_ZCH_DIAL>), g, t, lds_bytes, st, *b, actions);
