@@ -45,6 +45,10 @@
 #ifndef XR_DIAL_ASTAR
 #define XR_DIAL_ASTAR 1          // LDS form: bucket keys f = d + h (0: plain Dijkstra order, keys = d) — A/B switch
 #endif
+#ifndef XR_DIAL_QUAD
+#define XR_DIAL_QUAD 1         // LDS form: the nodes of a bucket are expanded by quads of lanes (one lane per direction)
+#endif
+#define XR_QUAD_POOL 128       // nodes of a bucket queued per workgroup for the quads (split evenly over the waves); no room: next round
 #ifndef XR_DIAL_CHAIN
 #define XR_DIAL_CHAIN 1
 #endif
@@ -433,6 +437,160 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 if (!s_ap_conn[i]) { const uint32_t w = field[s_ap_f[i]]; if (w < XR_W_UNREACHED) atomicMin(&s_bst[nx1], w >> 2); }
             // A lane scans word wi and — where the mask has more words than the workgroup has threads — word wi + nthr in
             // the SAME pass (one 64-bit bit set), so that no wave runs the body twice per round.
+#if XR_DIAL_QUAD
+            // A lane scans word wi and — where the mask has more words than the workgroup has threads — word wi + nthr in
+            // the SAME pass (one 64-bit bit set).  The nodes of this bucket are then expanded by QUADS of lanes, one lane per
+            // direction: a hop of the run-ahead chain is one neighbour's worth of instructions instead of four (a route is
+            // a sequential chain of hops, and a hop done by one lane costs ~2 k cycles of instruction issue even on an idle chip).
+            for (int wbase = 0; wbase < mw; wbase += 2 * nthr) {          // (uniform trip count: the expansion is wave-cooperative)
+                const int wi = wbase + tid;
+                const int wi2 = wi + nthr;
+                unsigned long long expd = 0;
+                if (wi < mw) {
+                    const bool has2 = wi2 < mw;
+                    uint32_t wmA = s_wmin[wi], wmB = has2 ? s_wmin[wi2] : XR_DIAL_INF;
+                    const bool actA = wmA < hi, actB = wmB < hi;
+                    if (actA || actB) {
+                        // the word (probably) holds a node of this bucket: take it.  Order matters: reset the cached minimum,
+                        // THEN take the bits, THEN read distances — a concurrent insertion is either seen here or survives
+                        uint32_t bA = 0, bB = 0;
+                        if (actA) { s_wmin[wi] = XR_DIAL_INF; bA = atomicExch(&s_open[wi], 0u); }
+                        if (actB) { s_wmin[wi2] = XR_DIAL_INF; bB = atomicExch(&s_open[wi2], 0u); }
+                        unsigned long long bits = (unsigned long long)bA | ((unsigned long long)bB << 32);
+                        unsigned long long keep = 0;
+                        uint32_t kminA = XR_DIAL_INF, kminB = XR_DIAL_INF;
+                        while (bits) {                                    // four distance loads in flight at a time
+                            int q[4];
+                            uint32_t w[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                q[j] = bits ? __ffsll((long long)bits) - 1 : -1;
+                                bits &= bits - 1;                        // (0 stays 0)
+                            }
+                            int fq[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) fq[j] = (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) w[j] = q[j] >= 0 ? field[fq[j]] : XR_DIAL_INF;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                if (q[j] < 0) continue;
+                                uint32_t cx = 0, cr, cy = 0, cz = 0;
+                                if (XR_DIAL_ASTAR) {
+                                    xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx, cr);
+                                    xr_divmod(cr, uZ, R.magic_z, cy, cz);
+                                }
+                                const uint32_t key = (w[j] >> 2) + heur((int)cx, (int)cy, (int)cz);
+                                if (key >= hi) {
+                                    keep |= 1ULL << q[j];
+                                    if (q[j] < 32) kminA = key < kminA ? key : kminA; else kminB = key < kminB ? key : kminB;
+                                } else expd |= 1ULL << q[j];
+                            }
+                        }
+                        if ((uint32_t)keep) { atomicOr(&s_open[wi], (uint32_t)keep); atomicMin(&s_wmin[wi], kminA); }
+                        if ((uint32_t)(keep >> 32)) { atomicOr(&s_open[wi2], (uint32_t)(keep >> 32)); atomicMin(&s_wmin[wi2], kminB); }
+                        if (actA) wmA = kminA;
+                        if (actB) wmB = kminB;
+                    }
+                    lmin = wmA < lmin ? wmA : lmin;
+                    lmin = wmB < lmin ? wmB : lmin;
+                }
+                XR_LAP(1);
+                // ---- the wave's nodes of this bucket go into its slice of a small LDS queue (no room: back into the mask)
+                {
+                    const int lane = tid & 63, wv = tid >> 6;
+                    const int qcap = XR_QUAD_POOL / ((nthr + 63) >> 6);
+                    int* qcnt = &s_pocket[0][0] + wv;                                                   // [16] counters
+                    unsigned short* qn = reinterpret_cast<unsigned short*>(&s_pocket[0][0] + 16) + wv * qcap;     // [XR_QUAD_POOL] nodes
+                    if (lane == 0) *qcnt = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    while (expd) {
+                        const int qb = __ffsll((long long)expd) - 1;
+                        expd &= expd - 1;
+                        const int wsel = qb < 32 ? wi : wi2;
+                        const uint32_t f = (uint32_t)((qb & 31) * mw + wsel);
+                        const int pos = atomicAdd(qcnt, 1);
+                        if (pos < qcap) qn[pos] = (unsigned short)f;
+                        else { atomicOr(&s_open[wsel], 1u << (qb & 31)); atomicMin(&s_wmin[wsel], m); lmin = m < lmin ? m : lmin; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int nq = min(__builtin_amdgcn_readfirstlane(*qcnt), qcap);
+                    // ---- quads: lanes 4g .. 4g+3 follow ONE chain, lane 4g+d relaxes direction d of the chain's current node
+                    const int dir = lane & 3, qbase = lane & ~3;
+                    int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
+                    uint32_t gd4 = 0;
+                    for (;;) {
+                        const unsigned long long idle_g = __ballot(gf < 0) & 0x1111111111111111ULL;       // one bit per idle quad
+                        if (gf < 0) {
+                            const int idx = qh + __popcll(idle_g & ((1ULL << qbase) - 1ULL));
+                            if (idx < nq) {
+                                gf = (int)qn[idx];
+                                uint32_t ux, ur, uy, uz;
+                                xr_divmod((uint32_t)gf, uYZ, R.magic_yz, ux, ur);
+                                xr_divmod(ur, uZ, R.magic_z, uy, uz);
+                                gx = (int)ux; gy = (int)uy; gz = (int)uz;
+                                gd4 = field[gf] & ~3u;
+                            }
+                        }
+                        qh += __popcll(idle_g);
+                        if (__ballot(gf >= 0) == 0ULL) break;                                            // uniform
+                        bool chain_cand = false, lowered = false, refused = false;
+                        int nf = -1;
+                        uint32_t cand4 = 0, key = 0;
+                        const bool vert = (ldir >> gz) & 1u;
+                        if (gf >= 0) {
+                            int nx = gx, ny = gy, nz = gz;
+                            uint32_t len4 = via4;
+                            if (dir == 0) {
+                                if (vert) { if (gy + 1 < Y) nf = gf + Z; len4 = el4y(gy + 1); ny++; }
+                                else      { if (gx + 1 < X) nf = gf + YZ; len4 = el4x(gx + 1); nx++; }
+                            } else if (dir == 1) {
+                                if (vert) { if (gy > 0) nf = gf - Z; len4 = el4y(gy); ny--; }
+                                else      { if (gx > 0) nf = gf - YZ; len4 = el4x(gx); nx--; }
+                            } else if (dir == 2) { if (gz + 1 < Z) nf = gf + 1; nz++; }
+                            else                 { if (gz > 0) nf = gf - 1; nz--; }
+                            if (nf >= 0) {
+                                const uint32_t wn = field[nf];
+                                cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny);
+                                const uint32_t cw = cand4 | (wn & 3u);
+                                // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
+                                if (wn != XR_W_BLOCK && cand4 < XR_W_USABLE_END && cw < wn) {
+                                    key = (cand4 >> 2) + heur(nx, ny, nz);                    // f = d + h
+                                    if (key > best) refused = true;                           // bound pruning (on f)
+                                    else {
+                                        const uint32_t old = atomicMin(&field[nf], cw);
+                                        lowered = cw < old;
+                                        chain_cand = lowered && XR_DIAL_CHAIN && key < hi;
+                                    }
+                                }
+                            }
+                        }
+                        const uint32_t c4 = (uint32_t)(__ballot(chain_cand) >> qbase) & 15u;
+                        const uint32_t r4 = (uint32_t)(__ballot(refused) >> qbase) & 15u;
+                        const int win = c4 ? __ffs((int)c4) - 1 : -1;                   // the chain goes on with the first lowered direction
+                        if (lowered && dir != win) {                                    // the others become open
+                            uint32_t oq, orr;
+                            xr_divmod((uint32_t)nf, umw, magic_mw, oq, orr);
+                            atomicOr(&s_open[orr], 1u << oq);
+                            atomicMin(&s_wmin[orr], key);
+                            lmin = key < lmin ? key : lmin;
+                        }
+                        if (gf >= 0) {
+                            if (r4 && dir == 0) xr_mask_or(s_defer, (uint32_t)gf, umw, magic_mw);
+                            if (win >= 0) {
+                                gf = __shfl(nf, qbase + win);
+                                gd4 = (uint32_t)__shfl((int)cand4, qbase + win);
+                                if (win == 0) { if (vert) gy++; else gx++; }
+                                else if (win == 1) { if (vert) gy--; else gx--; }
+                                else if (win == 2) gz++;
+                                else gz--;
+                            } else gf = -1;
+                        }
+                    }
+                }
+                XR_LAP(2);
+            }
+#else
             for (int wi = tid; wi < mw; wi += 2 * nthr) {
                 const int wi2 = wi + nthr;
                 const bool has2 = wi2 < mw;
@@ -552,6 +710,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 lmin = wmA < lmin ? wmA : lmin;
                 lmin = wmB < lmin ? wmB : lmin;
             }
+#endif
             XR_LAP(1);
             lmin = xr_wave_min_u32(lmin);
             if ((tid & 63) == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
