@@ -48,6 +48,9 @@
 #ifndef XR_DIAL_QUAD
 #define XR_DIAL_QUAD 1         // LDS form: the nodes of a bucket are expanded by quads of lanes (one lane per direction)
 #endif
+#ifndef XR_SCAN_UNROLL
+#define XR_SCAN_UNROLL 2      // open nodes of a mask word classified per loop iteration
+#endif
 #define XR_QUAD_POOL 128       // nodes of a bucket queued per workgroup for the quads (split evenly over the waves); no room: next round
 #ifndef XR_DIAL_CHAIN
 #define XR_DIAL_CHAIN 1
@@ -322,6 +325,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         s_yc[i] = (uint32_t)(b.coords[R.ys_off + min(i - 1, Y - 1)] - b.coords[R.ys_off]) << 2;
     auto el4x = [&](int i) { return s_xc[i + 1] - s_xc[i]; };
     auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
+    (void)el4x; (void)el4y;
     if (tid == 0) {
         s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0;
         s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1;
@@ -459,21 +463,21 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         unsigned long long bits = (unsigned long long)bA | ((unsigned long long)bB << 32);
                         unsigned long long keep = 0;
                         uint32_t kminA = XR_DIAL_INF, kminB = XR_DIAL_INF;
-                        while (bits) {                                    // four distance loads in flight at a time
-                            int q[4];
-                            uint32_t w[4];
+                        while (bits) {                                    // XR_SCAN_UNROLL distance loads in flight at a time
+                            int q[XR_SCAN_UNROLL];
+                            uint32_t w[XR_SCAN_UNROLL];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) {
                                 q[j] = bits ? __ffsll((long long)bits) - 1 : -1;
                                 bits &= bits - 1;                        // (0 stays 0)
                             }
-                            int fq[4];
+                            int fq[XR_SCAN_UNROLL];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) fq[j] = (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2);
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) fq[j] = (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2);
 #pragma unroll
-                            for (int j = 0; j < 4; j++) w[j] = q[j] >= 0 ? field[fq[j]] : XR_DIAL_INF;
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) w[j] = q[j] >= 0 ? field[fq[j]] : XR_DIAL_INF;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) {
                                 if (q[j] < 0) continue;
                                 uint32_t cx = 0, cr, cy = 0, cz = 0;
                                 if (XR_DIAL_ASTAR) {
@@ -539,16 +543,19 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         uint32_t cand4 = 0, key = 0;
                         const bool vert = (ldir >> gz) & 1u;
                         if (gf >= 0) {
-                            int nx = gx, ny = gy, nz = gz;
-                            uint32_t len4 = via4;
-                            if (dir == 0) {
-                                if (vert) { if (gy + 1 < Y) nf = gf + Z; len4 = el4y(gy + 1); ny++; }
-                                else      { if (gx + 1 < X) nf = gf + YZ; len4 = el4x(gx + 1); nx++; }
-                            } else if (dir == 1) {
-                                if (vert) { if (gy > 0) nf = gf - Z; len4 = el4y(gy); ny--; }
-                                else      { if (gx > 0) nf = gf - YZ; len4 = el4x(gx); nx--; }
-                            } else if (dir == 2) { if (gz + 1 < Z) nf = gf + 1; nz++; }
-                            else                 { if (gz > 0) nf = gf - 1; nz--; }
+                            // (no branch per direction: the quad's four lanes would run them one after the other, each with
+                            //  its own LDS round trip for the edge length)
+                            const int sgn = (dir & 1) ? -1 : 1;
+                            const bool planar = dir < 2;
+                            const int ddx = (planar && !vert) ? sgn : 0, ddy = (planar && vert) ? sgn : 0, ddz = planar ? 0 : sgn;
+                            const int nx = gx + ddx, ny = gy + ddy, nz = gz + ddz;
+                            if ((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z)
+                                nf = gf + ddx * YZ + ddy * Z + ddz;
+                            // edge length: difference of the two track coordinates (tables: coordinate x4 of track i at [i + 1])
+                            const uint32_t* ctab = vert ? s_yc : s_xc;
+                            const int c0 = vert ? gy : gx;
+                            const uint32_t ca = ctab[c0 + 1], cb = ctab[c0 + 1 + sgn];
+                            const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
                             if (nf >= 0) {
                                 const uint32_t wn = field[nf];
                                 cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny);
@@ -754,8 +761,10 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 }
             } else {
                 // ---- deterministic back-trace: first predecessor in the order E,S,W,N,U,D (the reference's own
-                // direction order, build_3Dgrid.py:127).  Lanes 0..5 test one direction each; ballot + ffs picks the
-                // first match (a wave-uniform lane id, so the winner's values are read with v_readlane, no LDS trip).
+                // direction order, build_3Dgrid.py:127).  TWO hops per LDS round trip: lanes 0..5 test one direction of the
+                // current node v each, lanes 6..41 test — speculatively, for each of the six possible predecessors u1 of v — one
+                // direction of u1 each (their addresses depend on v's coordinates only, so both levels load at once).  ballot +
+                // ffs picks the first match of each level (wave-uniform lane ids: the winners' values come through v_readlane).
                 // The field is only READ here; claimed nodes are zeroed afterwards.
                 int v = __builtin_amdgcn_readfirstlane((int)s_ap_f[best_i]);
                 uint32_t vw = field[v];
@@ -763,46 +772,71 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 xr_divmod((uint32_t)v, uYZ, R.magic_yz, ux, ur);
                 xr_divmod(ur, uZ, R.magic_z, uy, uz);
                 int x = (int)ux, y = (int)uy, z = (int)uz;
+                const int lvl2 = tid >= 6 && tid < 42;
+                const int d1 = tid < 6 ? tid : (tid < 42 ? (tid - 6) / 6 : 6);         // direction of the first hop this lane looks at
+                const int d2 = lvl2 ? (tid - 6) % 6 : 6;                               // ... and of the second (level-2 lanes)
+                // candidate predecessor of node (f; cx, cy, cz) in direction d (0..5 = E,S,W,N,U,D): flat index or -1, edge length x4
+                auto pred_of = [&](int f, int cx, int cy, int cz, int d, uint32_t& len4) -> int {
+                    // (no switch: six divergent cases would run one after the other, each with its own LDS round trip)
+                    const bool vt = (ldir >> cz) & 1u;
+                    const int ddx = (d == 0) - (d == 2), ddy = (d == 3) - (d == 1), ddz = (d == 4) - (d == 5);
+                    const int nx = cx + ddx, ny = cy + ddy, nz = cz + ddz;
+                    const bool along = ddz != 0 || (ddx != 0 && !vt) || (ddy != 0 && vt);      // planar moves follow the layer's direction
+                    const bool inb = d < 6 && along && (unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z;
+                    const uint32_t* ctab = ddx ? s_xc : s_yc;
+                    const int c0 = ddx ? cx : cy, c1 = c0 + ddx + ddy;
+                    const uint32_t ca = ctab[c0 + 1], cb = ctab[(ddz ? c0 : c1) + 1];
+                    len4 = ddz ? via4 : (cb > ca ? cb - ca : ca - cb);
+                    return inb ? f + ddx * YZ + ddy * Z + ddz : -1;
+                };
+                auto claim_node = [&](int node, uint32_t w, int src, uint32_t pl4) {     // thread 0: node joins the path, left through `src`
+                    uint32_t cq, cr;
+                    xr_divmod((uint32_t)node, umw, magic_mw, cq, cr);
+                    if (w & 2u) { d_vio += 1; d_held += 1; }
+                    atomicOr(&s_claim[cr], 1u << cq);
+                    if (plen < b.path_cap) path[plen] = node;
+                    plen++;
+                    fnv_mix(h, (uint32_t)node);
+                    if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
+                };
                 while ((vw >> 2) > 0) {
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);   // pred distance + edge, x4
-                    const bool vert = (ldir >> z) & 1u;
-                    int u = -1;
-                    uint32_t len4 = 0;
-                    switch (tid) {
-                    case 0: if (!vert && x + 1 < X) { u = v + YZ; len4 = el4x(x + 1); } break;   // E
-                    case 1: if (vert && y > 0)      { u = v - Z;  len4 = el4y(y); } break;       // S
-                    case 2: if (!vert && x > 0)     { u = v - YZ; len4 = el4x(x); } break;       // W
-                    case 3: if (vert && y + 1 < Y)  { u = v + Z;  len4 = el4y(y + 1); } break;   // N
-                    case 4: if (z + 1 < Z)          { u = v + 1;  len4 = via4; } break;           // U
-                    case 5: if (z > 0)              { u = v - 1;  len4 = via4; } break;           // D
-                    default: break;
-                    }
-                    uint32_t uw = XR_W_BLOCK;
-                    bool ok = false;
-                    if (u >= 0) {
-                        uw = field[u];
-                        ok = (uw - 1u) < (XR_W_USABLE_END - 1u) && (uw & ~3u) + len4 == need4;
-                    }
-                    const unsigned long long mm = __ballot(ok);
+                    uint32_t len1 = 0, len2 = 0;
+                    const int u1 = pred_of(v, x, y, z, d1, len1);
+                    const int x1 = x + (d1 == 0) - (d1 == 2), y1 = y + (d1 == 3) - (d1 == 1), z1 = z + (d1 == 4) - (d1 == 5);
+                    const int u2 = (lvl2 && u1 >= 0) ? pred_of(u1, x1, y1, z1, d2, len2) : -1;
+                    uint32_t uw1 = XR_W_BLOCK, uw2 = XR_W_BLOCK;
+                    if (u1 >= 0) uw1 = field[u1];
+                    if (u2 >= 0) uw2 = field[u2];
+                    const bool use1 = (uw1 - 1u) < (XR_W_USABLE_END - 1u);
+                    const bool ok1 = tid < 6 && use1 && (uw1 & ~3u) + len1 == need4;
+                    const bool ok2 = use1 && (uw2 - 1u) < (XR_W_USABLE_END - 1u) &&
+                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1);
+                    const unsigned long long mm = __ballot(ok1), mm2 = __ballot(ok2);
                     if (mm == 0) { if (tid == 0) status |= 0x100; break; }     // inconsistent field: cannot happen
                     const int src = __ffsll((long long)mm) - 1;                // wave-uniform
-                    const int pu = __builtin_amdgcn_readlane(u, src);
-                    const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw, src);
-                    const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len4, src);
-                    if (tid == 0) {                 // claim v
-                        uint32_t cq, cr;
-                        xr_divmod((uint32_t)v, umw, magic_mw, cq, cr);
-                        if (vw & 2u) { d_vio += 1; d_held += 1; }
-                        atomicOr(&s_claim[cr], 1u << cq);
-                        if (plen < b.path_cap) path[plen] = v;
-                        plen++;
-                        fnv_mix(h, (uint32_t)v);
-                        if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
-                    }
+                    const int pu = __builtin_amdgcn_readlane(u1, src);
+                    const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw1, src);
+                    const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len1, src);
+                    if (tid == 0) claim_node(v, vw, src, pl4);
                     x += (src == 0) - (src == 2);
                     y += (src == 3) - (src == 1);
                     z += (src == 4) - (src == 5);
                     v = pu; vw = puw;
+                    if ((vw >> 2) == 0) break;                                 // a source: the component is reached
+                    // ---- the second hop, already looked at by lanes 6 + 6 src .. 6 + 6 src + 5
+                    const uint32_t m6 = (uint32_t)(mm2 >> (6 + 6 * src)) & 63u;
+                    if (m6 == 0) { if (tid == 0) status |= 0x100; break; }
+                    const int srcb = __ffs((int)m6) - 1;
+                    const int lane2 = 6 + 6 * src + srcb;
+                    const int pu2 = __builtin_amdgcn_readlane(u2, lane2);
+                    const uint32_t puw2 = (uint32_t)__builtin_amdgcn_readlane((int)uw2, lane2);
+                    const uint32_t pl42 = (uint32_t)__builtin_amdgcn_readlane((int)len2, lane2);
+                    if (tid == 0) claim_node(v, vw, srcb, pl42);
+                    x += (srcb == 0) - (srcb == 2);
+                    y += (srcb == 3) - (srcb == 1);
+                    z += (srcb == 4) - (srcb == 5);
+                    v = pu2; vw = puw2;
                 }
                 if (tid == 0 && (status & 0x100)) {
                     s_remaining = 0;              // never taken on a consistent field; avoids spinning
