@@ -85,7 +85,13 @@ __device__ __forceinline__ uint32_t xr_wave_min_u32(uint32_t v) {
 // Returns true when net `a` is to be routed.
 __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int e, const int a) {
     const int tid = threadIdx.x;
-    if (b.nlegal[e] == 0) {
+    // the three loads that depend on (e, a) only are issued together: a route is ~70 us and every dependent global round trip
+    // in front of it costs 1-2 % of that
+    const int nl0 = b.nlegal[e];
+    const int r0 = b.env_region[e];
+    const bool a_in_words = a >= 1 && ((a - 1) >> 6) < b.legal_words;
+    const uint64_t lw0 = a_in_words ? b.legal[(int64_t)e * b.legal_words + ((a - 1) >> 6)] : 0ULL;
+    if (nl0 == 0) {
         if (b.auto_reset) {
             xr_env_reset(b, e, 1, XR_ENV_WAS_RESET);
         } else if (tid == 0) {
@@ -96,9 +102,7 @@ __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int 
         }
         return false;
     }
-    const XrRegionDev& R = b.regions[b.env_region[e]];
-    bool valid = (a >= 1 && a <= R.n_nets);
-    if (valid) valid = (b.legal[(int64_t)e * b.legal_words + ((a - 1) >> 6)] >> ((a - 1) & 63)) & 1ULL;
+    const bool valid = a_in_words && a <= b.regions[r0].n_nets && ((lw0 >> ((a - 1) & 63)) & 1ULL);
     if (!valid) {   // the reference never checks this client-side; here: flagged no-op
         if (tid == 0) {
             b.status[e] = XR_ENV_BAD_ACTION;
@@ -420,13 +424,14 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         __syncthreads();
         const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
         // h(v): distance to that box — coordinate differences + one via cost per layer (a consistent lower bound)
-        auto heur = [&](int x, int y, int z) -> uint32_t {
+        auto heur_c = [&](int xc, int yc, int z) -> uint32_t {                 // (from coordinates x4)
             if (!XR_DIAL_ASTAR) return 0u;
-            const int xc = (int)s_xc[x + 1], yc = (int)s_yc[y + 1];
             const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
             const int hz = max(0, max(hb4 - z, z - hb5));
             return ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
         };
+        auto heur = [&](int x, int y, int z) -> uint32_t { return heur_c((int)s_xc[x + 1], (int)s_yc[y + 1], z); };
+        (void)heur;
         int cur = 0;
         for (;;) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
@@ -471,20 +476,26 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                                 q[j] = bits ? __ffsll((long long)bits) - 1 : -1;
                                 bits &= bits - 1;                        // (0 stays 0)
                             }
+                            // (loads from safe addresses instead of guarded ones, all issued before the first use: one round trip
+                            //  for the distances, one for the coordinates)
                             int fq[XR_SCAN_UNROLL];
+                            uint32_t cx[XR_SCAN_UNROLL], cy[XR_SCAN_UNROLL], cz[XR_SCAN_UNROLL], xcq[XR_SCAN_UNROLL], ycq[XR_SCAN_UNROLL];
 #pragma unroll
-                            for (int j = 0; j < XR_SCAN_UNROLL; j++) fq[j] = (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2);
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) fq[j] = q[j] >= 0 ? (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2) : 0;
 #pragma unroll
-                            for (int j = 0; j < XR_SCAN_UNROLL; j++) w[j] = q[j] >= 0 ? field[fq[j]] : XR_DIAL_INF;
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) w[j] = field[fq[j]];
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) {
+                                uint32_t cr;
+                                xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx[j], cr);
+                                xr_divmod(cr, uZ, R.magic_z, cy[j], cz[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) { xcq[j] = s_xc[cx[j] + 1]; ycq[j] = s_yc[cy[j] + 1]; }
 #pragma unroll
                             for (int j = 0; j < XR_SCAN_UNROLL; j++) {
                                 if (q[j] < 0) continue;
-                                uint32_t cx = 0, cr, cy = 0, cz = 0;
-                                if (XR_DIAL_ASTAR) {
-                                    xr_divmod((uint32_t)fq[j], uYZ, R.magic_yz, cx, cr);
-                                    xr_divmod(cr, uZ, R.magic_z, cy, cz);
-                                }
-                                const uint32_t key = (w[j] >> 2) + heur((int)cx, (int)cy, (int)cz);
+                                const uint32_t key = (w[j] >> 2) + heur_c((int)xcq[j], (int)ycq[j], (int)cz[j]);
                                 if (key >= hi) {
                                     keep |= 1ULL << q[j];
                                     if (q[j] < 32) kminA = key < kminA ? key : kminA; else kminB = key < kminB ? key : kminB;
@@ -533,44 +544,42 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                                 xr_divmod((uint32_t)gf, uYZ, R.magic_yz, ux, ur);
                                 xr_divmod(ur, uZ, R.magic_z, uy, uz);
                                 gx = (int)ux; gy = (int)uy; gz = (int)uz;
-                                gd4 = field[gf] & ~3u;
                             }
                         }
                         qh += __popcll(idle_g);
                         if (__ballot(gf >= 0) == 0ULL) break;                                            // uniform
-                        bool chain_cand = false, lowered = false, refused = false;
-                        int nf = -1;
-                        uint32_t cand4 = 0, key = 0;
+#ifdef XR_COUNT_HOPS
+                        if (tid == XR_TIMING_TID) _ph[7] += 1;          // (probe: hop iterations of this wave instead of rounds)
+#endif
+                        // ---- one hop of every active quad.  All LDS reads are issued together (addresses made safe instead of
+                        // guarded), then pure ALU, then the one atomic: two LDS round trips per hop
+                        const bool act = gf >= 0;
+                        const int gfs = act ? gf : 0;
                         const bool vert = (ldir >> gz) & 1u;
-                        if (gf >= 0) {
-                            // (no branch per direction: the quad's four lanes would run them one after the other, each with
-                            //  its own LDS round trip for the edge length)
-                            const int sgn = (dir & 1) ? -1 : 1;
-                            const bool planar = dir < 2;
-                            const int ddx = (planar && !vert) ? sgn : 0, ddy = (planar && vert) ? sgn : 0, ddz = planar ? 0 : sgn;
-                            const int nx = gx + ddx, ny = gy + ddy, nz = gz + ddz;
-                            if ((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z)
-                                nf = gf + ddx * YZ + ddy * Z + ddz;
-                            // edge length: difference of the two track coordinates (tables: coordinate x4 of track i at [i + 1])
-                            const uint32_t* ctab = vert ? s_yc : s_xc;
-                            const int c0 = vert ? gy : gx;
-                            const uint32_t ca = ctab[c0 + 1], cb = ctab[c0 + 1 + sgn];
-                            const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
-                            if (nf >= 0) {
-                                const uint32_t wn = field[nf];
-                                cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny);
-                                const uint32_t cw = cand4 | (wn & 3u);
-                                // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
-                                if (wn != XR_W_BLOCK && cand4 < XR_W_USABLE_END && cw < wn) {
-                                    key = (cand4 >> 2) + heur(nx, ny, nz);                    // f = d + h
-                                    if (key > best) refused = true;                           // bound pruning (on f)
-                                    else {
-                                        const uint32_t old = atomicMin(&field[nf], cw);
-                                        lowered = cw < old;
-                                        chain_cand = lowered && XR_DIAL_CHAIN && key < hi;
-                                    }
-                                }
-                            }
+                        const int sgn = (dir & 1) ? -1 : 1;
+                        const bool planar = dir < 2;
+                        const int ddx = (planar && !vert) ? sgn : 0, ddy = (planar && vert) ? sgn : 0, ddz = planar ? 0 : sgn;
+                        const int nx = gx + ddx, ny = gy + ddy, nz = gz + ddz;
+                        const bool inb = act && (unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z;
+                        const int nf = inb ? gfs + ddx * YZ + ddy * Z + ddz : gfs;
+                        // coordinates x4 (tables: track i at [i + 1], padded at both ends): own x, own y, neighbour's along the layer's axis
+                        const uint32_t gw = field[gfs], wn = field[nf];
+                        const uint32_t xq = s_xc[gx + 1], yq = s_yc[gy + 1];
+                        const uint32_t cb = (vert ? s_yc : s_xc)[(vert ? gy : gx) + 1 + (planar ? sgn : 0)];
+                        const uint32_t ca = vert ? yq : xq;
+                        const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
+                        gd4 = gw & ~3u;
+                        const uint32_t cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny);
+                        const uint32_t cw = cand4 | (wn & 3u);
+                        const uint32_t key = (cand4 >> 2) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
+                        // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
+                        const bool go = inb && wn != XR_W_BLOCK && cand4 < XR_W_USABLE_END && cw < wn;
+                        const bool refused = go && key > best;                             // bound pruning (on f)
+                        bool lowered = false, chain_cand = false;
+                        if (go && !refused) {
+                            const uint32_t old = atomicMin(&field[nf], cw);
+                            lowered = cw < old;
+                            chain_cand = lowered && XR_DIAL_CHAIN && key < hi;
                         }
                         const uint32_t c4 = (uint32_t)(__ballot(chain_cand) >> qbase) & 15u;
                         const uint32_t r4 = (uint32_t)(__ballot(refused) >> qbase) & 15u;
@@ -584,13 +593,11 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         }
                         if (gf >= 0) {
                             if (r4 && dir == 0) xr_mask_or(s_defer, (uint32_t)gf, umw, magic_mw);
-                            if (win >= 0) {
-                                gf = __shfl(nf, qbase + win);
-                                gd4 = (uint32_t)__shfl((int)cand4, qbase + win);
-                                if (win == 0) { if (vert) gy++; else gx++; }
-                                else if (win == 1) { if (vert) gy--; else gx--; }
-                                else if (win == 2) gz++;
-                                else gz--;
+                            if (win >= 0) {                                 // every lane of the quad moves to the winner's node
+                                const int sw = (win & 1) ? -1 : 1;
+                                const int wx = (win < 2 && !vert) ? sw : 0, wy = (win < 2 && vert) ? sw : 0, wz = win < 2 ? 0 : sw;
+                                gf += wx * YZ + wy * Z + wz;
+                                gx += wx; gy += wy; gz += wz;
                             } else gf = -1;
                         }
                     }
@@ -722,7 +729,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
             lmin = xr_wave_min_u32(lmin);
             if ((tid & 63) == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
             nrounds++;
-#ifdef XR_PHASE_TIMING
+#if defined(XR_PHASE_TIMING) && !defined(XR_COUNT_HOPS)
             if (tid == XR_TIMING_TID) _ph[7] += 1;
 #endif
             __syncthreads();
@@ -805,9 +812,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     const int u1 = pred_of(v, x, y, z, d1, len1);
                     const int x1 = x + (d1 == 0) - (d1 == 2), y1 = y + (d1 == 3) - (d1 == 1), z1 = z + (d1 == 4) - (d1 == 5);
                     const int u2 = (lvl2 && u1 >= 0) ? pred_of(u1, x1, y1, z1, d2, len2) : -1;
-                    uint32_t uw1 = XR_W_BLOCK, uw2 = XR_W_BLOCK;
-                    if (u1 >= 0) uw1 = field[u1];
-                    if (u2 >= 0) uw2 = field[u2];
+                    // (both loads unconditionally, from a safe address where there is no candidate: no branch, one round trip)
+                    const uint32_t rw1 = field[u1 >= 0 ? u1 : v], rw2 = field[u2 >= 0 ? u2 : v];
+                    const uint32_t uw1 = u1 >= 0 ? rw1 : XR_W_BLOCK, uw2 = u2 >= 0 ? rw2 : XR_W_BLOCK;
                     const bool use1 = (uw1 - 1u) < (XR_W_USABLE_END - 1u);
                     const bool ok1 = tid < 6 && use1 && (uw1 & ~3u) + len1 == need4;
                     const bool ok2 = use1 && (uw2 - 1u) < (XR_W_USABLE_END - 1u) &&
