@@ -105,7 +105,7 @@ typedef struct xr_config {
     int32_t obs_writer_blocks; /* XR_OBS_SPLIT: workgroups of the net-plane writer; XR_OBS_QUEUE: workgroups of the
                                   persistent launch (0 = default: 512 / as many as are resident on the chip) */
     int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = auto (XR_ROUTER_DIAL wherever it applies;
-                                 only the full-rewrite queue launch of a batch of >= 2048 slots takes XR_ROUTER_SWEEP, measured
+                                 only the full-rewrite queue launch of a batch of >= 4096 slots takes XR_ROUTER_SWEEP, measured
                                  1-2 % faster there), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
                                  worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm) */
     int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 8) */
@@ -246,7 +246,7 @@ int32_t xr_batch_step_observe(xr_batch* b, const int32_t* actions_dev, float* ou
  * (a slot that re-initialises writes everything, a rejected action planes 0..1 only): the buffer ends up byte-identical to
  * what xr_batch_step_observe writes, with about half the HBM traffic under a uniform net choice.  Any other buffer: a full
  * write, exactly xr_batch_step_observe.  xr_batch_observe_timing reports mode | 16 when the in-place path ran (and mode | 32
- * when the auto router ran the line-segment sweeps in the queue launch: full rewrite of a batch of >= 2048 slots). */
+ * when the auto router ran the line-segment sweeps in the queue launch: full rewrite of a batch of >= 4096 slots). */
 int32_t xr_batch_step_observe_inplace(xr_batch* b, const int32_t* actions_dev, float* out_dev, int64_t env_stride,
                                       void* stream);
 

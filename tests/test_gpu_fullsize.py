@@ -143,7 +143,7 @@ def test_queue_form_observation_bytes_vs_oracle_with_rotation():
 
 
 def test_auto_router_selection_is_invisible_in_the_results():
-    """`router = 0` runs the line-segment sweeps in the full-rewrite queue launch of a batch of >= 2048 slots and the frontier
+    """`router = 0` runs the line-segment sweeps in the full-rewrite queue launch of a batch of >= 4096 slots and the frontier
     router in every other launch (xr_batch_observe_timing: mode | 32 when the sweeps ran; RegionBatch.observe_info).  Both implement XR-Maze v1 bit for
     bit, so the selection must not show anywhere: against forced `router = 2` (frontier) and `router = 1` (sweeps) twins, on
     the same actions — records, hash chains and the full observation buffers are byte-identical over full steps, in-place
@@ -152,8 +152,9 @@ def test_auto_router_selection_is_invisible_in_the_results():
     from oracle import xr_oracle as orc
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.regions import config_regions
-    B, R = 2048, 128
-    regions = config_regions(3, R)
+    from xroute_env_amd.regions import generate_region
+    B, R = 4096, 128
+    regions = [generate_region(7000 + i, k_range=(4, 12)) for i in range(R)]          # (K <= 12 keeps three 4096-env observation buffers at 36 GB)
     twins = {r: RegionBatch(regions, n_envs=B, device="cuda:0", auto_reset=True, router=r) for r in (0, 2, 1)}
     obs = {}
     for r, bt in twins.items():
@@ -193,9 +194,9 @@ def test_auto_router_selection_is_invisible_in_the_results():
     assert ("inplace", True, False) in seen
     h0 = twins[0].fetch("hash").cpu()
     assert torch.equal(h0, twins[2].fetch("hash").cpu()) and torch.equal(h0, twins[1].fetch("hash").cpu())
-    small = RegionBatch(regions, n_envs=512, device="cuda:0", auto_reset=True)       # below the threshold: frontier router
+    small = RegionBatch(regions, n_envs=2048, device="cuda:0", auto_reset=True)      # below the threshold: frontier router
     small.reset()
     o = small.alloc_observation()
-    small.random_actions(1, acts[:512])
-    small.step(acts[:512].contiguous(), o)
+    small.random_actions(1, acts[:2048])
+    small.step(acts[:2048].contiguous(), o)
     assert small.observe_info() == {"form": 3, "inplace": False, "sweeps": False, "writer_ms": 0.0}

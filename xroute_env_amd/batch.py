@@ -196,7 +196,7 @@ class RegionBatch:
 
     def observe_info(self) -> dict:
         """The last step(actions, obs_out) in words: form (1 fused, 2 split, 3 queue), whether the in-place path ran, and
-        whether the auto router ran the line-segment sweeps in that launch (full rewrite of a batch of >= 2048 slots)."""
+        whether the auto router ran the line-segment sweeps in that launch (full rewrite of a batch of >= 4096 slots)."""
         mode, ms = C.c_int32(0), C.c_float(0.0)
         _lib.check(self.L.xr_batch_observe_timing(self._h, C.byref(mode), C.byref(ms)))
         m = int(mode.value)

@@ -480,11 +480,11 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->stream_ok = stream_bytes <= 60 * 1024;
     b->route_lds = std::max(b->route_lds, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
     // router = 0 (auto) picks per entry point the scheme measured faster for it: the frontier router everywhere, except the
-    // FULL-rewrite queue launch of a large batch, where the line-segment sweeps are 1-2 % ahead (same box, DESIGN.md §5.1:
-    // 1.74-1.755 ms against 1.77-1.795 ms per 4096-env step; at 512 envs the frontier router wins 0.466 against 0.502 ms)
+    // FULL-rewrite queue launch of a very large batch, where the line-segment sweeps are ahead (same box, DESIGN.md §5.1:
+    // 1.727-1.730 ms against 1.773-1.775 ms per 4096-env step; at 2048 envs the frontier router wins, 0.921 against 0.945-0.954 ms)
     b->sweep_lds = std::max(lds_need, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
     b->sweep_full = b->cfg.router == 0 && b->kzch == -1 && b->lds_dist && sweep_lds_ok && b->cfg.block_threads == 0 &&
-                    b->cfg.n_envs >= 2048 && b->sweep_lds + kLdsStatic <= kLdsLimit;
+                    b->cfg.n_envs >= 4096 && b->sweep_lds + kLdsStatic <= kLdsLimit;
     if (b->route_lds + kLdsStatic > kLdsLimit)
         return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
     if (std::max(b->route_lds, b->sweep_full ? b->sweep_lds : 0) > 64 * 1024)

@@ -45,6 +45,11 @@
 #ifndef XR_DIAL_ASTAR
 #define XR_DIAL_ASTAR 1          // LDS form: bucket keys f = d + h (0: plain Dijkstra order, keys = d) — A/B switch
 #endif
+#if defined(XR_PHASE_TIMING) && defined(XR_PROBE_SETUP)
+#define XR_MARK(n) do { if ((n) == XR_PROBE_SETUP && threadIdx.x == XR_TIMING_TID) _ph[7] += clock64() - _t; } while (0)
+#else
+#define XR_MARK(n) do {} while (0)
+#endif
 #ifndef XR_DIAL_QUAD
 #define XR_DIAL_QUAD 1         // LDS form: the nodes of a bucket are expanded by quads of lanes (one lane per direction)
 #endif
@@ -151,12 +156,16 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
 // search: a flood that closes without meeting another pin's access point marks the pin isolated (s_ap_conn = 2) and the
 // searches skip it.  Same results by construction (the pocket's boundary is static), nothing explored for nothing.
 // ------------------------------------------------------------------------------------------------
-#define XR_POCKET_CAP 12
+#define XR_POCKET_CAP 12        // storage per wave (also the quads' node queue of the LDS form: do not shrink)
+#ifndef XR_POCKET_BUDGET_LDS
+#define XR_POCKET_BUDGET_LDS 12     // nodes a flood may visit before the pocket counts as open (<= XR_POCKET_CAP), LDS form
+#endif
+#define XR_POCKET_BUDGET_BIG 12     // ... HBM-scratch form (BASELINE config 5 has pockets of more than 4 nodes)
 template <class ApT, class BlockedFn>
 __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_of, const short* s_ap_pin, unsigned char* s_ap_conn,
                                                        int X, int Y, int Z, uint32_t ldir, uint32_t magic_yz, uint32_t magic_z,
                                                        BlockedFn blocked, int (*s_pocket)[XR_POCKET_CAP + 8], int* s_niso, int* s_src_iso,
-                                                       int first_pin) {
+                                                       int first_pin, const int budget) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwv = min((int)(blockDim.x >> 6), 4);
     if (wv >= nwv) return;
@@ -176,10 +185,10 @@ __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_o
             const bool is = i < nap && s_ap_pin[i] == pin;
             const unsigned long long mm = __ballot(is);
             const int pos = cnt + __popcll(mm & ((1ULL << lane) - 1ULL));
-            if (is && pos < XR_POCKET_CAP) vis[pos] = (int)ap_f_of[i];
+            if (is && pos < budget) vis[pos] = (int)ap_f_of[i];
             cnt += __popcll(mm);
         }
-        if (cnt > XR_POCKET_CAP) continue;                // (not a small pocket)
+        if (cnt > budget) continue;                // (not a small pocket)
         __builtin_amdgcn_wave_barrier();
         int lo = 0;
         while (lo < cnt && !open_pocket) {
@@ -198,7 +207,7 @@ __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_o
                 else if (dir == 2) nf = ((int)z + 1 < Z) ? f + 1 : -1;
                 else nf = (z > 0) ? f - 1 : -1;
                 if (nf >= 0 && blocked(nf)) nf = -1;
-                if (nf >= 0) for (int q = 0; q < cnt; q++) if (vis[q] == nf) { nf = -1; break; }      // (cnt <= XR_POCKET_CAP)
+                if (nf >= 0) for (int q = 0; q < cnt; q++) if (vis[q] == nf) { nf = -1; break; }      // (cnt <= budget)
             }
             unsigned long long cand = __ballot(nf >= 0);
             lo = hi;
@@ -207,7 +216,7 @@ __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_o
                 cand &= cand - 1;
                 const int c = __builtin_amdgcn_readlane(nf, src);
                 if (__ballot(lane < cnt && vis[lane] == c)) continue;          // already in the pocket (cnt <= 64 entries)
-                if (cnt >= XR_POCKET_CAP) { open_pocket = true; break; }
+                if (cnt >= budget) { open_pocket = true; break; }
                 if (lane == 0) vis[cnt] = c;
                 cnt++;
                 __builtin_amdgcn_wave_barrier();
@@ -320,7 +329,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     }
         for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_claim[i] = 0; s_wmin[i] = XR_DIAL_INF; }
     };
+    XR_MARK(1);
     build_field();
+    XR_MARK(2);
     if (tid <= X + 1) s_xc[tid] = my_xc;
     if (tid <= Y + 1) s_yc[tid] = my_yc;
     for (int i = tid + nthr; i <= X + 1; i += nthr)
@@ -335,6 +346,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1;
     }
     __syncthreads();
+    XR_MARK(3);
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
         const int apf = i < nthr ? my_ap_f : b.ap_node[R.ap_off + ap_lo + i];
@@ -367,10 +379,12 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         s_ap_conn[i] = cflag;
     }
     __syncthreads();
+    XR_MARK(4);
     // pins in closed pockets are never searched for (see xr_mark_isolated_pins)
     xr_mark_isolated_pins(nap, s_ap_f, s_ap_pin, s_ap_conn, X, Y, Z, ldir, R.magic_yz, R.magic_z,
-                          [&](int f) { return field[f] == XR_W_BLOCK; }, s_pocket, &s_niso, &s_src_iso, s_first_pin);
+                          [&](int f) { return field[f] == XR_W_BLOCK; }, s_pocket, &s_niso, &s_src_iso, s_first_pin, XR_POCKET_BUDGET_LDS);
     __syncthreads();
+    XR_MARK(5);
     for (int i = tid; i < nap; i += nthr) s_ap_conn[i] &= 0x7F;
     const int n_isolated = s_src_iso ? s_npins - 1 : s_niso;       // unreachable pins known up front
     if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
@@ -729,7 +743,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
             lmin = xr_wave_min_u32(lmin);
             if ((tid & 63) == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
             nrounds++;
-#if defined(XR_PHASE_TIMING) && !defined(XR_COUNT_HOPS)
+#if defined(XR_PHASE_TIMING) && !defined(XR_COUNT_HOPS) && !defined(XR_PROBE_SETUP)
             if (tid == XR_TIMING_TID) _ph[7] += 1;
 #endif
             __syncthreads();
@@ -1054,7 +1068,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __syncthreads();
     // pins in closed pockets are never searched for (see xr_mark_isolated_pins)
     xr_mark_isolated_pins(nap, s_ap_f, s_ap_pin, s_ap_conn, X, Y, Z, ldir, R.magic_yz, R.magic_z,
-                          [&](int f) { return node_net[f] == -1; }, s_pocket, &s_niso, &s_src_iso, s_first_pin);
+                          [&](int f) { return node_net[f] == -1; }, s_pocket, &s_niso, &s_src_iso, s_first_pin, XR_POCKET_BUDGET_BIG);
     __syncthreads();
     for (int i = tid; i < nap; i += nthr) s_ap_conn[i] &= 0x7F;
     const int n_isolated = s_src_iso ? s_npins - 1 : s_niso;       // unreachable pins known up front
