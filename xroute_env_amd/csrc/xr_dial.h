@@ -50,6 +50,9 @@
 #else
 #define XR_MARK(n) do {} while (0)
 #endif
+#ifndef XR_BIG_SPEC_FLAGS
+#define XR_BIG_SPEC_FLAGS 1     // HBM-scratch form: load node_net / owner of a neighbour together with its field word
+#endif
 #ifndef XR_DIAL_QUAD
 #define XR_DIAL_QUAD 1         // LDS form: the nodes of a bucket are expanded by quads of lanes (one lane per direction)
 #endif
@@ -1017,8 +1020,6 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         s_xc[i] = (uint32_t)(b.coords[R.xs_off + min(max(i - 1, 0), X - 1)] - b.coords[R.xs_off]) << 2;
     for (int i = tid; i <= Y + 1; i += nthr)
         s_yc[i] = (uint32_t)(b.coords[R.ys_off + min(max(i - 1, 0), Y - 1)] - b.coords[R.ys_off]) << 2;
-    auto el4x = [&](int i) { return s_xc[i + 1] - s_xc[i]; };
-    auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
     const int nap = ap_hi - ap_lo;
     if (tid == 0) {
@@ -1140,12 +1141,12 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             }
         __syncthreads();
         const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
-        auto heur = [&](int x, int y, int z) -> uint32_t {
-            const int xc = (int)s_xc[x + 1], yc = (int)s_yc[y + 1];
+        auto heur_c = [&](int xc, int yc, int z) -> uint32_t {                 // (from coordinates x4)
             const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
             const int hz = max(0, max(hb4 - z, z - hb5));
             return ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
         };
+        auto heur = [&](int x, int y, int z) -> uint32_t { return heur_c((int)s_xc[x + 1], (int)s_yc[y + 1], z); };
         int cur = 0;
         for (;;) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
@@ -1239,23 +1240,37 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                         xr_divmod(f, uYZ, R.magic_yz, x, r);
                         xr_divmod(r, uZ, R.magic_z, y, z);
                         const bool vert = (ldir >> z) & 1u;
-                        int nf = -1;
-                        int nx = (int)x, ny = (int)y, nz = (int)z;
-                        uint32_t len4 = via4;
-                        if (dir == 0) { nf = vert ? ((int)y + 1 < Y ? (int)f + Z : -1) : ((int)x + 1 < X ? (int)f + YZ : -1); len4 = vert ? el4y(y + 1) : el4x(x + 1); if (vert) ny++; else nx++; }
-                        else if (dir == 1) { nf = vert ? (y > 0 ? (int)f - Z : -1) : (x > 0 ? (int)f - YZ : -1); len4 = vert ? el4y(y) : el4x(x); if (vert) ny--; else nx--; }
-                        else if (dir == 2) { nf = ((int)z + 1 < Z) ? (int)f + 1 : -1; nz++; }
-                        else { nf = (z > 0) ? (int)f - 1 : -1; nz--; }
-                        if (nf < 0) continue;
-                        uint32_t wn = xr_ld(&fieldg[nf]);
+                        // (no branch per direction — the wave would run the four arms one after the other, each with its own round
+                        //  trips; loads from safe addresses, all issued before the first use)
+                        const int sgn = (dir & 1) ? -1 : 1;
+                        const bool planar = dir < 2;
+                        const int ddx = (planar && !vert) ? sgn : 0, ddy = (planar && vert) ? sgn : 0, ddz = planar ? 0 : sgn;
+                        const int nx = (int)x + ddx, ny = (int)y + ddy, nz = (int)z + ddz;
+                        const bool inb = (unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z;
+                        const int nf = inb ? (int)f + ddx * YZ + ddy * Z + ddz : (int)f;
+                        const uint32_t wn = xr_ld(&fieldg[nf]);
+#if XR_BIG_SPEC_FLAGS
+                        const int nn0 = node_net[nf], ow0 = owner[nf];        // flags of a first touch, loaded with the word, not after it
+#endif
+                        const uint32_t xq = s_xc[x + 1], yq = s_yc[y + 1];
+                        const uint32_t cb = (vert ? s_yc : s_xc)[(vert ? (int)y : (int)x) + 1 + (planar ? sgn : 0)];
+                        const uint32_t ca = vert ? yq : xq;
+                        const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
+                        if (!inb) continue;
                         uint32_t fl;
-                        if (wn == XR_BIG_CLEAN) { fl = node_flags(nf); if (fl == 0u) continue; }     // first touch: derive the flags
-                        else fl = wn & 3u;
+                        if (wn == XR_BIG_CLEAN) {                                 // first touch: derive the flags
+#if XR_BIG_SPEC_FLAGS
+                            fl = nn0 == -1 ? 0u : (1u | (((ow0 != 0 && ow0 != a && !(V2 && ow0 == -a)) || (nn0 > 0 && nn0 != a)) ? 2u : 0u));
+#else
+                            fl = node_flags(nf);
+#endif
+                            if (fl == 0u) continue;
+                        } else fl = wn & 3u;
                         const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + guide_of(nx, ny);
                         if (cand4 >= XR_W_USABLE_END) continue;
                         const uint32_t cw = cand4 | fl;
                         if (cw >= wn) continue;
-                        const uint32_t key = (cand4 >> 2) + heur(nx, ny, nz);        // f = d + h
+                        const uint32_t key = (cand4 >> 2) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
                         if (key > best) {                              // bound pruning: f is looked at again by the next search
                             const int k = atomicAdd(&s_ndefer, 1);
                             if (k < defer_cap) deferl[k] = f;
@@ -1317,7 +1332,8 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     s_remaining = 0;
                 }
             } else {
-                // back-trace (see the LDS form); a CLEAN neighbour was never reached and cannot be a predecessor
+                // back-trace (see the LDS form: branch-free predecessor arithmetic, two hops per round trip — here the round trips
+                // go to L2); a CLEAN neighbour was never reached and cannot be a predecessor
                 int v = __builtin_amdgcn_readfirstlane(s_ap_f[best_i]);
                 uint32_t vw = xr_ld(&fieldg[v]);
                 uint32_t ux, ur, uy, uz;
@@ -1325,45 +1341,67 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 xr_divmod(ur, uZ, R.magic_z, uy, uz);
                 int x = (int)ux, y = (int)uy, z = (int)uz;
                 int np = 0;
+                const int lvl2 = tid >= 6 && tid < 42;
+                const int d1 = tid < 6 ? tid : (tid < 42 ? (tid - 6) / 6 : 6);
+                const int d2 = lvl2 ? (tid - 6) % 6 : 6;
+                auto pred_of = [&](int f, int cx, int cy, int cz, int d, uint32_t& len4) -> int {
+                    const bool vt = (ldir >> cz) & 1u;
+                    const int ddx = (d == 0) - (d == 2), ddy = (d == 3) - (d == 1), ddz = (d == 4) - (d == 5);
+                    const int nx = cx + ddx, ny = cy + ddy, nz = cz + ddz;
+                    const bool along = ddz != 0 || (ddx != 0 && !vt) || (ddy != 0 && vt);
+                    const bool inb = d < 6 && along && (unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z;
+                    const uint32_t* ctab = ddx ? s_xc : s_yc;
+                    const int c0 = ddx ? cx : cy, c1 = c0 + ddx + ddy;
+                    const uint32_t ca = ctab[c0 + 1], cb = ctab[(ddz ? c0 : c1) + 1];
+                    len4 = ddz ? via4 : (cb > ca ? cb - ca : ca - cb);
+                    return inb ? f + ddx * YZ + ddy * Z + ddz : -1;
+                };
+                auto claim_node = [&](int node, uint32_t w, int src, uint32_t pl4) {     // thread 0
+                    if (w & 2u) { d_vio += 1; d_held += 1; }
+                    pathg[np] = (uint32_t)node;
+                    if (plen < b.path_cap) path[plen] = node;
+                    plen++;
+                    fnv_mix(h, (uint32_t)node);
+                    if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
+                };
                 while ((vw >> 2) > 0) {
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);
-                    const bool vert = (ldir >> z) & 1u;
-                    int u = -1;
-                    uint32_t len4 = 0;
-                    switch (tid) {
-                    case 0: if (!vert && x + 1 < X) { u = v + YZ; len4 = el4x(x + 1); } break;   // E
-                    case 1: if (vert && y > 0)      { u = v - Z;  len4 = el4y(y); } break;       // S
-                    case 2: if (!vert && x > 0)     { u = v - YZ; len4 = el4x(x); } break;       // W
-                    case 3: if (vert && y + 1 < Y)  { u = v + Z;  len4 = el4y(y + 1); } break;   // N
-                    case 4: if (z + 1 < Z)          { u = v + 1;  len4 = via4; } break;           // U
-                    case 5: if (z > 0)              { u = v - 1;  len4 = via4; } break;           // D
-                    default: break;
-                    }
-                    uint32_t uw = XR_W_BLOCK;
-                    bool ok = false;
-                    if (u >= 0) {
-                        uw = xr_ld(&fieldg[u]);
-                        ok = (uw - 1u) < (XR_W_USABLE_END - 1u) && (uw & ~3u) + len4 == need4;
-                    }
-                    const unsigned long long mm = __ballot(ok);
+                    uint32_t len1 = 0, len2 = 0;
+                    const int u1 = pred_of(v, x, y, z, d1, len1);
+                    const int x1 = x + (d1 == 0) - (d1 == 2), y1 = y + (d1 == 3) - (d1 == 1), z1 = z + (d1 == 4) - (d1 == 5);
+                    const int u2 = (lvl2 && u1 >= 0) ? pred_of(u1, x1, y1, z1, d2, len2) : -1;
+                    const uint32_t rw1 = xr_ld(&fieldg[u1 >= 0 ? u1 : v]), rw2 = xr_ld(&fieldg[u2 >= 0 ? u2 : v]);
+                    const uint32_t uw1 = u1 >= 0 ? rw1 : XR_W_BLOCK, uw2 = u2 >= 0 ? rw2 : XR_W_BLOCK;
+                    const bool use1 = (uw1 - 1u) < (XR_W_USABLE_END - 1u);
+                    const bool ok1 = tid < 6 && use1 && (uw1 & ~3u) + len1 == need4;
+                    const bool ok2 = use1 && (uw2 - 1u) < (XR_W_USABLE_END - 1u) &&
+                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1);
+                    const unsigned long long mm = __ballot(ok1), mm2 = __ballot(ok2);
                     if (mm == 0) { if (tid == 0) status |= 0x100; break; }
                     const int src = __ffsll((long long)mm) - 1;
-                    const int pu = __builtin_amdgcn_readlane(u, src);
-                    const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw, src);
-                    const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len4, src);
-                    if (tid == 0) {
-                        if (vw & 2u) { d_vio += 1; d_held += 1; }
-                        pathg[np] = (uint32_t)v;
-                        if (plen < b.path_cap) path[plen] = v;
-                        plen++;
-                        fnv_mix(h, (uint32_t)v);
-                        if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
-                    }
+                    const int pu = __builtin_amdgcn_readlane(u1, src);
+                    const uint32_t puw = (uint32_t)__builtin_amdgcn_readlane((int)uw1, src);
+                    const uint32_t pl4 = (uint32_t)__builtin_amdgcn_readlane((int)len1, src);
+                    if (tid == 0) claim_node(v, vw, src, pl4);
                     np++;
                     x += (src == 0) - (src == 2);
                     y += (src == 3) - (src == 1);
                     z += (src == 4) - (src == 5);
                     v = pu; vw = puw;
+                    if ((vw >> 2) == 0) break;
+                    const uint32_t m6 = (uint32_t)(mm2 >> (6 + 6 * src)) & 63u;
+                    if (m6 == 0) { if (tid == 0) status |= 0x100; break; }
+                    const int srcb = __ffs((int)m6) - 1;
+                    const int lane2 = 6 + 6 * src + srcb;
+                    const int pu2 = __builtin_amdgcn_readlane(u2, lane2);
+                    const uint32_t puw2 = (uint32_t)__builtin_amdgcn_readlane((int)uw2, lane2);
+                    const uint32_t pl42 = (uint32_t)__builtin_amdgcn_readlane((int)len2, lane2);
+                    if (tid == 0) claim_node(v, vw, srcb, pl42);
+                    np++;
+                    x += (srcb == 0) - (srcb == 2);
+                    y += (srcb == 3) - (srcb == 1);
+                    z += (srcb == 4) - (srcb == 5);
+                    v = pu2; vw = puw2;
                 }
                 if (tid == 0 && (status & 0x100)) {
                     s_remaining = 0;
