@@ -53,6 +53,9 @@
 #ifndef XR_BIG_SPEC_FLAGS
 #define XR_BIG_SPEC_FLAGS 1     // HBM-scratch form: load node_net / owner of a neighbour together with its field word
 #endif
+#ifndef XR_POCKET_MASK
+#define XR_POCKET_MASK 1        // LDS form: pocket flood with a bitmask as its visited set
+#endif
 #ifndef XR_DIAL_QUAD
 #define XR_DIAL_QUAD 1         // LDS form: the nodes of a bucket are expanded by quads of lanes (one lane per direction)
 #endif
@@ -384,8 +387,91 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     __syncthreads();
     XR_MARK(4);
     // pins in closed pockets are never searched for (see xr_mark_isolated_pins)
+#if XR_POCKET_MASK
+    // LDS form: the flood keeps its visited set in a node bitmask that is still all-zero at this point (wave 0: defer, wave 1:
+    // claim) — test-and-set by one LDS atomic per candidate, all candidates of a pass at once — instead of comparing every
+    // candidate with every node visited so far; the bits are cleared again afterwards.  Same pockets, same verdicts.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        if (wv < 2) {
+            uint32_t* vmask = wv == 0 ? s_defer : s_claim;
+            int* pcnt = &s_pocket[wv][0];
+            unsigned short* vis = reinterpret_cast<unsigned short*>(&s_pocket[wv][1]);
+            const int vcap = 2 * (XR_POCKET_CAP + 8 - 1);
+            const int nwv = min((int)(nthr >> 6), 2);
+            auto visit = [&](uint32_t f) {                 // new in this flood: counted and (room permitting) listed
+                uint32_t q, r;
+                xr_divmod(f, umw, magic_mw, q, r);
+                const uint32_t bit = 1u << q;
+                if (!(atomicOr(&vmask[r], bit) & bit)) {
+                    const int pos = atomicAdd(pcnt, 1);
+                    if (pos < vcap) vis[pos] = (unsigned short)f;
+                    else atomicAnd(&vmask[r], ~bit);      // (far beyond the budget: the pocket is open anyway)
+                }
+            };
+            int pj = 0;
+            for (int i0 = 0; i0 < nap; i0++) {
+                if (!(s_ap_conn[i0] & 0x80)) continue;    // (bit 7: first access point of its pin)
+                const short pin = s_ap_pin[i0];
+                if ((pj++ % nwv) != wv) continue;
+                if (lane == 0) *pcnt = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < nap; i += 64) if (s_ap_pin[i] == pin) visit((uint32_t)s_ap_f[i]);
+                __builtin_amdgcn_wave_barrier();
+                int cnt = __builtin_amdgcn_readfirstlane(*pcnt), lo = 0;
+                while (lo < cnt && cnt <= XR_POCKET_BUDGET_LDS) {
+                    const int hi = min(cnt, lo + 16);
+                    const int k = lo + (lane >> 2), dir = lane & 3;
+                    if (k < hi) {
+                        const int f = (int)vis[k];
+                        uint32_t x, r, y, z;
+                        xr_divmod((uint32_t)f, (uint32_t)YZ, R.magic_yz, x, r);
+                        xr_divmod(r, (uint32_t)Z, R.magic_z, y, z);
+                        const bool vert = (ldir >> z) & 1u;
+                        const int sgn = (dir & 1) ? -1 : 1;
+                        const bool planar = dir < 2;
+                        const int ddx = (planar && !vert) ? sgn : 0, ddy = (planar && vert) ? sgn : 0, ddz = planar ? 0 : sgn;
+                        const int nx = (int)x + ddx, ny = (int)y + ddy, nz = (int)z + ddz;
+                        if ((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z) {
+                            const int nf = f + ddx * YZ + ddy * Z + ddz;
+                            if (field[nf] != XR_W_BLOCK) visit((uint32_t)nf);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    lo = hi;
+                    cnt = __builtin_amdgcn_readfirstlane(*pcnt);
+                }
+                const bool open_pocket = cnt > XR_POCKET_BUDGET_LDS;
+                // closed pocket: isolated unless it holds an access point of another pin of the net
+                bool other = false;
+                if (!open_pocket)
+                    for (int b0 = 0; b0 < nap; b0 += 64) {
+                        const int i = b0 + lane;
+                        bool hit = false;
+                        if (i < nap && s_ap_pin[i] != pin) {
+                            uint32_t q, r;
+                            xr_divmod((uint32_t)s_ap_f[i], umw, magic_mw, q, r);
+                            hit = (vmask[r] >> q) & 1u;
+                        }
+                        if (__ballot(hit)) other = true;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < min(cnt, vcap); i += 64) {          // the mask goes back to all-zero
+                    uint32_t q, r;
+                    xr_divmod((uint32_t)vis[i], umw, magic_mw, q, r);
+                    atomicAnd(&vmask[r], ~(1u << q));
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (open_pocket || other) continue;
+                for (int i = lane; i < nap; i += 64) if (s_ap_pin[i] == pin) s_ap_conn[i] = (s_ap_conn[i] & 0x80) | 2;
+                if (lane == 0) { if ((int)pin == s_first_pin) s_src_iso = 1; else atomicAdd(&s_niso, 1); }
+            }
+        }
+    }
+#else
     xr_mark_isolated_pins(nap, s_ap_f, s_ap_pin, s_ap_conn, X, Y, Z, ldir, R.magic_yz, R.magic_z,
                           [&](int f) { return field[f] == XR_W_BLOCK; }, s_pocket, &s_niso, &s_src_iso, s_first_pin, XR_POCKET_BUDGET_LDS);
+#endif
     __syncthreads();
     XR_MARK(5);
     for (int i = tid; i < nap; i += nthr) s_ap_conn[i] &= 0x7F;
