@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 timeout 1200 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
 cd /tmp
 export XR_BENCH_NO_FORK=1      # no worker pool under the profiler (its tool is preloaded into every child)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs > $OUT/trace.log 2>&1
