@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 253 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 STAGGER_SEED = 0x5EED5EED
 
@@ -71,6 +72,9 @@ def parse():
                     help="skip the `extras` of the default N = 1 line (batch-1 Game.step latency = BASELINE config 1; DQN counterpart attached on 1024 envs = config 3)")
     ap.add_argument("--c5-envs", type=int, default=1024, help="env slots of the BASELINE config 5 leg (256x256x12 regions)")
     ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
+    ap.add_argument("--pack-envs", type=int, default=4096,
+                    help="env slots of the design-derived leg: the 253 regions extracted from the reference's ispd18_test1.input.{lef,def,guide} "
+                         "(tests/golden/ispd18_test1_regions.npz) cycled over this many slots, full step in the queue form (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--learner", action="store_true",
@@ -225,11 +229,50 @@ def kernel_entry(name, ms, nbytes, env_steps, bound, note):
             "frac": ach / HBM_PEAK_GBPS, "env_steps_per_s": env_steps / (ms * 1e-3) if ms > 0 else 0.0, "note": note}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: start the N ranks ourselves — a child `python -m
+    torch.distributed.run --nproc-per-node N bench.py <same flags>` — and forward rank 0's JSON line.  Decided before this
+    process has touched the GPU (nothing here imports torch); the children are fresh processes (no exec / re-exec).  Exit
+    code = the launcher's: non-zero when any rank failed."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks ({' '.join(cmd[1:8])} ...)", file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:                  # rank 0 prints ONE JSON line; anything else the ranks write to stdout goes to stderr
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited 0 but printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never benchmark a different number of GPUs than the one asked for (a flat, wrong scaling curve)
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: refusing to run", file=sys.stderr)
+        sys.exit(2)
 
     # ---- env slots of this rank; regions are generated on the host cores BEFORE the GPU is touched (fork pool) -------
     strong = args.global_envs > 0
@@ -246,6 +289,10 @@ def main():
         regions = gen_regions(args.config, B, first_env)
     do_legs = world == 1 and rank == 0 and not args.no_legs and not args.region_pack
     c5_regions = gen_regions(5, min(args.c5_regions, args.c5_envs)) if do_legs and args.c5_envs > 0 else None
+    pack_regions = None
+    if do_legs and args.pack_envs > 0 and os.path.exists(PACK_PATH):
+        from xroute_env_amd.lefdef import load_region_pack
+        pack_regions = load_region_pack(PACK_PATH)
 
     import numpy as np
     import torch
@@ -263,8 +310,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -281,8 +326,12 @@ def main():
     from xroute_env_amd.dist import RECORD_BYTES, gather_records_fixed
 
     if args.agent:
+        if world > 1:
+            if rank == 0:
+                print("bench.py: --agent runs on ONE GPU (rank 0 would report a one-GPU number for N): use --gpus 1", file=sys.stderr)
+            sys.exit(2)
         if rank == 0:
-            print(json.dumps(agent_leg(args, regions, dev, world)), flush=True)
+            print(json.dumps(agent_leg(args, regions, dev, 1)), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -404,8 +453,9 @@ def main():
     obs_bytes = float((4.0 * (2.0 + 7.0 * k_after) * n_nodes[None, :]).sum().item()) / nst
     real_per_step = real_steps / nst
     kernels = []
+    headline_form = batch.observe_timing()[0] if fused else 0      # (asked NOW: the legs below run other forms on the same batch)
     if fused:
-        form = batch.observe_timing()[0]            # 1 fused launch, 2 split, 3 queue (the default where it applies)
+        form = headline_form                        # 1 fused launch, 2 split, 3 queue (the default where it applies)
         kname = "xr_step_queue_kernel" if form == 3 else "xr_route_kernel"
         note = ("the step kernel (xr_batch_step_observe, queue form): one persistent launch draining route tasks (LDS-resident "
                 "router: latency-bound) and net-plane units of the fp32 observation (HBM-write-bound) — a MIXED kernel, priced "
@@ -499,6 +549,11 @@ def main():
                 kernels.append(config5_leg(args, c5_regions, dev))
             except Exception as ex:
                 kernels.append({"kernel": "config5 route", "error": str(ex)})
+        if pack_regions:
+            try:        # (its observation buffer, 68 GB at K = 77, sits beside the headline's 36 GB: sized for 288 GB of HBM)
+                kernels.append(pack_leg(args, pack_regions, dev))
+            except Exception as ex:
+                kernels.append({"kernel": "xr_step_queue_kernel (design-derived ispd18_test1 region pack)", "error": str(ex)})
 
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes of THIS command (tools/profile_round.sh)
@@ -544,7 +599,9 @@ def main():
                                    +
                                    "full step = random net-order action + XR-Maze v1 route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
-                                   + (" (one persistent launch after a planning kernel)" if fused and batch.observe_timing()[0] == 3 else " (fused launch)" if fused else "")
+                                   + (" (queue form: one persistent launch after a planning kernel)" if headline_form == 3 else
+                                      " (split form: route kernel + concurrent net-plane writer)" if headline_form == 2 else
+                                      " (fused launch: one workgroup per env)" if fused else "")
                                    + (", RCCL all_gather of per-env results" if world > 1 else "")
                                    + (" + learner flow (policy on rank 0, i32 action broadcast)" if learner else "")
                                    + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
@@ -711,6 +768,73 @@ def _head_of(batch, head):
     head.copy_(full[:, :head.shape[1]])
     del full
     return head
+
+
+def pack_leg(args, pack, dev):
+    """The REAL ispd18_test1 regions on the record: 4096 env slots over the 253 regions `xroute_env_amd.lefdef` extracts from the
+    reference's own ispd/ispd18_test1/ispd18_test1.input.{lef,def,guide} (per-GCell windows: 20-26 x 27-45 x 9 tracks, K up to 77),
+    full step in the default queue form, with its own oracle replay.  Their N is rarely a multiple of 4, so channel planes are not
+    16-byte aligned: the unit writer is xr_unit_stream.  Slots keep their region (max_route_count = 2^30: the replay needs no
+    rotation bookkeeping; rotation itself is covered by the tests)."""
+    import numpy as np
+    import torch
+    from xroute_env_amd.batch import RegionBatch
+    Bp = args.pack_envs
+    slot_regions = [pack[e % len(pack)] for e in range(Bp)]
+    b = RegionBatch(pack, n_envs=Bp, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
+                    launch_order=args.launch_order, max_route_count=1 << 30)
+    b.reset(rotate=True)
+    acts = torch.empty(Bp, dtype=torch.int32, device=dev)
+    obs = b.alloc_observation()
+    n_nodes = torch.tensor([r.n_nodes for r in slot_regions], dtype=torch.float64, device=dev)
+    nl0 = b.fetch("nlegal").cpu().numpy()
+    off = stagger_offsets(nl0, 0)
+    off_d = torch.from_numpy(off).to(dev)
+    pre_seeds = [args.seed ^ 0x9ACC ^ i for i in range(int(off.max()))]
+    zero = torch.zeros_like(acts)
+    for i, sd in enumerate(pre_seeds):
+        b.random_actions(sd, acts)
+        torch.where(off_d > i, acts, zero, out=acts)
+        b.step(acts)
+    n_w, n_t = 3, max(args.steps, 5)
+    seeds = [args.seed + 300000 + i for i in range(n_w + n_t)]
+    klog = torch.zeros((n_t, Bp), dtype=torch.int32, device=dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
+    for i in range(n_w):
+        b.random_actions(seeds[i], acts)
+        b.step(acts, obs)
+    s0 = b.total_steps()
+    for i, (e0, e1) in enumerate(evs):
+        b.random_actions(seeds[n_w + i], acts)
+        e0.record()
+        b.step(acts, obs)
+        e1.record()
+        b.fetch("nlegal", klog[i])
+    torch.cuda.synchronize(dev)
+    ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
+    real = (b.total_steps() - s0) / n_t
+    info = b.observe_info()
+    k_after = klog.to(torch.float64)
+    nbytes = float((4.0 * n_nodes).sum().item()) + float((4.0 * (2.0 + 7.0 * k_after) * n_nodes[None, :]).sum().item()) / n_t
+    ent = kernel_entry("xr_step_queue_kernel (design-derived ispd18_test1 region pack)", ms, nbytes, real,
+                       "hbm-write (routing phase: lds-latency)",
+                       f"{Bp} env slots over the {len(pack)} regions extracted from the reference's ispd18_test1.input.lef/def/guide "
+                       "(tests/golden/ispd18_test1_regions.npz, xroute_env_amd/lefdef.py): full step (random net-order action + route + "
+                       "fp32 observation of every env), queue form, stationary nets-left distribution; planes are not 16-byte aligned "
+                       "(N % 4 != 0 for 98 % of the regions): unit writer xr_unit_stream; bytes = state load + 4·N·(2+7K) per slot")
+    ent["data"] = "ispd18_test1 (design-derived regions)"
+    ent["form"] = info
+    ent["mean_nets_left"] = float(k_after.mean().item())
+    ent["mean_nodes"] = float(n_nodes.mean().item())
+    gpu_hash = b.fetch("hash").cpu().numpy().view("uint64")
+    gpu_cum = b.fetch("cum").cpu().numpy()
+    b.close()
+    del obs
+    try:
+        ent["parity"] = parity_check(slot_regions, seeds, (off, pre_seeds), gpu_hash, gpu_cum)
+    except Exception as ex:
+        ent["parity"] = {"error": str(ex)}
+    return ent
 
 
 def config5_leg(args, c5_regions, dev):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 3
+#define XR_ABI_VERSION 4
 
 /* status codes */
 #define XR_OK            0
@@ -70,6 +70,10 @@ extern "C" {
 #define XR_ENV_UNREACHABLE   2   /* at least one pin could not be reached */
 #define XR_ENV_PATH_TRUNC    4   /* path longer than path_cap: path list truncated, metrics exact */
 #define XR_ENV_WAS_RESET     8   /* auto_reset: this step re-initialised the env instead of routing */
+#define XR_ENV_ROUTER_ABORT 16   /* the router gave up on this net: a search exceeded its round cap (1024 + N relaxation rounds, far
+                                    beyond anything a legal region needs; xr_config.debug_round_cap forces it).  The pins not
+                                    connected yet are charged as unreachable; the env stays consistent and the device never
+                                    spins on a pathological region */
 
 typedef struct xr_batch xr_batch;
 
@@ -132,6 +136,9 @@ typedef struct xr_config {
                                  launch; the prediction is the chosen net's bounding box and pin count), slot order otherwise;
                                  1 = slot order always; 2 = longest first always.  Results do not depend on it.  (Takes the
                                  struct's former tail padding: sizeof(xr_config) is unchanged.) */
+    int32_t debug_round_cap;  /* 0 = default.  > 0: relaxation rounds one search of the router may take before it aborts with
+                                 XR_ENV_ROUTER_ABORT (tests force the abort path with 1) */
+    int32_t reserved0;        /* keep 0 */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--envs", "256", "--cpu-seconds", "2", "--c5-envs", "8", "--c5-regions", "2"] + extra, capture_output=True, text=True, timeout=600)
+                          "--envs", "256", "--cpu-seconds", "2", "--c5-envs", "8", "--c5-regions", "2", "--pack-envs", "512"] + extra, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -41,6 +41,10 @@ def test_bench_json_contract(extra):
         # per-kernel lines: the step kernel, the route-only kernel and the BASELINE config 5 route, each with its own numbers
         assert names[0] == "xr_step_queue_kernel" and "xr_route_kernel" in names and any("config 5" in n for n in names)
         assert any("in-place" in n for n in names)
+        # the REAL ispd18_test1 regions (extracted from the reference's LEF/DEF/guide) with their own oracle replay
+        pk = [k for k in d["kernels"] if "design-derived" in k["kernel"]][0]
+        assert pk["parity"]["hash_chains_equal"] is True and pk["parity"]["cumulative_metrics_equal"] is True and pk["form"]["form"] == 3
+        assert "queue form" in d["config"]["workload"]
         for k in d["kernels"]:
             assert k["ms"] > 0 and k["bytes"] > 0 and abs(k["frac"] - k["achieved"] / 8000.0) < 1e-3 and k["env_steps_per_s"] > 0
         # driver-visible side numbers: BASELINE config 1 latency and config 3 with the DQN counterpart attached
@@ -106,6 +110,24 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert "learner flow" in d["config"]["workload"] and d["value"] > 0 and d["config"]["slots_stepped_per_batch_step"] > 0.5
+
+
+def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must not benchmark ONE GPU under an N = 2 label: it starts the two ranks
+    itself (a child torch.distributed.run) and forwards rank 0's line; a WORLD_SIZE that contradicts --gpus is refused."""
+    env = dict(os.environ, XR_BENCH_BACKEND="gloo", XR_BENCH_SAME_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--envs", "128"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 256 and d["value"] > 0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--envs", "16"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode == 2 and "refusing" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_value_is_stationary_in_warmup():

@@ -357,3 +357,36 @@ def test_longest_first_order_on_a_multi_round_batch():
     order = twins[0].fetch("route_order").cpu().numpy()
     assert sorted(order.tolist()) == list(range(B)) and not np.array_equal(order, np.arange(B))
     assert twins[1].fetch("route_order").abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(force_scratch_field=True), dict(router=1)],
+                         ids=["frontier-lds", "frontier-hbm-scratch", "sweeps"])
+def test_round_cap_aborts_the_net_not_the_device(kw):
+    """No router loop is unbounded: a search that exceeds its round cap (default 1024 + N, forced to 1 here) gives up on the
+    net — XR_ENV_ROUTER_ABORT, remaining pins charged as unreachable — and the env stays consistent: the episode goes on,
+    the legal set shrinks, and the next launch with the default cap routes as the oracle does."""
+    from xroute_env_amd import _lib
+    from xroute_env_amd.batch import RegionBatch
+    regions = [generate_region(9100 + i) for i in range(16)]
+    batch = RegionBatch(regions, device="cuda:0", debug_round_cap=1, **kw)
+    batch.reset()
+    aborted = 0
+    for _ in range(6):
+        legal = batch.legal_sets()
+        acts = [min(s) if s else 0 for s in legal]
+        nl0 = batch.fetch("nlegal").cpu().numpy().copy()
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+        torch.cuda.synchronize()
+        st = batch.fetch("status").cpu().numpy()
+        nl1 = batch.fetch("nlegal").cpu().numpy()
+        dl = batch.fetch("delta").cpu().numpy()
+        ab = (st & _lib.XR_ENV_ROUTER_ABORT) != 0
+        aborted += int(ab.sum())
+        assert np.all((st[ab] & _lib.XR_ENV_UNREACHABLE) != 0) and np.all(dl[ab, 0] >= 1)
+        assert np.array_equal(nl1, nl0 - (np.array(acts) != 0))          # bookkeeping intact: the routed (or abandoned) net left netSet
+    assert aborted > 0
+    # the default cap never triggers on these regions (and the parity suites compare statuses with the oracle's)
+    ok = RegionBatch(regions, device="cuda:0", **kw)
+    ok.reset()
+    ok.step(torch.tensor([1] * 16, dtype=torch.int32, device="cuda:0"))
+    assert not np.any(ok.fetch("status").cpu().numpy() & _lib.XR_ENV_ROUTER_ABORT)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("XR_LIB", "libxroute_hip.so"))   #
 XR_OK = 0
 XR_ERR_INVALID, XR_ERR_NOMEM, XR_ERR_HIP, XR_ERR_STATE, XR_ERR_RANGE, XR_ERR_PARSE = -1, -2, -3, -4, -5, -6
 
-XR_ENV_OK, XR_ENV_BAD_ACTION, XR_ENV_UNREACHABLE, XR_ENV_PATH_TRUNC, XR_ENV_WAS_RESET = 0, 1, 2, 4, 8
+XR_ENV_OK, XR_ENV_BAD_ACTION, XR_ENV_UNREACHABLE, XR_ENV_PATH_TRUNC, XR_ENV_WAS_RESET, XR_ENV_ROUTER_ABORT = 0, 1, 2, 4, 8, 16
 XR_OWNER_FOREIGN = 0x7FFF
 
 (XR_FETCH_CUM, XR_FETCH_DELTA, XR_FETCH_REWARD, XR_FETCH_DONE, XR_FETCH_NLEGAL, XR_FETCH_STATUS,
@@ -40,7 +40,7 @@ class XrConfig(C.Structure):
                 ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
                 ("guide_cost", C.c_int32), ("guide_margin", C.c_int32), ("maze_end_iter", C.c_int32),
                 ("stream_per_region", C.c_int32), ("obs_helper_blocks", C.c_int32), ("obs_split_permille", C.c_int32),
-                ("launch_order", C.c_int32)]
+                ("launch_order", C.c_int32), ("debug_round_cap", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class XrStepRecord(C.Structure):          # include/xroute_hip.h xr_step_record (48 bytes)
@@ -110,7 +110,7 @@ def lib():
         fn = getattr(L, name)
         if name not in ("xr_last_error", "xr_config_default"):
             fn.restype = C.c_int32
-    if L.xr_abi_version() != 3:
+    if L.xr_abi_version() != 4:
         raise RuntimeError("libxroute_hip.so ABI version mismatch")
     _LIB = L
     return L

@@ -43,7 +43,7 @@ class RegionBatch:
                  force_scratch_field: bool = False, obs_mode: int = 0, obs_writer_blocks: int = 0,
                  obs_split_permille: int = 0, router: int = 0, dial_mult: int = 0,
                  stream_per_region: bool = False, obs_helper_blocks: int = 0, launch_order: int = 0,
-                 guide_cost: int = 0, guide_margin: int = 0, maze_end_iter: int = 1):
+                 guide_cost: int = 0, guide_margin: int = 0, maze_end_iter: int = 1, debug_round_cap: int = 0):
         self.device = _require_gpu(device)
         self.L = _lib.lib()
         self.regions = list(regions)
@@ -60,10 +60,11 @@ class RegionBatch:
         cfg.obs_mode = int(obs_mode)                    # 0 default, 1 fused single launch, 2 split (route || net-plane writer)
         cfg.obs_writer_blocks = int(obs_writer_blocks)
         cfg.obs_split_permille = int(obs_split_permille)   # split form: share of the net planes the writer kernel takes
-        cfg.router = int(router)                        # 0 default (bucketed frontier), 1 line-segment sweeps, 2 frontier (required)
+        cfg.router = int(router)                        # 0 auto (frontier router; the full-rewrite queue launch of >= 4096 slots takes the sweeps), 1 line-segment sweeps, 2 frontier (required)
         cfg.dial_mult = int(dial_mult)
         cfg.launch_order = int(launch_order)             # route-only launches: 0 auto, 1 slot order, 2 longest predicted route first
-        cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (-1 default, 0 none)
+        cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (0 = none = the default; < 0 is rejected)
+        cfg.debug_round_cap = int(debug_round_cap)       # 0 default (1024 + N rounds per search); tests force XR_ENV_ROUTER_ABORT with 1
         cfg.guide_cost, cfg.guide_margin, cfg.maze_end_iter = int(guide_cost), int(guide_margin), int(maze_end_iter)   # XR-Maze v2
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg

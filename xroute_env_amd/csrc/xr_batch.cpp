@@ -177,6 +177,8 @@ void xr_config_default(xr_config* c) {
     c->stream_per_region = 0;
     c->obs_helper_blocks = 0;
     c->launch_order = 0;
+    c->debug_round_cap = 0;
+    c->reserved0 = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -211,6 +213,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
         return fail(XR_ERR_RANGE, "xr_batch_create: guide_cost in [0, 2^22), guide_margin >= 0, maze_end_iter in 1..8 with drc_cost*drc_unit << (maze_end_iter-1) < 2^22");
     if (cfg->stream_per_region < 0 || cfg->stream_per_region > 1 || (cfg->stream_per_region && cfg->n_envs > 64))
         return fail(XR_ERR_RANGE, "xr_batch_create: stream_per_region is 0 or 1 and needs n_envs <= 64");
+    if (cfg->debug_round_cap < 0 || cfg->obs_helper_blocks < 0)
+        return fail(XR_ERR_INVALID, "xr_batch_create: debug_round_cap and obs_helper_blocks must be >= 0");
     if (cfg->block_threads != 0 && (cfg->block_threads < 64 || cfg->block_threads > 1024 || cfg->block_threads % 64))
         return fail(XR_ERR_INVALID, "xr_batch_create: block_threads must be a multiple of 64 in [64, 1024]");
     int ndev = 0;
@@ -242,6 +246,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->loaded = false;
     b->obs_valid_ptr = nullptr;
     b->n_cus = 0;
+    b->route_slots = 0;
     memset(&b->dev, 0, sizeof(b->dev));
 
     std::vector<XrRegionDev> hreg(n_regions);
@@ -602,6 +607,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.touched = b->touched.p; d.records = b->records.p;
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
+    d.round_cap = b->cfg.debug_round_cap;
     d.guide_cost = b->cfg.guide_cost; d.guide_margin = b->cfg.guide_margin; d.maze_end_iter = b->cfg.maze_end_iter;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
@@ -757,7 +763,7 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         // in-place form: only when THIS buffer holds the observation of the state before the step (else: a full write)
         d.obs_incremental = (inplace && b->obs_valid_ptr == out_dev && b->obs_valid_stride == env_stride) ? 1 : 0;
         b->last_obs_inplace = d.obs_incremental;
-        b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
+        b->obs_valid_ptr = nullptr;                 // (set again below once every launch of this call has been enqueued without error)
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
         XR_HIP(xr_launch_plan(&d, actions_dev, st));
         // (route tasks in slot order: longest-first measured SLOWER in the queue forms, full rewrite 1.72 -> 1.83 ms, in-place
@@ -796,12 +802,17 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
             XR_HIP(hipEventRecord(b->ev_join, b->aux_stream));
             XR_HIP(hipStreamWaitEvent(st, b->ev_join, 0));
         }
+        b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
         return XR_OK;
     }
     b->last_obs_mode = split ? XR_OBS_SPLIT : XR_OBS_FUSED;
     b->last_obs_inplace = 0;                                  // the fused and split forms always write the whole observation
-    b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
-    if (!split) return launch_route_form(b, d, actions_dev, st);
+    b->obs_valid_ptr = nullptr;
+    if (!split) {
+        const int32_t rc = launch_route_form(b, d, actions_dev, st);
+        if (rc == XR_OK) { b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride; }
+        return rc;
+    }
     // plan (caller's stream) -> fork: net-plane writer on the internal stream || route kernel (+ planes 0..1) on the
     // caller's stream -> join.  Everything is ordered by events; the host never waits.
     d.obs_head_only = 1;
@@ -815,6 +826,7 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
                                b->aux_stream));
     XR_HIP(hipEventRecord(b->ev_w1, b->aux_stream));
     XR_HIP(hipStreamWaitEvent(st, b->ev_w1, 0));
+    b->obs_valid_ptr = out_dev; b->obs_valid_stride = env_stride;
     return XR_OK;
 }
 }  // namespace

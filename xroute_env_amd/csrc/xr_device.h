@@ -128,5 +128,6 @@ struct XrBatchDev {
     int32_t guide_cost, guide_margin, maze_end_iter;   // XR-Maze v2 knobs (0, 0, 1 = XR-Maze v1)
     int32_t dial_mult_big;   // the same for the HBM-scratch form
     int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
+    int32_t round_cap;       // relaxation rounds one search may take before the router aborts (0: 1024 + N), XR_ENV_ROUTER_ABORT
     double w_violation, w_via, w_wirelength;
 };

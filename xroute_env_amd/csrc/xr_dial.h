@@ -261,6 +261,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
     __shared__ int s_gb[4], s_retry;                          // XR-Maze v2: guide box of the net (track indices), rip-up decision
+    __shared__ int s_abort;                                   // a hop loop hit the round cap
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -272,6 +273,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     const int YZ = Y * Z;
     const uint32_t ldir = R.ldir_mask;
     const int mw = (N + 31) >> 5;
+    const int round_cap = b.round_cap > 0 ? b.round_cap : 1024 + N;
     const uint32_t umw = (uint32_t)mw, magic_mw = R.magic_mw;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
@@ -348,7 +350,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     auto el4y = [&](int i) { return s_yc[i + 1] - s_yc[i]; };
     (void)el4x; (void)el4y;
     if (tid == 0) {
-        s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0;
+        s_first_pin = 0x7FFFFFFF; s_npins = 0; s_niso = 0; s_src_iso = 0; s_abort = 0;
         s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1;
     }
     __syncthreads();
@@ -536,10 +538,15 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         auto heur = [&](int x, int y, int z) -> uint32_t { return heur_c((int)s_xc[x + 1], (int)s_yc[y + 1], z); };
         (void)heur;
         int cur = 0;
-        for (;;) {
+        // Bounded: a search takes a few tens of rounds (BASELINE configs: <= 43); round_cap = 1024 + N is far beyond any legal
+        // region (a maze whose only path visits every node needs ~N/4).  Past it the router gives up on this net
+        // (XR_ENV_ROUTER_ABORT): the env, not the device, pays for a pathological input.
+        bool aborted = false;
+        for (int nsr = 0;; nsr++) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
             const uint32_t m = s_min[cur], best = s_bst[cur];
             if (m == XR_DIAL_INF || m > best) break;                 // uniform
+            if (nsr >= round_cap || s_abort) { aborted = true; break; }   // uniform (s_abort: written before the last barrier)
             const uint32_t hi = m + delta;
             uint32_t lmin = XR_DIAL_INF;
             if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; }
@@ -637,7 +644,11 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     const int dir = lane & 3, qbase = lane & ~3;
                     int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
                     uint32_t gd4 = 0;
-                    for (;;) {
+                    for (int nhop = 0;; nhop++) {
+                        if (nhop >= round_cap) {          // (every hop lowers a field word: finite anyway; the cap is the hang guard)
+                            if (gf >= 0 && dir == 0) { xr_mask_or(s_open, (uint32_t)gf, umw, magic_mw); s_abort = 1; }
+                            break;
+                        }
                         const unsigned long long idle_g = __ballot(gf < 0) & 0x1111111111111111ULL;       // one bit per idle quad
                         if (gf < 0) {
                             const int idx = qh + __popcll(idle_g & ((1ULL << qbase) - 1ULL));
@@ -841,6 +852,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         }
         XR_LAP(6);
 
+        if (aborted) {                        // uniform: the remaining pins are charged as unreachable, nothing is traced
+            if (tid == 0) { d_vio += s_remaining; status |= XR_ENV_ROUTER_ABORT | XR_ENV_UNREACHABLE; s_remaining = 0; s_target_i = -1; }
+        } else
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
         if (tid < 64) {
             // (distance, flat index) of the best target: one LDS 64-bit atomic min per candidate lane
@@ -909,7 +923,8 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     fnv_mix(h, (uint32_t)node);
                     if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
                 };
-                while ((vw >> 2) > 0) {
+                for (int nt = 0; (vw >> 2) > 0; nt++) {
+                    if (nt > N) { if (tid == 0) status |= 0x100; break; }    // (distances strictly decrease: a path is simple; hang guard)
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);   // pred distance + edge, x4
                     uint32_t len1 = 0, len2 = 0;
                     const int u1 = pred_of(v, x, y, z, d1, len1);
@@ -1080,6 +1095,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     const uint32_t ldir = R.ldir_mask;
     const int mw = (N + 31) >> 5;
     const int ng = (mw + 31) >> 5;
+    const int round_cap = b.round_cap > 0 ? b.round_cap : 1024 + N;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
     const int64_t mwg = (int64_t)(b.n_max >> 5) + 1;
@@ -1234,10 +1250,12 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         };
         auto heur = [&](int x, int y, int z) -> uint32_t { return heur_c((int)s_xc[x + 1], (int)s_yc[y + 1], z); };
         int cur = 0;
-        for (;;) {
+        bool aborted = false;                 // (round cap: see the LDS form)
+        for (int nsr = 0;; nsr++) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
             const uint32_t m = s_min[cur], best = s_bst[cur];
             if (m == XR_DIAL_INF || m > best) break;                 // uniform
+            if (nsr >= round_cap) { aborted = true; break; }         // uniform
             const uint32_t hi = m + delta;
             uint32_t lmin = XR_DIAL_INF;
             if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; s_nG = 0; }
@@ -1313,9 +1331,18 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 __syncthreads();
                 // ---- D: relax, one lane per (node, direction); run ahead inside the bucket -----------------------
                 int eb = 0;
-                for (;;) {
+                for (int npass = 0;; npass++) {
                     const int nE = min(s_nE[eb], XR_BIG_CE);
                     if (nE == 0) break;                                  // uniform
+                    if (npass >= round_cap) {            // hang guard (every pass lowers field words: finite anyway): what is left stays open
+                        uint2* El = eb ? s_E1 : s_E0;
+                        for (int it = tid; it < nE; it += nthr) { open_insert(El[it].x, m); }
+                        lmin = m < lmin ? m : lmin;
+                        __syncthreads();
+                        if (tid == 0) s_nE[eb] = 0;
+                        __syncthreads();
+                        break;
+                    }
                     uint2* Ecur = eb ? s_E1 : s_E0;
                     uint2* Enxt = eb ? s_E0 : s_E1;
                     for (int it = tid; it < 4 * nE; it += nthr) {
@@ -1390,6 +1417,9 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         }
         XR_LAP(2);
 
+        if (aborted) {                        // uniform: the remaining pins are charged as unreachable, nothing is traced
+            if (tid == 0) { d_vio += s_remaining; status |= XR_ENV_ROUTER_ABORT | XR_ENV_UNREACHABLE; s_remaining = 0; s_target_i = -1; s_plen = 0; }
+        } else
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
         if (tid < 64) {
             for (int i = tid; i < nap; i += 64) {
@@ -1450,7 +1480,8 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     fnv_mix(h, (uint32_t)node);
                     if (src >= 4) d_via += 1; else d_wl += (int)(pl4 >> 2);
                 };
-                while ((vw >> 2) > 0) {
+                for (int nt = 0; (vw >> 2) > 0; nt++) {
+                    if (nt > N) { if (tid == 0) status |= 0x100; break; }    // (hang guard: distances strictly decrease)
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);
                     uint32_t len1 = 0, len2 = 0;
                     const int u1 = pred_of(v, x, y, z, d1, len1);

@@ -532,11 +532,13 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
     uint32_t* nxt = s_dirty1;       // dirty lines reported during this iteration
     int parity = 0;
 
+    const int round_cap = b.round_cap > 0 ? b.round_cap : 1024 + N;     // hang guard, see xr_dial.h
     while (s_remaining > 0) {
         // new search: the bound was reset, so lines that refused candidates must be looked at again
         for (int i = tid; i < nlw; i += nthr) { const uint32_t m = s_defer[i]; if (m) { atomicOr(&cur[i], m); s_defer[i] = 0; } }
         // ---- relax to the (pruned) fixpoint ----------------------------------------------------
-        for (;;) {
+        bool aborted = false;
+        for (int nss = 0;; nss++) {
             // bound from the targets' current distances
             for (int i = tid; i < nap; i += nthr)
                 if (!s_ap_conn[i]) { const uint32_t w = field[s_ap_l[i]]; if (w < XR_W_UNREACHED) atomicMin(&s_bound, w >> 2); }
@@ -567,6 +569,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
                 __syncthreads();
                 nH = s_cnt[parity][0]; nV = s_cnt[parity][1]; nC = s_cnt[parity][2];
                 if (nH + nV + nC == 0) break;              // uniform: nothing left to visit
+                if (nss >= round_cap) { aborted = true; break; }      // uniform
                 if (tid == 0) { s_cnt[parity ^ 1][0] = 0; s_cnt[parity ^ 1][1] = 0; s_cnt[parity ^ 1][2] = 0; }
             }
             XR_LAP(1);
@@ -653,6 +656,9 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
             XR_LAP(2);
         }
 
+        if (aborted) {                        // uniform: the remaining pins are charged as unreachable, nothing is traced
+            if (tid == 0) { d_vio += s_remaining; status |= XR_ENV_ROUTER_ABORT | XR_ENV_UNREACHABLE; s_remaining = 0; s_target_i = -1; }
+        } else
         // ---- nearest access point of an unconnected pin; ties -> lowest flat index (wave 0) --------
         if (tid < 64) {
             if (LDS_DIST) for (int i = tid; i < claim_words; i += 64) s_claim[i] = 0;   // aliases the (dead) worklists
@@ -697,7 +703,8 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
                 // fake a predecessor match on the node after it).
                 int v = s_ap_l[best_i];
                 uint32_t vw = field[v];
-                while ((vw >> 2) > 0) {
+                for (int nt = 0; (vw >> 2) > 0; nt++) {
+                    if (nt > N) { if (tid == 0) status |= 0x100; break; }      // (hang guard: distances strictly decrease)
                     int x, y, z;
                     lay.decode(v, x, y, z);
                     const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u);   // pred distance + edge, x4
@@ -1384,39 +1391,20 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
     const int e = (int)(ent >> 14), rank = (int)(ent & 0x3FFFu);
     const XrRegionDev R = b.regions[b.plan_region[e]];
     const int N = R.N, Z = R.Z, Y = R.Y, X = R.X, YZ = Y * Z;
-    const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
     const int nwords = (N + 15) >> 4;
-    for (int w = tid; w <= nwords; w += 256) {                 // one spare word: the funnel shift reads w + 1
-        const int f0 = w << 4;
-        // 16 nodes = two 16-byte loads (node_off is a multiple of 8 elements), issued before any compare
-        int pk[8];
-        if (f0 + 16 <= N) {
-            const int4 v0 = *reinterpret_cast<const int4*>(nn + f0), v1 = *reinterpret_cast<const int4*>(nn + f0 + 8);
-            pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int fa = f0 + 2 * i, fb = fa + 1;
-                const int lo = fa < N ? (int)(unsigned short)nn[fa] : 0, hi = fb < N ? (int)(unsigned short)nn[fb] : 0;
-                pk[i] = lo | (hi << 16);
-            }
-        }
-        uint32_t hit = 0;                                      // bit i: node f0 + i is an access point of the net
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int v = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xFFFF);
-            hit |= (v == id && f0 + i < N) ? (1u << i) : 0u;
-        }
-        uint32_t m = 0;
-        while (hit) {                                          // rare: ~1 % of the nodes
-            const int i = __ffs((int)hit) - 1; hit &= hit - 1;
-            const int f = f0 + i;
-            const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
-            const bool adj = (x + 1 < X && nn[f + YZ] == id) || (y > 0 && nn[f - Z] == id) || (x > 0 && nn[f - YZ] == id) ||
-                             (y + 1 < Y && nn[f + Z] == id) || (z + 1 < Z && nn[f + 1] == id) || (z > 0 && nn[f - 1] == id);
-            m |= (adj ? 3u : 1u) << (2 * i);
-        }
-        s_m[w] = m;
+    (void)X; (void)Y; (void)Z; (void)YZ;
+    // The two masks are zero except at the net's access points (a handful of nodes): they come from the net's access-point list
+    // (ap_feat: node | has-same-net-axis-neighbour << 31, decided once at load), exactly as xr_unit_aligned takes them — not
+    // from a scan of the region's node array (17 KB and 16 compares per word, per unit: what kept this writer at ~0.5 of peak)
+    const int ap_lo = b.net_csr[R.net_off + id], ap_hi = b.net_csr[R.net_off + id + 1];
+    int my_ap = 0;
+    const bool has_ap = ap_lo + tid < ap_hi;                   // (<= XR_MAX_AP_PER_NET = 128 access points: one per thread)
+    if (has_ap) my_ap = b.ap_feat[R.ap_off + ap_lo + tid];      // issued before the zero fill
+    for (int w = tid; w <= nwords; w += 256) s_m[w] = 0u;      // one spare word: the funnel shift reads w + 1
+    __syncthreads();
+    if (has_ap) {
+        const int f = my_ap & 0x7FFFFFFF;
+        atomicOr(&s_m[f >> 4], (my_ap < 0 ? 3u : 1u) << ((f & 15) << 1));
     }
     __syncthreads();
     float* __restrict__ row = b.obs_out + (int64_t)e * b.obs_stride;          // 16-byte aligned

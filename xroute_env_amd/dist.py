@@ -160,6 +160,7 @@ class ShardedVectorEnv:
         self.equal = n_total % self.world == 0
         self._all = torch.empty((n_total, RECORD_BYTES), dtype=torch.uint8, device=self.device) if self.equal else None
         self._actions_all = torch.zeros(n_total, dtype=torch.int32, device=self.device)
+        self._legal_all = None          # [n_total, legal_words] int64, allocated at the first exchange (equal shards: one collective, no host wait)
 
     def reset(self):
         return self.env.reset()
@@ -192,7 +193,9 @@ class ShardedVectorEnv:
 
     def _exchange(self, info: dict, policy: Callable) -> torch.Tensor:
         rec_all = self._gather(info["record"], self._all)
-        legal_all = self._gather(info["legal"])
+        if self.equal and self.world > 1 and (self._legal_all is None or self._legal_all.shape[1] != info["legal"].shape[1]):
+            self._legal_all = torch.empty((self.n_total, info["legal"].shape[1]), dtype=info["legal"].dtype, device=self.device)
+        legal_all = self._gather(info["legal"], self._legal_all)
         self._records_all = rec_all
         if self.rank == 0:
             self._actions_all.copy_(policy(unpack_records(rec_all), legal_all).to(torch.int32))

@@ -198,5 +198,6 @@ def serve_zmq(server: SimulatorServer, port_recv="5556", port_initial="6667", ho
                     sim.close(linger=0)
                     sim = None
                 ctl.send(server.on_control(ctl.recv()))
-            else:
+                break                                     # the rest of this poll batch may name the socket just closed
+            elif sock is sim:
                 server.on_reply(sim.recv())
