@@ -137,3 +137,44 @@ print("tinylists ok", real)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, XR_LIB="libxroute_hip_tinylists.so"))
     assert out.returncode == 0 and "tinylists ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_lds_frontier_router_list_overflow_paths():
+    """The same tiny-list build for the LDS form (xr_dial3.h: queue of 8 nodes, hot list of 16, node list of 64): a bucket that
+    does not fit the queue stays in the hot list, a hot list that is full sends nodes to the cold mask, a cold mask with more
+    nodes than the node list holds is classified in several passes, a path longer than the node list is flushed in chunks —
+    on every route.  Capacity must never change a result: full episodes of ispd18_test1-sized regions against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import xr_oracle as orc
+from xroute_env_amd.batch import RegionBatch
+from xroute_env_amd.regions import generate_region
+regs = [generate_region(7900 + i) for i in range(16)] + [generate_region(7950 + i, dims=(9, 7, 4), k_range=(2, 5), net_span=5) for i in range(8)]
+for kw in (dict(), dict(guide_cost=700, guide_margin=1, maze_end_iter=3)):
+    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, **kw)
+    batch.reset()
+    ob = orc.OracleBatch(regs, **kw)
+    acts = torch.empty(len(regs), dtype=torch.int32, device="cuda:0")
+    real = 0
+    for it in range(40):
+        batch.random_actions(60 + it, acts)
+        ref = ob.step(acts.cpu().numpy(), threads=ob.max_threads(), auto_reset=True)
+        batch.step(acts)
+        rec = batch.records()
+        assert np.array_equal(rec["delta"], ref["delta"]) and np.array_equal(rec["done"], ref["done"]), (kw, it)
+        real += ref["real_steps"]
+    h = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    assert [int(v) for v in h] == [e.hash() for e in ob.envs]
+    owner = batch.fetch("owner").cpu().numpy()
+    for e, env in enumerate(ob.envs):
+        assert np.array_equal(owner[e, :env.n], env.owner())
+print("tinylists lds ok", real)
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, XR_LIB="libxroute_hip_tinylists.so"))
+    assert out.returncode == 0 and "tinylists lds ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

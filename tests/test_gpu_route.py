@@ -57,7 +57,7 @@ def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
     return total
 
 
-@pytest.mark.parametrize("router", [0, 1])          # 0: default (bucketed frontier), 1: line-segment sweeps
+@pytest.mark.parametrize("router", [0, 1, 3])       # 0: default (frontier router, round 3's LDS form), 1: line-segment sweeps, 3: round 2's LDS form
 def test_route_parity_ispd_sized(router):
     regions = [generate_region(3000 + i) for i in range(24)]
     n = _run_episode_parity(regions, policy="random", router=router)
@@ -73,7 +73,7 @@ def test_route_parity_frontier_bucket_widths(mult):
 
 @pytest.mark.parametrize("dims", [(1, 1, 1), (1, 7, 1), (5, 1, 2), (2, 2, 2), (3, 4, 5), (6, 5, 3), (16, 9, 4),
                                   (7, 31, 9), (33, 8, 2), (12, 12, 12)])
-@pytest.mark.parametrize("router", [0, 1])
+@pytest.mark.parametrize("router", [0, 1, 3])
 def test_route_parity_odd_dims(dims, router):
     n = dims[0] * dims[1] * dims[2]
     regions = [generate_region(4000 + 17 * i + n, dims=dims, k_range=(1, 6), net_span=4) for i in range(6)]
@@ -359,8 +359,8 @@ def test_longest_first_order_on_a_multi_round_batch():
     assert twins[1].fetch("route_order").abs().sum().item() == 0
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(force_scratch_field=True), dict(router=1)],
-                         ids=["frontier-lds", "frontier-hbm-scratch", "sweeps"])
+@pytest.mark.parametrize("kw", [dict(), dict(force_scratch_field=True), dict(router=1), dict(router=3)],
+                         ids=["frontier-lds", "frontier-hbm-scratch", "sweeps", "frontier-lds-round2"])
 def test_round_cap_aborts_the_net_not_the_device(kw):
     """No router loop is unbounded: a search that exceeds its round cap (default 1024 + N, forced to 1 here) gives up on the
     net — XR_ENV_ROUTER_ABORT, remaining pins charged as unreachable — and the env stays consistent: the episode goes on,

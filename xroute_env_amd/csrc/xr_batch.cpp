@@ -102,7 +102,8 @@ struct xr_batch {
     DevBuf<XrRegionDev> regions;
     DevBuf<uint32_t> rg_rec;
     DevBuf<int16_t> rg_node_net, rg_owner0;
-    DevBuf<int32_t> coords, net_csr, ap_node, ap_feat;
+    DevBuf<int32_t> coords, net_csr, ap_node, ap_feat, net_info;
+    DevBuf<uint8_t> ap_flags;
     DevBuf<int16_t> ap_pin;
     DevBuf<uint64_t> legal0;
     // envs
@@ -206,8 +207,8 @@ int32_t xr_batch_create(const xr_config* cfg, xr_batch** out) {
     if (cfg->launch_order < 0 || cfg->launch_order > 2) return fail(XR_ERR_INVALID, "xr_batch_create: launch_order must be 0, 1 or 2");
     if (cfg->obs_mode < 0 || cfg->obs_mode > XR_OBS_QUEUE || cfg->obs_writer_blocks < 0 || cfg->obs_split_permille < 0 || cfg->obs_split_permille > 1000)
         return fail(XR_ERR_INVALID, "xr_batch_create: obs_mode must be 0, XR_OBS_FUSED, XR_OBS_SPLIT or XR_OBS_QUEUE; obs_writer_blocks >= 0; obs_split_permille in 0..1000");
-    if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL || cfg->dial_mult < 0 || cfg->dial_mult > 64)
-        return fail(XR_ERR_INVALID, "xr_batch_create: router must be 0, XR_ROUTER_SWEEP or XR_ROUTER_DIAL; dial_mult in 0..64");
+    if (cfg->router < 0 || cfg->router > XR_ROUTER_DIAL_R2 || cfg->dial_mult < 0 || cfg->dial_mult > 64)
+        return fail(XR_ERR_INVALID, "xr_batch_create: router must be 0, XR_ROUTER_SWEEP, XR_ROUTER_DIAL or XR_ROUTER_DIAL_R2; dial_mult in 0..64");
     if (cfg->guide_cost < 0 || cfg->guide_cost >= (1 << 22) || cfg->guide_margin < 0 || cfg->maze_end_iter < 1 || cfg->maze_end_iter > 8 ||
         ((int64_t)cfg->drc_cost * cfg->drc_unit << (cfg->maze_end_iter - 1)) >= (1 << 22))
         return fail(XR_ERR_RANGE, "xr_batch_create: guide_cost in [0, 2^22), guide_margin >= 0, maze_end_iter in 1..8 with drc_cost*drc_unit << (maze_end_iter-1) < 2^22");
@@ -254,6 +255,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<int32_t> hcoords, hcsr, hap_node, hap_feat;
     std::vector<int16_t> hap_pin;
     std::vector<float> hwork;            // per (region, net): predicted route work (launch order of route-only launches)
+    std::vector<int32_t> hinfo;          // per (region, net): static facts for xr_dial3.h (XrBatchDev::net_info)
+    std::vector<uint8_t> hap_flags;      // per access point: bit 0 = its pin sits in a closed pocket
+    int64_t edge_max = b->cfg.via_cost;  // longest edge of any region graph (distance range check of xr_dial3.h)
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
@@ -348,6 +352,57 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                 const bool adj = (x + 1 < d.dim_x && net_of(f + YZd) == n) || (y > 0 && net_of(f - Zd) == n) || (x > 0 && net_of(f - YZd) == n) ||
                                  (y + 1 < Yd && net_of(f + Zd) == n) || (z + 1 < Zd && net_of(f + 1) == n) || (z > 0 && net_of(f - 1) == n);
                 hap_feat[i] = f | (adj ? (int32_t)0x80000000 : 0);
+            }
+        }
+        // Static facts of every net for the round-3 router: lowest pin, number of distinct pins, and which pins are ISOLATED — all
+        // access points of the pin sit in a pocket closed by BLOCKAGE nodes that holds no access point of another pin of the net.
+        // Such a pin can never be reached (nor reach anything): XR-Maze v1 charges one violation for it, and a router that has to
+        // find that out by searching explores the whole component first.  The pocket's boundary is static, so the flood (budget 64
+        // nodes; a larger pocket just counts as open, the result is the same) runs here, once, not in every route.
+        hinfo.resize(hcsr.size(), 0);
+        hap_flags.resize(hap_node.size(), 0);
+        {
+            const int Xd = d.dim_x, Yd = d.dim_y, Zd = d.dim_z, YZd = Yd * Zd;
+            for (int i = 1; i < Xd; i++) edge_max = std::max<int64_t>(edge_max, d.xs_host[i] - d.xs_host[i - 1]);
+            for (int i = 1; i < Yd; i++) edge_max = std::max<int64_t>(edge_max, d.ys_host[i] - d.ys_host[i - 1]);
+            auto blocked = [&](int f) { return XR_REC_TYPE(d.nodes_host[f]) == XR_TYPE_BLOCKAGE; };
+            std::vector<int> seen_pins, pocket;
+            for (int n = 1; n <= d.n_nets; n++) {
+                const int lo = cnt[n], hi = cnt[n + 1];
+                if (hi <= lo) continue;
+                seen_pins.clear();
+                for (int i = lo; i < hi; i++) {
+                    const int pn = hap_pin[base + i];
+                    if (std::find(seen_pins.begin(), seen_pins.end(), pn) == seen_pins.end()) seen_pins.push_back(pn);
+                }
+                const int first = *std::min_element(seen_pins.begin(), seen_pins.end());
+                int n_iso = 0, src_iso = 0;
+                for (int pn : seen_pins) {
+                    pocket.clear();
+                    for (int i = lo; i < hi; i++) if (hap_pin[base + i] == pn) pocket.push_back(hap_node[base + i]);
+                    bool open_pocket = false;
+                    for (size_t k = 0; k < pocket.size() && !open_pocket; k++) {
+                        const int f = pocket[k], z = f % Zd, y = (f / Zd) % Yd, x = f / YZd;
+                        const bool vert = d.layer_dir_host[z] != 0;
+                        const int nb[4] = {vert ? (y + 1 < Yd ? f + Zd : -1) : (x + 1 < Xd ? f + YZd : -1),
+                                           vert ? (y > 0 ? f - Zd : -1) : (x > 0 ? f - YZd : -1),
+                                           z + 1 < Zd ? f + 1 : -1, z > 0 ? f - 1 : -1};
+                        for (int q = 0; q < 4; q++) {
+                            if (nb[q] < 0 || blocked(nb[q])) continue;
+                            if (std::find(pocket.begin(), pocket.end(), nb[q]) != pocket.end()) continue;
+                            if (pocket.size() >= 64) { open_pocket = true; break; }
+                            pocket.push_back(nb[q]);
+                        }
+                    }
+                    if (open_pocket) continue;
+                    bool other = false;                    // an access point of another pin of the net inside the pocket: reachable
+                    for (int i = lo; i < hi && !other; i++)
+                        if (hap_pin[base + i] != pn && std::find(pocket.begin(), pocket.end(), hap_node[base + i]) != pocket.end()) other = true;
+                    if (other) continue;
+                    for (int i = lo; i < hi; i++) if (hap_pin[base + i] == pn) hap_flags[base + i] = 1;
+                    if (pn == first) src_iso = 1; else n_iso++;
+                }
+                hinfo[R.net_off + n] = (first & 0x3FFF) | ((int)seen_pins.size() << 14) | (n_iso << 22) | (src_iso << 30);
             }
         }
         // predicted work of routing net n: extent of its access points (DBU; a layer of span counted as half a via) times
@@ -469,12 +524,25 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             b->route_lds = big_lds;
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 512;       // (256: 4.2-4.7 ms, 512: 3.7-3.9 ms, config 5)
         }
+        // round 3's LDS form (xr_dial3.h) where it applies: the field fits with its queues, node ids fit 16 bits, and no distance
+        // can exceed the 27 bits its field word holds — (N + 1) x (longest edge + largest penalty) bounds every simple path
+        {
+            const size_t d3_lds = XR3_LDS_BYTES(b->n_max, x_max, y_max);
+            const int64_t pen_max = ((int64_t)b->cfg.drc_cost * b->cfg.drc_unit) << (b->cfg.maze_end_iter - 1);
+            const bool range_ok = ((int64_t)b->n_max + 1) * (edge_max + pen_max + b->cfg.guide_cost) < XR3_DIST_LIMIT;
+            if (b->kzch == -1 && b->lds_dist && b->cfg.router != XR_ROUTER_DIAL_R2 && range_ok && b->n_max < 65536 &&
+                d3_lds + kLdsStatic <= kLdsLimit) {
+                b->kzch = -3;
+                b->route_lds = d3_lds;
+            }
+        }
         const bool v2 = b->cfg.guide_cost > 0 || b->cfg.maze_end_iter > 1;
+        if (v2 && b->kzch == -3) b->kzch = -4;
         if (v2 && b->kzch == -1) b->kzch = -2;          // the instantiations with the XR-Maze v2 knobs compiled in (LDS and HBM-scratch form)
-        if (v2 && b->kzch != -2)
+        if (v2 && b->kzch != -2 && b->kzch != -4)
             return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR-Maze v2 (guide_cost / maze_end_iter) needs the frontier router "
                                       "(router != XR_ROUTER_SWEEP, regions within its limits)");
-        if (b->kzch >= 0 && b->cfg.router == XR_ROUTER_DIAL) {
+        if (b->kzch >= 0 && (b->cfg.router == XR_ROUTER_DIAL || b->cfg.router == XR_ROUTER_DIAL_R2)) {
             return fail(XR_ERR_RANGE, "xr_batch_load_regions: XR_ROUTER_DIAL: the largest region (%d nodes) exceeds the frontier router's limits", b->n_max);
         }
     }
@@ -488,7 +556,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     // FULL-rewrite queue launch of a very large batch, where the line-segment sweeps are ahead (same box, DESIGN.md §5.1:
     // 1.727-1.730 ms against 1.773-1.775 ms per 4096-env step; at 2048 envs the frontier router wins, 0.921 against 0.945-0.954 ms)
     b->sweep_lds = std::max(lds_need, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
-    b->sweep_full = b->cfg.router == 0 && b->kzch == -1 && b->lds_dist && sweep_lds_ok && b->cfg.block_threads == 0 &&
+    b->sweep_full = b->cfg.router == 0 && (b->kzch == -1 || b->kzch == -3) && b->lds_dist && sweep_lds_ok && b->cfg.block_threads == 0 &&
                     b->cfg.n_envs >= 4096 && b->sweep_lds + kLdsStatic <= kLdsLimit;
     if (b->route_lds + kLdsStatic > kLdsLimit)
         return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
@@ -525,6 +593,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->touched, B);
     XR_ALLOC(b->route_order, B);
     XR_ALLOC(b->net_work, hcsr.size());
+    XR_ALLOC(b->net_info, hcsr.size());
+    XR_ALLOC(b->ap_flags, std::max<size_t>(1, hap_flags.size()));
     XR_ALLOC(b->owner, (size_t)B * b->n_max);
     XR_ALLOC(b->legal, (size_t)B * legal_words);
     XR_ALLOC(b->hash, B);
@@ -563,6 +633,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             if (hwork[i] > 0.0f) hclass[i] = (uint8_t)(1 + std::min(254, (int)(254.0f * hwork[i] / wmax)));
     }
     XR_HIP(hipMemcpyAsync(b->net_work.p, hclass.data(), hclass.size(), hipMemcpyHostToDevice, st));
+    hinfo.resize(hcsr.size(), 0);
+    XR_HIP(hipMemcpyAsync(b->net_info.p, hinfo.data(), hinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!hap_flags.empty()) XR_HIP(hipMemcpyAsync(b->ap_flags.p, hap_flags.data(), hap_flags.size(), hipMemcpyHostToDevice, st));
     if (!hap_node.empty()) {
         XR_HIP(hipMemcpyAsync(b->ap_node.p, hap_node.data(), hap_node.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         XR_HIP(hipMemcpyAsync(b->ap_pin.p, hap_pin.data(), hap_pin.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
@@ -598,7 +671,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     XrBatchDev& d = b->dev;
     d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
-    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p; d.net_work = b->net_work.p;
+    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p; d.net_work = b->net_work.p; d.net_info = b->net_info.p; d.ap_flags = b->ap_flags.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
     d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.lw_max = (int)lw_max; d.lines_max = lines_max; d.x_max = x_max; d.y_max = y_max; d.legal_words = legal_words; d.path_cap = b->path_cap;
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;
@@ -651,7 +724,9 @@ int32_t xr_batch_sizes(const xr_batch* b, int32_t* n_envs, int32_t* n_regions, i
     if (k_max) *k_max = b->k_max;
     if (legal_words) *legal_words = b->legal_words;
     if (path_cap) *path_cap = b->path_cap;
-    if (obs_env_stride) *obs_env_stride = ((int64_t)(2 + 7 * (int64_t)b->k_max) * (int64_t)b->n_max + 3) & ~(int64_t)3;
+    // (a multiple of 32 floats: every env's row starts on a 128-byte line, which is what lets the writers of unaligned planes
+    //  store whole lines — any stride >= (2+7*k_max)*n_max is accepted, this is the one to prefer)
+    if (obs_env_stride) *obs_env_stride = ((int64_t)(2 + 7 * (int64_t)b->k_max) * (int64_t)b->n_max + 31) & ~(int64_t)31;
     return XR_OK;
 }
 

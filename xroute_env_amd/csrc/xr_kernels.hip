@@ -825,14 +825,23 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
 }
 
 #include "xr_dial.h"
+#include "xr_dial3.h"
 
 // router selection of the step kernels: ZCH == XR_ZCH_DIAL -> the bucketed-frontier router (xr_dial.h, the default),
 // else the line-segment sweeps above (xr_config.router = XR_ROUTER_SWEEP)
 #define XR_ZCH_DIAL (-1)
 #define XR_ZCH_DIAL2 (-2)      // the frontier router (either form) with the XR-Maze v2 knobs compiled in
+#define XR_ZCH_DIAL3 (-3)      // round 3's LDS form (xr_dial3.h: one searching wave, explicit queues, predecessor directions in the field)
+#define XR_ZCH_DIAL3V2 (-4)    // ... with the XR-Maze v2 knobs
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int e, const int a, char* smem) {
-    if constexpr (ZCH == XR_ZCH_DIAL2) {
+    if constexpr (ZCH == XR_ZCH_DIAL3V2) {
+        static_assert(LDS_DIST, "xr_dial3.h is an LDS form");
+        xr_dial3_route_env<true>(b, e, a, smem);
+    } else if constexpr (ZCH == XR_ZCH_DIAL3) {
+        static_assert(LDS_DIST, "xr_dial3.h is an LDS form");
+        xr_dial3_route_env<false>(b, e, a, smem);
+    } else if constexpr (ZCH == XR_ZCH_DIAL2) {
         if constexpr (LDS_DIST) xr_dial_route_env<true>(b, e, a, smem);
         else xr_dial_route_env_big<true>(b, e, a, smem);
     } else if constexpr (ZCH == XR_ZCH_DIAL) {
@@ -1184,7 +1193,7 @@ __global__ void __launch_bounds__(1024) xr_route_order_kernel(XrBatchDev b, cons
 // observation stream of some workgroups overlap the latency-bound routing of others on the same CU.
 // ------------------------------------------------------------------------------------------------
 template <bool LDS_DIST, int ZCH>
-__global__ void xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
+__global__ void __launch_bounds__(1024, 4) xr_route_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {     // (register budget of 4 waves per SIMD: its own 4 workgroups per CU; without it the compiler aims higher and spills to scratch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef XR_TIMELINE
     // `make timeline`: absolute 100 MHz timestamps of this workgroup (start, routed, written) + where it ran
@@ -1407,54 +1416,55 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
         atomicOr(&s_m[f >> 4], (my_ap < 0 ? 3u : 1u) << ((f & 15) << 1));
     }
     __syncthreads();
-    float* __restrict__ row = b.obs_out + (int64_t)e * b.obs_stride;          // 16-byte aligned
-    const long long a = (long long)(2 + 7 * rank) * N;                       // first float of the unit
-    auto bits8 = [&](int f) {                 // masks of nodes f .. f+3 (2 bits each) in the low byte
-        const int bit = f << 1, w = bit >> 5, sh = bit & 31;
-        return __funnelshift_r(s_m[w], s_m[w + 1], sh);
+    // The unit's 7 planes are ONE contiguous run of 7*N floats at float (2 + 7*rank)*N of the env's row — plane boundaries only
+    // matter for the VALUE of a float (plane = offset / N, node = offset % N), not for where it is written.  So the run is written
+    // exactly like an aligned unit: cut at 128-byte-aligned multiples of 4 KB into 7 pieces, slot t of every piece in rotation,
+    // every wave store 8 whole 128-byte lines.  (tools/micro/write_unaligned.hip, N = 7650: 16-byte-aligned slots that start
+    // anywhere in a line reach 4.3-4.6 TB/s, the same bytes as whole lines 5.6-5.7 TB/s — as fast as aligned planes.)
+    float* __restrict__ run = b.obs_out + (int64_t)e * b.obs_stride + (int64_t)(2 + 7 * rank) * N;
+    const int total = 7 * N;
+    const int head = (int)((32u - (uint32_t)((reinterpret_cast<uintptr_t>(run) >> 2) & 31u)) & 31u);     // floats before the first 128-byte line
+    const int nslot = total > head ? (total - head) >> 2 : 0;                 // aligned float4 slots of the run
+    const int piece = ((nslot + 7 * 256 - 1) / (7 * 256)) * 256;              // slots per piece: a multiple of 256 (4 KB)
+    auto one = [&](int o) -> float {          // value of the float at run offset o
+        int pl = 0, f = o;
+        while (f >= N) { f -= N; pl++; }
+        return ((s_m[f >> 4] >> (((f & 15) << 1) + (pl ? 1 : 0))) & 1u) ? 1.f : 0.f;
     };
-#ifndef XR_STREAM_ROTATE
-#define XR_STREAM_ROTATE 1
-#endif
-#if XR_STREAM_ROTATE
-    // aligned float4 slots: 4 KB of each of the 7 planes in rotation (slot t of plane pl = nodes r_pl + 4t ..)
-    for (int t = tid; t < (N >> 2) + 1; t += 256) {
+    // (plane, node) of this thread's slot in each piece, advanced by 1024 floats per step
+    int ppl[7], pnd[7];
 #pragma unroll
-        for (int pl = 0; pl < 7; pl++) {
-            const long long p0 = a + (long long)pl * N;
-            const long long s0 = (p0 + 3) >> 2;
-            const int r = (int)((s0 << 2) - p0);
-            if (t < ((N - r) >> 2)) {
-                const uint32_t m = bits8(r + (t << 2)) >> (pl ? 1 : 0);
+    for (int p = 0; p < 7; p++) {
+        int o = head + ((p * piece + tid) << 2), pl = 0;
+        while (o >= N && pl < 7) { o -= N; pl++; }
+        ppl[p] = pl; pnd[p] = o;
+    }
+    for (int it = 0; it < piece; it += 256) {
+#pragma unroll
+        for (int p = 0; p < 7; p++) {
+            const int sl = p * piece + it + tid;
+            if (sl < nslot) {
+                const int f = pnd[p], pl = ppl[p];
                 float4 v;
-                v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
-                XR_ST4(row + ((s0 + t) << 2), v);
+                if (f + 3 < N) {                                  // four nodes of one plane: two mask words, one funnel shift
+                    const int bit = f << 1, w = bit >> 5;
+                    const uint32_t m = __funnelshift_r(s_m[w], s_m[w + 1], bit & 31) >> (pl ? 1 : 0);
+                    v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
+                } else {                                          // the slot straddles two planes: float by float
+                    const int o = head + (sl << 2);
+                    v.x = one(o); v.y = one(o + 1); v.z = one(o + 2); v.w = one(o + 3);
+                }
+                XR_ST4(run + head + (sl << 2), v);
             }
+            int nf = pnd[p] + 1024;
+            while (nf >= N) { nf -= N; ppl[p]++; }                // (N < 1024: several planes per step)
+            pnd[p] = nf;
         }
     }
-#endif
-    for (int pl = 0; pl < 7; pl++) {
-        const long long p0 = a + (long long)pl * N, p1 = p0 + N;               // this plane's float range
-        const long long s0 = (p0 + 3) >> 2, s1 = p1 >> 2;                      // aligned slots fully inside it
-        const int sel = pl ? 1 : 0;
-#if !XR_STREAM_ROTATE
-        for (long long sl = s0 + tid; sl < s1; sl += 256) {
-            const uint32_t m = bits8((int)((sl << 2) - p0)) >> sel;
-            float4 v;
-            v.x = (m & 1u) ? 1.f : 0.f; v.y = (m & 4u) ? 1.f : 0.f; v.z = (m & 16u) ? 1.f : 0.f; v.w = (m & 64u) ? 1.f : 0.f;
-            XR_ST4(row + (sl << 2), v);
-        }
-#endif
-        // ragged ends of the plane: at most 3 floats each (the whole plane when it holds no aligned slot)
-        auto one = [&](long long g) { const int f = (int)(g - p0); return ((s_m[f >> 4] >> (((f & 15) << 1) + sel)) & 1u) ? 1.f : 0.f; };
-        if (s0 < s1) {
-            const int nh = (int)((s0 << 2) - p0), nt = (int)(p1 - (s1 << 2));
-            if (tid < nh) row[p0 + tid] = one(p0 + tid);
-            else if (tid >= 64 && tid - 64 < nt) row[(s1 << 2) + (tid - 64)] = one((s1 << 2) + (tid - 64));
-        } else {
-            for (long long g = p0 + tid; g < p1; g += 256) row[g] = one(g);
-        }
-    }
+    // ragged ends of the run: < 32 floats before the first whole line, < 4 after the last slot
+    if (tid < head && tid < total) run[tid] = one(tid);
+    const int tail0 = head + (nslot << 2);
+    if (tid >= 64 && tail0 + (tid - 64) < total) run[tail0 + (tid - 64)] = one(tail0 + (tid - 64));
     __syncthreads();
 }
 
@@ -1698,6 +1708,16 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
         hipError_t e = hipFuncSetAttribute(d2fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
+    const void* d3fns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL3>),
+                            reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL3>),
+                            reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL3>),
+                            reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL3V2>),
+                            reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL3V2>),
+                            reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL3V2>)};
+    for (int i = 0; i < 6; i++) {
+        hipError_t e = hipFuncSetAttribute(d3fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
     const void* dfns[6] = {reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>),
                            reinterpret_cast<const void*>(&xr_step_queue_kernel<true, XR_ZCH_DIAL>),
                            reinterpret_cast<const void*>(&xr_order_kernel<true, XR_ZCH_DIAL>),
@@ -1732,7 +1752,11 @@ hipError_t xr_route_set_max_lds(size_t bytes) {
 hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
                            int threads, hipStream_t st) {
     const dim3 g(b->env_count > 0 ? b->env_count : b->n_envs), t(threads);
-    if (zch == XR_ZCH_DIAL2) {
+    if (zch == XR_ZCH_DIAL3V2) {
+        hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL3V2>), g, t, lds_bytes, st, *b, actions);
+    } else if (zch == XR_ZCH_DIAL3) {
+        hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL3>), g, t, lds_bytes, st, *b, actions);
+    } else if (zch == XR_ZCH_DIAL2) {
         if (lds_dist) hipLaunchKernelGGL((xr_route_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_route_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
     } else if (zch == XR_ZCH_DIAL) {
@@ -1753,7 +1777,11 @@ hipError_t xr_launch_route(const XrBatchDev* b, const int32_t* actions, int lds_
 hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int stride, int32_t* net_stats, int lds_dist, int zch,
                            size_t lds_bytes, int threads, hipStream_t st) {
     const dim3 g(b->n_envs), t(threads);
-    if (zch == XR_ZCH_DIAL2) {
+    if (zch == XR_ZCH_DIAL3V2) {
+        hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL3V2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+    } else if (zch == XR_ZCH_DIAL3) {
+        hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL3>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
+    } else if (zch == XR_ZCH_DIAL2) {
         if (lds_dist) hipLaunchKernelGGL((xr_order_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
         else hipLaunchKernelGGL((xr_order_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, orders, stride, net_stats);
     } else if (zch == XR_ZCH_DIAL) {
@@ -1773,7 +1801,9 @@ hipError_t xr_launch_order(const XrBatchDev* b, const int32_t* orders, int strid
 
 // resident workgroups per CU of the step kernel as the runtime would place it, and its static LDS
 hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threads, int* wg_per_cu, size_t* static_lds) {
-    const void* fn = zch == XR_ZCH_DIAL2 ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>)
+    const void* fn = zch == XR_ZCH_DIAL3V2 ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL3V2>)
+                     : zch == XR_ZCH_DIAL3 ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL3>)
+                     : zch == XR_ZCH_DIAL2 ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL2>)
                                                      : reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL2>))
                      : zch == XR_ZCH_DIAL ? (lds_dist ? reinterpret_cast<const void*>(&xr_route_kernel<true, XR_ZCH_DIAL>)
                                                     : reinterpret_cast<const void*>(&xr_route_kernel<false, XR_ZCH_DIAL>))
@@ -1793,7 +1823,11 @@ hipError_t xr_route_occupancy(int lds_dist, int zch, size_t lds_bytes, int threa
 hipError_t xr_launch_step_queue(const XrBatchDev* b, const int32_t* actions, int lds_dist, int zch, size_t lds_bytes,
                                 int threads, int blocks, hipStream_t st) {
     const dim3 g(blocks), t(threads);
-    if (zch == XR_ZCH_DIAL2) {
+    if (zch == XR_ZCH_DIAL3V2) {
+        hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL3V2>), g, t, lds_bytes, st, *b, actions);
+    } else if (zch == XR_ZCH_DIAL3) {
+        hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL3>), g, t, lds_bytes, st, *b, actions);
+    } else if (zch == XR_ZCH_DIAL2) {
         if (lds_dist) hipLaunchKernelGGL((xr_step_queue_kernel<true, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
         else hipLaunchKernelGGL((xr_step_queue_kernel<false, XR_ZCH_DIAL2>), g, t, lds_bytes, st, *b, actions);
     } else if (zch == XR_ZCH_DIAL) {
