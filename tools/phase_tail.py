@@ -30,7 +30,7 @@ for i in range(steps):
 rows.sort()
 tot = np.array([r[0] for r in rows])
 print(f"router {router}: {len(rows)} routes; total cycles mean {tot.mean():.0f} p50 {np.percentile(tot,50):.0f} p90 {np.percentile(tot,90):.0f} p99 {np.percentile(tot,99):.0f} max {tot.max()}")
-names = ["setup", "ph1", "ph2", "sel+trace", "ph4", "epilogue", "ph6"]
+names = ["setup", "ph1", "ph2", "sel+trace", "ph4", "epilogue", "ph6"] if not os.environ.get("XR_COUNT") else ["setup", "subrounds", "hop cycles", "queue entries", "hop iters (1 wave)", "active quad-hops (1 wave)", "ph6"]
 print("phase means:", {n: int(np.mean([r[2 + k] for r in rows])) for k, n in enumerate(names)}, "rounds mean", np.mean([r[1] for r in rows]))
 print("slowest routes (total, rounds, phases..., path_len, env, net):")
 for r in rows[-8:]:
