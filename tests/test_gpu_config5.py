@@ -140,10 +140,9 @@ print("tinylists ok", real)
 
 
 def test_lds_frontier_router_list_overflow_paths():
-    """The same tiny-list build for the LDS form (xr_dial3.h: queue of 8 nodes, hot list of 16, node list of 64): a bucket that
-    does not fit the queue stays in the hot list, a hot list that is full sends nodes to the cold mask, a cold mask with more
-    nodes than the node list holds is classified in several passes, a path longer than the node list is flushed in chunks —
-    on every route.  Capacity must never change a result: full episodes of ispd18_test1-sized regions against the oracle."""
+    """The same tiny-list build for the LDS form (xr_dial3.h: node list of 8): a path longer than the node list becomes sources /
+    gets claimed in chunks while the pointer chase is still running — on every route, XR-Maze v1 and v2.  Capacity must never
+    change a result: full episodes of ispd18_test1-sized regions against the oracle."""
     import os
     import subprocess
     import sys

@@ -19,19 +19,12 @@
 #endif
 #define XR_BIG_MAXG 1024       // groups (1024 nodes each): regions up to 1 M nodes
 #define XR_MAX_AP_PER_NET 128   // access points of one net staged in LDS by the route kernel
-// round 3's LDS form of the frontier router (xr_dial3.h): list capacities (never affect results) and its LDS footprint
-#ifndef XR3_CAPC
-#define XR3_CAPC 128          // one of the three rotating queues of the current bucket (u16 nodes)
-#endif
-#ifndef XR3_CAPL
-#define XR3_CAPL 256          // hot list (u32: node | bucket << 16)
-#endif
+// round 3's LDS form of the frontier router (xr_dial3.h): its node list (path chunks) and its LDS footprint
 #ifndef XR3_TMP
-#define XR3_TMP 512           // node list (u16): mask compaction, path chunks
+#define XR3_TMP 512           // node list (u16): path nodes of a back-trace, flushed in chunks
 #endif
-static_assert(XR3_TMP >= 64 && XR3_TMP % 32 == 0 && XR3_TMP / 32 <= 64, "the node list holds at least two mask words per step and at most one per lane");
-#define XR3_LDS_BYTES(n_max, x_max, y_max) ((size_t)(n_max) * 4 + 2 * ((size_t)(n_max) / 32 + 1) * 4 + (size_t)XR3_CAPL * 4 + \
-                                            ((size_t)(x_max) + (size_t)(y_max) + 4) * 4 + 3 * (size_t)XR3_CAPC * 2 + (size_t)XR3_TMP * 2 + 16)
+#define XR3_LDS_BYTES(n_max, x_max, y_max) ((size_t)(n_max) * 4 + 3 * ((size_t)(n_max) / 32 + 1) * 4 + \
+                                            ((size_t)(x_max) + (size_t)(y_max) + 4) * 4 + (size_t)XR3_TMP * 2 + 16)
 #define XR3_DIST_LIMIT ((1ll << 27) - 64)     // the form's field word holds 27 distance bits
 
 // One region (static after xr_batch_load_regions). Node arrays are in the reference observation's

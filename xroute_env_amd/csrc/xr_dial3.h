@@ -1,40 +1,30 @@
 // xr_dial3.h — XR-Maze v1/v2, LDS form of the frontier router, round 3.  Included by xr_kernels.hip only
-// (device code, gfx950 / wave64).  Same results as xr_dial.h / the oracle, bit for bit; a different machine underneath.
+// (device code, gfx950 / wave64).  Same results as xr_dial.h / the oracle, bit for bit.
 //
-// What round 2's router spent its time on (profiles/r02_m_route_phase_cycles.txt, 158 k cycles per route): a mask scan per
-// round (17 %), barrier skew between the four waves of a round (22 %), a two-hops-per-round-trip back-trace that re-derives
-// every predecessor (18 %), a pocket flood per route (part of 14 % set-up).  None of that is the search itself — ~200-350 node
-// expansions per route.  This form removes them:
+// Round 2's router spent 158-175 k cycles per route (profiles/r02_m_route_phase_cycles.txt): a pocket flood and an O(nap^2) pin
+// census per route (part of 23 k set-up), a two-hops-per-round-trip back-trace that re-derives every predecessor (39 k), and the
+// rounds themselves.  This form keeps round 2's rounds (one barrier per round, mask scan, quads of lanes following chains) — on
+// heavy routes nothing tried this round beat them, see DESIGN.md §5.3 — and removes the rest:
 //
-//  * ONE wave searches (16 quads, one lane per direction).  The sim (tools/sim/dial3_sim.py) says 16 quads need 41 lock-step
-//    hop iterations per route where 64 need 33: the frontier of an A* band is a few nodes wide.  With one wave there is no
-//    workgroup barrier inside a search, no cross-wave atomics, and every queue counter is a wave-uniform scalar.  The other waves
-//    build the field, then wait at the closing barrier (a parked wave costs nothing); which wave searches rotates with the env id so
-//    that the workgroups of a CU do not pile onto one SIMD.
-//  * Explicit queues instead of a mask scan per round.  Keys f = d + h live on a fixed grid of buckets of width 2^dshift:
-//    `cur` = nodes of the bucket being expanded, `later` = the HOT part of the frontier as (node, bucket) entries (bucket <
-//    current + XR3_HOTW), everything else (`cold`: leftovers of earlier searches, overflow, far keys) is a node bitmask with a
-//    lower bound of its keys — h only grows from one search of a net to the next, so an old lower bound stays one.  A round =
-//    min bucket of the hot list (one DPP reduction) + one partition pass; the cold mask is classified only when the frontier
-//    reaches its lower bound.  Capacities never affect the result: what does not fit goes cold.
 //  * The field word carries the predecessor direction:  dist << 5 | pdir << 2 | held << 1 | valid.  Lowering is a min() on the
 //    WORD, so among candidates of equal distance the lowest pdir (E,S,W,N,U,D = 0..5, the spec's back-trace order,
 //    reference baseline/build_3Dgrid.py:127) wins: when the search stops every node with d + h <= best holds its exact distance AND
 //    its first tight predecessor (every tight predecessor u of such a node has d(u) + h(u) <= best too, so it was expanded with
-//    its final distance and its candidate word took part in the min).  The back-trace is a pointer chase: one LDS read per node.
+//    its final distance and its candidate word took part in the min).  A node is re-opened only when its DISTANCE went down.
+//    The back-trace is a pointer chase: one LDS read per node, by one wave, while the others wait at the barrier.
 //    27 distance bits: the host only selects this form when (N + 1) * (longest edge + penalty) < 2^27 (else: xr_dial.h).
 //  * Isolated pins (closed pockets) and the per-net constants (first pin, number of pins) are static: decided at load
-//    (xr_batch_load_regions), one word per net — no flood, no O(nap^2) pin census per route.
+//    (xr_batch_load_regions), one word per net — no flood, no pin census per route.
+//  * Path nodes are listed while the chase runs and become sources / get claimed in parallel afterwards (no claim mask).
 //
-// Why the results cannot differ: any label-correcting order reaches the same pruned fixpoint (xr_dial.h's argument: for every edge
-// u->v, word(v) <= candidate(u, v) or u is queued / cold / deferred; the search stops when a lower bound of every pending key
-// exceeds `best`).  Duplicate queue entries and stale bucket tags only cost a wasted expansion.
+// Two other search organisations were built on this word format and measured this round (git history of this file): ONE searching
+// wave with explicit bucket queues and wave-uniform counters (mean route -30 %, but a route with a wide frontier — 60 rounds — took
+// 2.5 M cycles against 1.0 M: 16 quads and list thrash), and a workgroup-wide list form with shared LDS counters (every append /
+// pop is a returning LDS atomic inside the hop loop: slower on every route).  Both were bit-exact; neither beat mask rounds where
+// it matters: a launch is as long as its longest route.
 #pragma once
 
-// capacities XR3_CAPC / XR3_CAPL / XR3_TMP and XR3_LDS_BYTES: xr_device.h (the host sizes the launch from them)
-#ifndef XR3_HOTW
-#define XR3_HOTW 3            // buckets ahead of the current one that are kept as list entries
-#endif
+// XR3_TMP and XR3_LDS_BYTES: xr_device.h (the host sizes the launch from them)
 #define XR3_UNREACHED 0xFFFFFFFDu      // | held << 1   (dist bits all ones, pdir 7)
 #define XR3_DMAX 0x07FFFFFFu           // distance of an unreached word
 #define XR3_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -67,12 +57,10 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ unsigned short s_ap_f[XR_MAX_AP_PER_NET];
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];      // 0 target, 1 connected, 2 isolated (static, from the load)
-    __shared__ uint32_t s_cold_lb;                              // lower bound of the keys of the cold set (XR_DIAL_INF: empty)
-    __shared__ uint32_t s_best, s_bnew;                         // per round: smallest target distance, smallest hot bucket
+    __shared__ uint32_t s_min[3], s_bst[3];                     // rotating per round: smallest open key, smallest target distance
     __shared__ int s_hb[6];                                     // bounding box of the unconnected targets: x, y (coordinates x32), z
-    __shared__ int s_cnt;                                       // mask compaction: next free slot of s_tmp
-    __shared__ int s_nLc[2];                                    // entries of the hot list (current / being rebuilt)
-    __shared__ int s_nc[3], s_qh[3];                            // bucket queues: entries, next entry to hand out
+    __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
+    __shared__ unsigned short s_qn[XR_QUAD_POOL];
     __shared__ int s_remaining, s_abort;
     __shared__ int s_gb[4], s_retry;                            // XR-Maze v2: guide box of the net (track indices), rip-up decision
 
@@ -92,19 +80,20 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
 
-    // LDS carve:  field u32[n_max] | cold u32[mw_max] | defer u32[mw_max] | later u32[CAPL] | tab u32[x_max+2 + y_max+2] |
-    //             cur u16[3][CAPC] | tmp u16[TMP]
+    // LDS carve:  field u32[n_max] | open | defer | wmin (u32[mw_max] each) | tab u32[x_max+2 + y_max+2] | tmp u16[TMP]
+    //   open    bit f: node lowered but not expanded yet (transposed bit order, xr_dial.h: node f <-> word f % mw, bit f / mw)
+    //   defer   bit f: an edge out of f was refused only because of the search bound; re-opened when the next search starts
+    //   wmin[w] lower bound of the keys of the open nodes of word w (XR_DIAL_INF: none)
     uint32_t* field = reinterpret_cast<uint32_t*>(smem);
     const int mw_max = (b.n_max >> 5) + 1;
-    uint32_t* s_cold = field + b.n_max;
-    uint32_t* s_defer = s_cold + mw_max;          // also: "to be classified when the next search starts" (new sources)
-    uint32_t* s_later = s_defer + mw_max;
+    uint32_t* s_open = field + b.n_max;
+    uint32_t* s_defer = s_open + mw_max;
+    uint32_t* s_wmin = s_defer + mw_max;
     // coordinate tables (x32, relative to the first track): tab[k] = 32*(xs[clamp(k-1)] - xs[0]), k = 0 .. X+1 (the coordinate of
     // track x is tab[x+1]; padded at both ends); the y table follows at XO
-    uint32_t* s_tab = s_later + XR3_CAPL;
+    uint32_t* s_tab = s_wmin + mw_max;
     const int XO = b.x_max + 2;
-    unsigned short* s_cur = reinterpret_cast<unsigned short*>(s_tab + XO + b.y_max + 2);
-    unsigned short* s_tmp = s_cur + 3 * XR3_CAPC;
+    unsigned short* s_tmp = reinterpret_cast<unsigned short*>(s_tab + XO + b.y_max + 2);
 
     // loads that depend on (e, a) only: issued now, consumed after the grid build
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
@@ -153,7 +142,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                 dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
             }
         }
-        for (int i = tid; i < mw; i += nthr) { s_cold[i] = 0; s_defer[i] = 0; }
+        for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_wmin[i] = XR_DIAL_INF; }
     };
     build_field();
     if (tid <= X + 1) s_tab[tid] = my_xc;
@@ -162,7 +151,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         s_tab[i] = (uint32_t)(b.coords[R.xs_off + min(i - 1, X - 1)] - b.coords[R.xs_off]) << 5;
     for (int i = tid + nthr; i <= Y + 1; i += nthr)
         s_tab[XO + i] = (uint32_t)(b.coords[R.ys_off + min(i - 1, Y - 1)] - b.coords[R.ys_off]) << 5;
-    if (tid == 0) { s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1; s_cold_lb = XR_DIAL_INF; }
+    if (tid == 0) { s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1; }
     if (V2 && b.guide_cost) __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
@@ -191,13 +180,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
 
     const uint32_t via5 = (uint32_t)b.via_cost << 5;
     uint32_t pen5 = (uint32_t)b.pen_cost << 5;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
-    int dshift;                                             // bucket width 2^dshift ~ dial_mult x the smallest edge length
-    {
-        const uint32_t dl = max(R.w_min * (uint32_t)b.dial_mult, 1u);
-        dshift = 31 - __clz((int)dl);
-        if (dshift > 0 && ((dl >> (dshift - 1)) & 1u)) dshift += 1;          // (>= 1.5 x 2^k rounds up)
-        dshift = min(max(dshift, 11), 20);                   // bucket tags are 16 bits: key < 2^27
-    }
+    const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;  // bucket width (keys f = d + h, DBU)
     const uint32_t guide5 = V2 ? (uint32_t)b.guide_cost << 5 : 0u;
     const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
     auto guide_of = [&](int x, int y) __attribute__((always_inline)) -> uint32_t {
@@ -223,38 +206,38 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         xr_divmod(ur, uZ, R.magic_z, uy, uz);
         x = (int)ux; y = (int)uy; z = (int)uz;
     };
-    auto mask_or = [&](uint32_t* mask, uint32_t f) __attribute__((always_inline)) {
+    // a node becomes a source: distance 0, open
+    auto make_source = [&](uint32_t f) __attribute__((always_inline)) {
         uint32_t q, r;
         xr_divmod(f, umw, magic_mw, q, r);
-        atomicOr(&mask[r], 1u << q);
-    };
-    // append by the lanes with `pred` to a list whose length is the LDS counter `cnt`: one atomic per wave.  Returns the lane's
-    // slot (valid where pred); the counter may run past the capacity — readers clamp it.
-    auto block_append = [&](bool pred, int* cnt) __attribute__((always_inline)) -> int {
-        const unsigned long long m = __ballot(pred);
-        if (m == 0ULL) return 0;
-        const int first = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == first) base = atomicAdd(cnt, (int)__popcll(m));
-        base = __builtin_amdgcn_readlane(base, first);
-        return base + xr3_mbcnt(m);
+        field[f] &= 3u;
+        atomicOr(&s_open[r], 1u << q);
+        s_wmin[r] = 0u;                       // (racing plain stores of the same value)
     };
 
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
-    // sources of the first search: the access points of the lowest pin (classified when the search starts)
+    // component = all access points of the lowest pin id
     for (int i = tid; i < nap; i += nthr)
-        if (s_ap_conn[i] == 1) { field[s_ap_f[i]] &= 3u; mask_or(s_defer, (uint32_t)s_ap_f[i]); }
-    if (tid == 0) { s_remaining = npins - 1 - n_isolated; s_nLc[0] = 0; s_nLc[1] = 0; s_abort = 0; }
+        if (s_ap_conn[i] == 1) make_source((uint32_t)s_ap_f[i]);
+    if (tid == 0) { s_remaining = npins - 1 - n_isolated; s_abort = 0; }
     // the tracing wave's bookkeeping (uniform over that wave; meaningless in the others)
     int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0, nrounds = 0;
     uint64_t h = wv == sw ? b.hash[e] : 0ULL;
-    int par = 0;                                            // which of s_nLc counts the hot list
-    __syncthreads();
 
-    while (s_remaining > 0) {                               // uniform: written before the barrier that precedes every test
-        // ---- new search: heuristic box = bounding box of the access points of the unconnected (not isolated) pins -------------
-        if (tid == 0) { s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1; }
+    for (;;) {
+        // ---- new search: sources are open with distance 0; deferred nodes are looked at again ------------
+        if (tid == 0) {
+            s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
+            s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
+            s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1;
+        }
+        for (int i = tid; i < mw; i += nthr) {
+            const uint32_t m = s_defer[i];
+            if (m) { atomicOr(&s_open[i], m); s_defer[i] = 0; s_wmin[i] = 0u; }   // (0: a lower bound; the first scan fixes it)
+        }
         __syncthreads();
+        if (s_remaining <= 0) break;          // uniform: written before the barrier above
+        // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
         for (int i = tid; i < nap; i += nthr)
             if (!s_ap_conn[i]) {
                 int ax, ay, az;
@@ -272,262 +255,172 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             const int hz = max(0, max(hb4 - z, z - hb5));
             return ((uint32_t)(hx + hy) >> 5) + __umul24((uint32_t)hz, (uint32_t)b.via_cost);
         };
-        // a node with key `key` (bucket kb) joins the frontier: hot list entry while it is near and there is room, else cold
-        uint32_t hotlim = 0x10000u;                      // first bucket that is NOT kept as a list entry (search start: all are)
-        auto push_later = [&](bool valid, uint32_t f, uint32_t key, uint32_t kb) __attribute__((always_inline)) {
-            const bool hot = valid && kb < hotlim;
-            const int pos = block_append(hot, &s_nLc[par]);
-            const bool ok = hot && pos < XR3_CAPL;
-            if (ok) s_later[pos] = f | (kb << 16);
-            if (valid && !ok) { mask_or(s_cold, f); atomicMin(&s_cold_lb, key); }
-        };
-        // the set bits of a node mask -> classified into the hot list / the cold mask, by the whole workgroup.  Ends with a
-        // barrier; `mask` is empty afterwards except for what classification put back (cold scan: what stays cold).
-        auto scan_mask = [&](uint32_t* mask) __attribute__((always_inline)) {
-            auto classify = [&](bool act, uint32_t f) __attribute__((always_inline)) {
-                const uint32_t w = field[f];
-                int x, y, z;
-                node_xyz(f, x, y, z);
-                const uint32_t key = (w >> 5) + heur_c((int)s_tab[x + 1], (int)s_tab[XO + y + 1], z);
-                push_later(act, f, key, key >> dshift);
-            };
-            // compaction: a thread lists the nodes of its words (words tid, tid + nthr, ...) from a slot range it reserves with
-            // one atomic, and clears the words; then the list is classified one node per thread per step
-            if (tid == 0) s_cnt = 0;
-            __syncthreads();
-            int cnt = 0;
-            for (int wi = tid; wi < mw; wi += nthr) cnt += __popc(mask[wi]);
-            int pos = cnt ? atomicAdd(&s_cnt, cnt) : 0;
-            __syncthreads();
-            const int total = s_cnt;
-            if (total <= XR3_TMP) {
-                if (cnt)
-                    for (int wi = tid; wi < mw; wi += nthr) {
-                        uint32_t m = mask[wi];
-                        if (m) mask[wi] = 0u;
-                        while (m) {
-                            const int q = __ffs((int)m) - 1;
-                            m &= m - 1;
-                            s_tmp[pos++] = (unsigned short)(q * mw + wi);        // (transposed bit order: node = bit * mw + word)
+        XR_LAP(4);
+        int cur = 0;
+        bool aborted = false;                 // (round cap: xr_dial.h)
+        for (int nsr = 0;; nsr++) {
+            const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
+            const uint32_t m = s_min[cur], best = s_bst[cur];
+            if (m == XR_DIAL_INF || m > best) break;                 // uniform
+            if (nsr >= round_cap || s_abort) { aborted = true; break; }   // uniform (s_abort: written before the last barrier)
+            const uint32_t hi = m + delta;
+            uint32_t lmin = XR_DIAL_INF;
+            if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; }
+            // bound for the next round: smallest tentative distance of an unconnected target
+            // (by the threads at the END of the workgroup: the first wave carries the words beyond one per thread)
+            for (int i = nthr - 1 - tid; i < nap; i += nthr)
+                if (!s_ap_conn[i]) { const uint32_t d = field[s_ap_f[i]] >> 5; if (d != XR3_DMAX) atomicMin(&s_bst[nx1], d); }
+            // A lane scans word wi and — where the mask has more words than the workgroup has threads — word wi + nthr in the
+            // SAME pass (one 64-bit bit set).  The nodes of this bucket are then expanded by QUADS of lanes, one lane per direction.
+            for (int wbase = 0; wbase < mw; wbase += 2 * nthr) {          // (uniform trip count: the expansion is wave-cooperative)
+                const int wi = wbase + tid;
+                const int wi2 = wi + nthr;
+                unsigned long long expd = 0;
+                if (wi < mw) {
+                    const bool has2 = wi2 < mw;
+                    uint32_t wmA = s_wmin[wi], wmB = has2 ? s_wmin[wi2] : XR_DIAL_INF;
+                    const bool actA = wmA < hi, actB = wmB < hi;
+                    if (actA || actB) {
+                        // the word (probably) holds a node of this bucket: take it.  Order matters: reset the cached minimum,
+                        // THEN take the bits, THEN read distances — a concurrent insertion is either seen here or survives
+                        uint32_t bA = 0, bB = 0;
+                        if (actA) { s_wmin[wi] = XR_DIAL_INF; bA = atomicExch(&s_open[wi], 0u); }
+                        if (actB) { s_wmin[wi2] = XR_DIAL_INF; bB = atomicExch(&s_open[wi2], 0u); }
+                        unsigned long long bits = (unsigned long long)bA | ((unsigned long long)bB << 32);
+                        unsigned long long keep = 0;
+                        uint32_t kminA = XR_DIAL_INF, kminB = XR_DIAL_INF;
+                        while (bits) {                                    // XR_SCAN_UNROLL distance loads in flight at a time
+                            int q[XR_SCAN_UNROLL];
+                            uint32_t w[XR_SCAN_UNROLL];
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) {
+                                q[j] = bits ? __ffsll((long long)bits) - 1 : -1;
+                                bits &= bits - 1;                        // (0 stays 0)
+                            }
+                            int fq[XR_SCAN_UNROLL];
+                            int cx[XR_SCAN_UNROLL], cy[XR_SCAN_UNROLL], cz[XR_SCAN_UNROLL];
+                            uint32_t xcq[XR_SCAN_UNROLL], ycq[XR_SCAN_UNROLL];
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) fq[j] = q[j] >= 0 ? (q[j] & 31) * mw + (q[j] < 32 ? wi : wi2) : 0;
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) w[j] = field[fq[j]];
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) node_xyz((uint32_t)fq[j], cx[j], cy[j], cz[j]);
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) { xcq[j] = s_tab[cx[j] + 1]; ycq[j] = s_tab[XO + cy[j] + 1]; }
+#pragma unroll
+                            for (int j = 0; j < XR_SCAN_UNROLL; j++) {
+                                if (q[j] < 0) continue;
+                                const uint32_t key = (w[j] >> 5) + heur_c((int)xcq[j], (int)ycq[j], cz[j]);
+                                if (key >= hi) {
+                                    keep |= 1ULL << q[j];
+                                    if (q[j] < 32) kminA = key < kminA ? key : kminA; else kminB = key < kminB ? key : kminB;
+                                } else expd |= 1ULL << q[j];
+                            }
+                        }
+                        if ((uint32_t)keep) { atomicOr(&s_open[wi], (uint32_t)keep); atomicMin(&s_wmin[wi], kminA); }
+                        if ((uint32_t)(keep >> 32)) { atomicOr(&s_open[wi2], (uint32_t)(keep >> 32)); atomicMin(&s_wmin[wi2], kminB); }
+                        if (actA) wmA = kminA;
+                        if (actB) wmB = kminB;
+                    }
+                    lmin = wmA < lmin ? wmA : lmin;
+                    lmin = wmB < lmin ? wmB : lmin;
+                }
+                XR_LAP(1);
+                // ---- the wave's nodes of this bucket go into its slice of a small LDS queue (no room: back into the mask)
+                {
+                    const int qcap = XR_QUAD_POOL / ((nthr + 63) >> 6);
+                    int* qcnt = &s_qcnt[wv];
+                    unsigned short* qn = s_qn + wv * qcap;
+                    if (lane == 0) *qcnt = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    while (expd) {
+                        const int qb = __ffsll((long long)expd) - 1;
+                        expd &= expd - 1;
+                        const int wsel = qb < 32 ? wi : wi2;
+                        const uint32_t f = (uint32_t)((qb & 31) * mw + wsel);
+                        const int pos = atomicAdd(qcnt, 1);
+                        if (pos < qcap) qn[pos] = (unsigned short)f;
+                        else { atomicOr(&s_open[wsel], 1u << (qb & 31)); atomicMin(&s_wmin[wsel], m); lmin = m < lmin ? m : lmin; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int nq = min(__builtin_amdgcn_readfirstlane(*qcnt), qcap);
+                    // ---- quads: lanes 4g .. 4g+3 follow ONE chain, lane 4g+d relaxes direction d of the chain's current node
+                    int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
+                    for (int nhop = 0;; nhop++) {
+                        if (nhop >= round_cap) {          // (every hop lowers a field word: finite anyway; the cap is the hang guard)
+                            if (gf >= 0 && dir == 0) { uint32_t oq, orr; xr_divmod((uint32_t)gf, umw, magic_mw, oq, orr); atomicOr(&s_open[orr], 1u << oq); s_abort = 1; }
+                            break;
+                        }
+                        const unsigned long long idle_g = __ballot(gf < 0) & 0x1111111111111111ULL;       // one bit per idle quad
+                        if (gf < 0) {
+                            const int idx = qh + (int)__popcll(idle_g & ((1ULL << qbase) - 1ULL));
+                            if (idx < nq) { gf = (int)qn[idx]; node_xyz((uint32_t)gf, gx, gy, gz); }
+                        }
+                        qh += (int)__popcll(idle_g);
+                        if (__ballot(gf >= 0) == 0ULL) break;                                            // uniform
+                        // ---- one hop of every active quad: all LDS reads together (safe addresses), ALU, one atomic ------------
+                        const bool act = gf >= 0;
+                        const int gfs = act ? gf : 0;
+                        const bool vert = (ldir >> gz) & 1u;
+                        const int c = planar ? (vert ? gy : gx) : gz;
+                        const int lim = vert ? limV : limH;
+                        const bool inb = act && (unsigned)(c + sgn) < (unsigned)lim;
+                        const int nf = inb ? gfs + (vert ? stepV : stepH) : gfs;
+                        const uint32_t gw = field[gfs], wn = field[nf];
+                        const uint32_t xq = s_tab[gx + 1], yq = s_tab[XO + gy + 1];
+                        const uint32_t cb = s_tab[(vert ? XO : 0) + (planar ? c + 1 + sgn : 0)];           // neighbour's coordinate along the layer's axis
+                        const uint32_t ca = vert ? yq : xq;
+                        const uint32_t dlt = cb - ca, adl = (int)dlt < 0 ? 0u - dlt : dlt;
+                        const uint32_t len5 = planar ? adl : via5;
+                        const int nx = gx + ((planar && !vert) ? sgn : 0), ny = gy + ((planar && vert) ? sgn : 0), nz = gz + (planar ? 0 : sgn);
+                        const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + guide_of(nx, ny);
+                        const uint32_t cw = cand5 | (vert ? pdV : pdH) | (wn & 3u);
+                        const uint32_t key = (cand5 >> 5) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
+                        // blockage, or no improvement of the WORD (distance, then predecessor direction): nothing to do
+                        const bool go = inb && wn != 0u && gw < 0xFFFFFFE0u && cand5 < 0xFFFFFFC0u && cw < wn;
+                        const bool refused = go && key > best;                                 // bound pruning (on f)
+                        bool improved = false;
+                        if (go && !refused) {
+                            const uint32_t old = atomicMin(&field[nf], cw);
+                            improved = (cw >> 5) < (old >> 5);                                 // the DISTANCE went down (not only the direction)
+                        }
+                        const bool chain_cand = improved && key < hi;
+                        const uint32_t c4 = (uint32_t)(__ballot(chain_cand) >> qbase) & 15u;
+                        const uint32_t r4 = (uint32_t)(__ballot(refused) >> qbase) & 15u;
+                        const int win = c4 ? __ffs((int)c4) - 1 : -1;                          // the chain goes on with the first lowered direction
+                        if (improved && dir != win) {                                          // the others become open
+                            uint32_t oq, orr;
+                            xr_divmod((uint32_t)nf, umw, magic_mw, oq, orr);
+                            atomicOr(&s_open[orr], 1u << oq);
+                            atomicMin(&s_wmin[orr], key);
+                            lmin = key < lmin ? key : lmin;
+                        }
+                        if (act) {
+                            if (r4 && dir == 0) { uint32_t oq, orr; xr_divmod((uint32_t)gf, umw, magic_mw, oq, orr); atomicOr(&s_defer[orr], 1u << oq); }
+                            if (win >= 0) {                                 // every lane of the quad moves to the winner's node
+                                const int sw_ = (win & 1) ? -1 : 1;
+                                const int wx = (win < 2 && !vert) ? sw_ : 0, wy = (win < 2 && vert) ? sw_ : 0, wz = win < 2 ? 0 : sw_;
+                                gf += wx * YZ + wy * Z + wz;
+                                gx += wx; gy += wy; gz += wz;
+                            } else gf = -1;
                         }
                     }
-                __syncthreads();
-                for (int i0 = 0; i0 < total; i0 += nthr) {
-                    const bool act = i0 + tid < total;
-                    classify(act, act ? (uint32_t)s_tmp[i0 + tid] : 0u);
                 }
-                __syncthreads();
-                return;
+                XR_LAP(2);
             }
-            // more nodes than the list holds (rare): XR3_TMP / 32 words at a time.  Every word is taken exactly once — a node
-            // that classification puts BACK into this mask (cold scan) lands in a word already done (it stays) or still to
-            // come (it is classified again: harmless) — so the scan ends whatever the capacities are.
-            for (int w0 = 0; w0 < mw; w0 += XR3_TMP / 32) {
-                __syncthreads();
-                if (tid == 0) s_cnt = 0;
-                __syncthreads();
-                const int wi = w0 + tid;
-                uint32_t m = (tid < XR3_TMP / 32 && wi < mw) ? mask[wi] : 0u;
-                int p = m ? atomicAdd(&s_cnt, __popc(m)) : 0;
-                if (m) mask[wi] = 0u;
-                while (m) {
-                    const int q = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    s_tmp[p++] = (unsigned short)(q * mw + wi);
-                }
-                __syncthreads();
-                const int tot = s_cnt;
-                for (int i0 = 0; i0 < tot; i0 += nthr) {
-                    const bool act = i0 + tid < tot;
-                    classify(act, act ? (uint32_t)s_tmp[i0 + tid] : 0u);
-                }
-            }
-            __syncthreads();
-        };
-
-        // search start: new sources + deferred nodes are classified (the cold set stays cold: its lower bound still holds)
-        scan_mask(s_defer);
-        XR_LAP(1);
-
-        bool aborted = false;
-        for (int nsr = 0;; nsr++) {
-            // ---- bucket advance: bound, smallest hot bucket, the cold set's lower bound ---------------------------------------
-            if (tid == 0) {
-                s_best = XR3_DMAX; s_bnew = 0xFFFFu; s_nLc[par ^ 1] = 0;
-                s_nc[0] = 0; s_nc[1] = 0; s_nc[2] = 0; s_qh[0] = 0; s_qh[1] = 0; s_qh[2] = 0;
-            }
-            __syncthreads();
-            const int nL = min(s_nLc[par], XR3_CAPL);
-            {
-                uint32_t lb = XR3_DMAX, tmin = 0xFFFFu;     // smallest tentative distance of an unconnected target; smallest hot bucket
-                for (int i = tid; i < nap; i += nthr)
-                    if (!s_ap_conn[i]) { const uint32_t d = field[s_ap_f[i]] >> 5; lb = d < lb ? d : lb; }
-                for (int i = tid; i < nL; i += nthr) { const uint32_t t = s_later[i] >> 16; tmin = t < tmin ? t : tmin; }
-                if (wv * 64 < nap) { lb = xr3_wave_min(lb); if (lane == 0 && lb != XR3_DMAX) atomicMin(&s_best, lb); }
-                if (wv * 64 < nL) { tmin = xr3_wave_min(tmin); if (lane == 0) atomicMin(&s_bnew, tmin); }
-            }
-            __syncthreads();
-            const uint32_t best = s_best;                 // XR3_DMAX: no target reached yet
-            const uint32_t bnew = s_bnew;                 // 0xFFFF: the hot list is empty
-            const uint32_t cold_lb = s_cold_lb;
-            const bool hot_any = nL > 0, cold_any = cold_lb != XR_DIAL_INF;
-            const uint32_t hot_lb = hot_any ? (bnew << dshift) : XR_DIAL_INF;
-            const uint32_t all_lb = hot_lb < cold_lb ? hot_lb : cold_lb;
-            if (all_lb == XR_DIAL_INF || (best != XR3_DMAX && all_lb > best)) break;       // exhausted, or every pending key > best
-            if (nsr >= round_cap || s_abort) { aborted = true; break; }
-#ifdef XR3_NO_ROOM_RULE
-            if (cold_any && (!hot_any || (cold_lb >> dshift) <= bnew)) {
-#else
-            if (cold_any && (!hot_any || ((cold_lb >> dshift) <= bnew && nL <= XR3_CAPL / 2))) {
-#endif
-                // the frontier reached the cold set's lower bound (and the hot list has room): classify the cold set; what
-                // stays cold gets an exact bound.  No room: the hot bucket goes first (order never affects the result).
-                const uint32_t cb = cold_lb >> dshift;
-                hotlim = (hot_any && bnew < cb ? bnew : cb) + XR3_HOTW;
-                __syncthreads();                                  // (every thread has read s_cold_lb)
-                if (tid == 0) s_cold_lb = XR_DIAL_INF;
-                scan_mask(s_cold);                                // (begins and ends with a barrier)
-                continue;
-            }
-            const int bcur = (int)bnew;
-            hotlim = bnew + XR3_HOTW;
-            const uint32_t hi = (bnew + 1u) << dshift;
+            lmin = xr3_wave_min(lmin);
+            if (lane == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
             if (wv == sw) nrounds++;
 #ifdef XR_PHASE_TIMING
             if (tid == XR_TIMING_TID) _ph[7] += 1;
 #endif
-            // ---- partition: entries of this bucket -> queue 0, the rest rebuilt into the list (other counter) -----------------
-            {
-                constexpr int KP = (XR3_CAPL + 63) / 64;         // entries per thread when the workgroup is a single wave
-                uint32_t ent[KP];
-#pragma unroll
-                for (int k = 0; k < KP; k++) { const int i = tid + k * nthr; ent[k] = i < nL ? s_later[i] : 0xFFFFFFFFu; }
-                __syncthreads();                                  // all reads before the list is rewritten
-#pragma unroll
-                for (int k = 0; k < KP; k++) {
-                    if (k * nthr >= nL) break;                    // uniform
-                    const bool have = tid + k * nthr < nL;
-                    const bool isc = have && (ent[k] >> 16) == bnew;
-                    const int pc = block_append(isc, &s_nc[0]);
-                    const bool toc = isc && pc < XR3_CAPC;
-                    if (toc) s_cur[pc] = (unsigned short)(ent[k] & 0xFFFFu);
-                    const bool keep = have && !toc;               // (a bucket larger than the queue: the rest stays in the list)
-                    const int pk = block_append(keep, &s_nLc[par ^ 1]);
-                    if (keep) s_later[pk] = ent[k];
-                }
-                par ^= 1;
-                __syncthreads();
-            }
+            __syncthreads();
             XR_LAP(6);
-            // ---- the bucket: sub-rounds over three rotating queues (take from one, in-bucket nodes go to the next, the third is
-            // reset); within a sub-round every wave's quads follow chains and take queue entries until the queue is drained ------
-            for (int sub = 0;; sub++) {
-                const int cbuf = sub % 3, nbuf = (sub + 1) % 3, rbuf = (sub + 2) % 3;
-                const int ncur = min(s_nc[cbuf], XR3_CAPC);
-                if (ncur == 0) break;                             // uniform
-                if (sub >= round_cap) {                           // hang guard: what is queued goes cold, the search aborts
-                    for (int i = tid; i < ncur; i += nthr) { mask_or(s_cold, (uint32_t)s_cur[cbuf * XR3_CAPC + i]); atomicMin(&s_cold_lb, 0u); }
-                    if (tid == 0) s_abort = 1;
-                    break;
-                }
-                if (tid == 0) { s_nc[rbuf] = 0; s_qh[rbuf] = 0; }
-#ifdef XR3_COUNT
-                if (tid == XR_TIMING_TID) { _ph[1] += 1; _ph[3] += ncur; }      // sub-rounds; queue entries
-#endif
-                const unsigned short* qcur = s_cur + cbuf * XR3_CAPC;
-                unsigned short* qnxt = s_cur + nbuf * XR3_CAPC;
-                int gf = -1, gx = 0, gy = 0, gz = 0;
-                bool drained = false;
-                for (int nhop = 0;; nhop++) {
-                    if (nhop >= round_cap) {                      // hang guard (every hop lowers a field word: finite anyway)
-                        if (gf >= 0 && dir == 0) { mask_or(s_cold, (uint32_t)gf); atomicMin(&s_cold_lb, 0u); s_abort = 1; }
-                        break;
-                    }
-                    const unsigned long long idle_g = __ballot(gf < 0) & 0x1111111111111111ULL;       // one bit per idle quad
-                    if (idle_g != 0ULL && !drained) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&s_qh[cbuf], (int)__popcll(idle_g));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (base >= ncur) drained = true;
-                        else if (gf < 0) {
-                            const int idx = base + (int)__popcll(idle_g & ((1ULL << qbase) - 1ULL));
-                            if (idx < ncur) { gf = (int)qcur[idx]; node_xyz((uint32_t)gf, gx, gy, gz); }
-                        }
-                    }
-                    if (__ballot(gf >= 0) == 0ULL) break;                                            // this wave: queue drained, no chain alive
-#ifdef XR3_COUNT
-                    if (tid == XR_TIMING_TID) { _ph[4] += 1; _ph[5] += (long long)__popcll(__ballot(gf >= 0)) >> 2; }   // hop iterations; active quads (this wave)
-#endif
-                    // ---- one hop of every active quad: all LDS reads together (safe addresses), ALU, one atomic ------------
-                    const bool act = gf >= 0;
-                    const int gfs = act ? gf : 0;
-                    const bool vert = (ldir >> gz) & 1u;
-                    const int c = planar ? (vert ? gy : gx) : gz;
-                    const int lim = vert ? limV : limH;
-                    const bool inb = act && (unsigned)(c + sgn) < (unsigned)lim;
-                    const int nf = inb ? gfs + (vert ? stepV : stepH) : gfs;
-                    const uint32_t gw = field[gfs], wn = field[nf];
-                    const uint32_t xq = s_tab[gx + 1], yq = s_tab[XO + gy + 1];
-                    const uint32_t cb = s_tab[(vert ? XO : 0) + (planar ? c + 1 + sgn : 0)];           // neighbour's coordinate along the layer's axis
-                    const uint32_t ca = vert ? yq : xq;
-                    const uint32_t dlt = cb - ca, adl = (int)dlt < 0 ? 0u - dlt : dlt;
-                    const uint32_t len5 = planar ? adl : via5;
-                    const int nx = gx + ((planar && !vert) ? sgn : 0), ny = gy + ((planar && vert) ? sgn : 0), nz = gz + (planar ? 0 : sgn);
-                    const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + guide_of(nx, ny);
-                    const uint32_t cw = cand5 | (vert ? pdV : pdH) | (wn & 3u);
-                    const uint32_t key = (cand5 >> 5) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
-                    // blockage, or no improvement of the WORD (distance, then predecessor direction): nothing to do
-                    const bool go = inb && wn != 0u && gw < 0xFFFFFFE0u && cand5 < 0xFFFFFFC0u && cw < wn;
-                    const bool refused = go && best != XR3_DMAX && key > best;                  // bound pruning (on f)
-                    bool improved = false;
-                    if (go && !refused) {
-                        const uint32_t old = atomicMin(&field[nf], cw);
-                        improved = (cw >> 5) < (old >> 5);                                     // the DISTANCE went down (not only the direction)
-                    }
-                    const bool chain_cand = improved && key < hi;
-                    const uint32_t c4 = (uint32_t)(__ballot(chain_cand) >> qbase) & 15u;
-                    const int win = c4 ? __ffs((int)c4) - 1 : -1;                              // the chain goes on with the first lowered direction
-                    const bool psh = improved && dir != win;
-                    if (__ballot(psh) != 0ULL) {                                               // the others join the frontier
-                        const uint32_t kb = key >> dshift;
-                        const bool wantc = psh && kb == (uint32_t)bcur;
-                        const int pc = block_append(wantc, &s_nc[nbuf]);
-                        const bool toc = wantc && pc < XR3_CAPC;
-                        if (toc) qnxt[pc] = (unsigned short)nf;
-                        push_later(psh && !toc, (uint32_t)nf, key, kb);
-                    }
-                    const unsigned long long mR = __ballot(refused);
-                    if (mR != 0ULL) {                                                          // an edge refused by the bound: the node is looked at again
-                        const uint32_t r4 = (uint32_t)(mR >> qbase) & 15u;
-                        if (r4 && dir == 0 && act) mask_or(s_defer, (uint32_t)gf);
-                    }
-                    if (act) {
-                        if (win >= 0) {                                 // every lane of the quad moves to the winner's node
-                            const int sw_ = (win & 1) ? -1 : 1;
-                            const int wx = (win < 2 && !vert) ? sw_ : 0, wy = (win < 2 && vert) ? sw_ : 0, wz = win < 2 ? 0 : sw_;
-                            gf += wx * YZ + wy * Z + wz;
-                            gx += wx; gy += wy; gz += wz;
-                        } else gf = -1;
-                    }
-                }
-                __syncthreads();
-            }
-            XR_LAP(2);
+            cur = nx1;
         }
-        // what is still in the hot list goes cold: its keys are >= the tag's bucket edge, and keys only grow from here on
-        {
-            const int nL = min(s_nLc[par], XR3_CAPL);
-            for (int i = tid; i < nL; i += nthr) {
-                const uint32_t ent = s_later[i];
-                mask_or(s_cold, ent & 0xFFFFu);
-                atomicMin(&s_cold_lb, (ent >> 16) << dshift);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { s_nLc[par] = 0; }
-        XR_LAP(6);
 
-        // ===================== the tracing wave: target, back-trace, new sources (the others wait at the barrier) ==========
+        // ===================== the tracing wave: target, back-trace, new sources (the others go on to the next barrier) ==========
         if (wv == sw) {
             int remaining = s_remaining;
             if (aborted) {                        // round cap: the remaining pins are charged as unreachable, nothing is traced
@@ -562,8 +455,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         XR3_WSYNC();
                         for (int i = lane; i < np; i += 64) {
                             const uint32_t f = s_tmp[i];
-                            field[f] &= 3u;
-                            mask_or(s_defer, f);
+                            make_source(f);
                             if (owner[f] == 0) owner[f] = claim_val;
                         }
                         XR3_WSYNC();
@@ -597,13 +489,13 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         remaining -= 1;
                         // the reached pin joins the component with all of its access points
                         for (int i = lane; i < nap; i += 64)
-                            if (s_ap_pin[i] == (short)tpin) { s_ap_conn[i] = 1; field[s_ap_f[i]] &= 3u; mask_or(s_defer, (uint32_t)s_ap_f[i]); }
+                            if (s_ap_pin[i] == (short)tpin) { s_ap_conn[i] = 1; make_source((uint32_t)s_ap_f[i]); }
                     }
                 }
             }
             if (lane == 0) s_remaining = remaining;
         }
-        __syncthreads();
+        __syncthreads();      // every thread has left the round loop (its exit test reads s_min / s_bst) before the next search resets them
         XR_LAP(3);
     }
     // ---- does the attempt stand (XR-Maze v2)?  Its path uses a node held by another net and attempts are left: rip it up ----
@@ -626,7 +518,6 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     pen5 = ((uint32_t)b.pen_cost << 5) << attempt;
     __syncthreads();                                          // the owner grid is clean again before the field is rebuilt
     build_field();
-    if (tid == 0) s_cold_lb = XR_DIAL_INF;
     for (int i = tid; i < nap; i += nthr) s_ap_conn[i] = (unsigned char)(s_ap_conn[i] == 2 ? 2 : (s_ap_pin[i] == (short)first_pin ? 1 : 0));
     __syncthreads();
     }
