@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from xroute_env_amd.regions import ACCESS, BLOCKAGE, NORMAL, Region, pack_records
+from xroute_env_amd.regions import ACCESS, BLOCKAGE, NORMAL, Region, pack_records, records_from_entries
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -32,23 +32,16 @@ def g1_data(case) -> list:
 
 
 def g1_records(case) -> np.ndarray:
-    """Dense packed records of a G1 case (nodes absent from the list = unused NORMAL)."""
+    """Dense packed records of a G1 case (nodes absent from the list = unused NORMAL; a vertex listed twice = the reference's
+    per-entry OR, regions.records_from_entries)."""
     X, Y, Z = (int(v) for v in case["dims"])
     n = X * Y * Z
-    ntype = np.full(n, NORMAL, np.int64)
-    used = np.zeros(n, np.int64)
-    net = np.full(n, -1, np.int64)
-    pin = np.full(n, -1, np.int64)
-    if len(case["maze"]):
-        m = case["maze"].astype(np.int64)
-        info = case["info"].astype(np.int64)
-        f = (m[:, 0] * Y + m[:, 1]) * Z + m[:, 2]
-        t = info[:, 1]
-        ntype[f] = np.where(t == -1, BLOCKAGE, np.where(t == 0, NORMAL, ACCESS))
-        used[f] = info[:, 0]
-        net[f] = np.where(t >= 1, t - 1, -1)
-        pin[f] = np.where(t >= 1, info[:, 2] - 1, -1)
-    return pack_records(ntype, used, net, pin)
+    if not len(case["maze"]):
+        return records_from_entries(n, [], [], [], [])
+    m = case["maze"].astype(np.int64)
+    info = case["info"].astype(np.int64)
+    f = (m[:, 0] * Y + m[:, 1]) * Z + m[:, 2]
+    return records_from_entries(n, f, info[:, 1], info[:, 0], info[:, 2])
 
 
 def load_json(name):

@@ -179,6 +179,37 @@ def gen_g1(ref_grid):
             data_inf = [data[0], data[1], data[2], [1, 4, 9, 10]]
             cases.append((data_inf, set(), True))
 
+    # (e) a vertex listed more than once (appended last: the cases above and their random stream stay byte-identical).  The
+    # reference looks at every entry on its own (build_3Dgrid.py:18-43): obstacle OR access point from either entry.
+    dup = [[2, 2, 3], [], [2, 500, 1], [1, 2]]
+    for (x, y, z, info) in [(0, 0, 0, [1, -1, -1]), (0, 0, 0, [0, 1, 1]),          # blockage + unused AP of net 1
+                            (1, 0, 1, [1, 0, -1]), (1, 0, 1, [0, 2, 1]),           # occupied plain node + unused AP of net 2
+                            (1, 1, 2, [0, 1, 1]), (1, 1, 2, [0, 1, 2]),            # the same vertex as two pins of net 1
+                            (0, 1, 2, [0, 1, 2]), (0, 1, 1, [0, 0, -1]), (0, 1, 1, [0, 0, -1]),   # a plain node twice
+                            (1, 1, 1, [0, 2, 3]), (1, 1, 1, [1, 2, 3])]:           # AP listed unused, then used
+        dup[1].append([[x, y, z], [10 * x, 20 * y, z], info])
+    cases.append((dup, set(), False))
+    cases.append((dup, {2}, False))
+    cases.append((dup, set(), True))
+    rng_d = np.random.default_rng(20241002)
+    for i in range(5):
+        data = random_tiny_data(rng_d, full=True)
+        extra = []
+        for v in data[1]:
+            if rng_d.random() < 0.3:                 # list the vertex again: same net if it is an access point, other flags free
+                info = list(v[2])
+                if info[1] >= 1:
+                    info = [int(rng_d.random() < 0.5), info[1], int(rng_d.integers(1, 4))]
+                    if rng_d.random() < 0.3:
+                        info = [int(rng_d.random() < 0.8), -1, -1]
+                else:
+                    info = [int(rng_d.random() < 0.5), int(rng_d.choice([-1, 0])), -1]
+                extra.append([list(v[0]), list(v[1]), info])
+        data[1] = data[1] + extra
+        order = rng_d.permutation(len(data[1]))
+        data[1] = [data[1][j] for j in order]
+        cases.append((data, set(), bool(i & 1)))
+
     out = {"n_cases": np.array(len(cases))}
     for i, (data, routed, inference) in enumerate(cases):
         obs, netset, v, w, via = quiet(ref_grid.build_3Dgrid, data, set(routed), inference)

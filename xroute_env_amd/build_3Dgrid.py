@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .regions import ACCESS, BLOCKAGE, NORMAL, pack_records
+from .regions import ACCESS, BLOCKAGE, NORMAL, pack_records, records_from_entries
 
 
 def get_grid_size(data):
@@ -26,25 +26,19 @@ def get_grid_size(data):
 def data_to_records(data) -> np.ndarray:
     """Reference `data` list -> dense packed node records in flat order f=(x*Y+y)*Z+z.
     Vertices the list does not mention are unused NORMAL nodes (the reference never touches them,
-    baseline/build_3Dgrid.py:18-43)."""
+    baseline/build_3Dgrid.py:18-43); a vertex listed more than once is an obstacle / an access point if ANY of its entries
+    says so, as in the reference's per-entry loop (regions.records_from_entries)."""
     X, Y, Z = (int(v) for v in data[0])
     n = X * Y * Z
-    ntype = np.full(n, NORMAL, np.int64)
-    used = np.zeros(n, np.int64)
-    net = np.full(n, -1, np.int64)
-    pin = np.full(n, -1, np.int64)
-    if len(data[1]):
-        maze = np.array([v[0] for v in data[1]], dtype=np.int64).reshape(-1, 3)
-        info = np.array([v[2] for v in data[1]], dtype=np.int64).reshape(-1, 3)
-        f = (maze[:, 0] * Y + maze[:, 1]) * Z + maze[:, 2]
-        t = info[:, 1]
-        if ((t < -1)).any():
-            raise AssertionError("Net must be -1, 0 or >= 1")      # build_3Dgrid.py:32 asserts the same
-        ntype[f] = np.where(t == -1, BLOCKAGE, np.where(t == 0, NORMAL, ACCESS))
-        used[f] = (info[:, 0] == 1)                                  # `bool_occupy == 1` (:24,:34)
-        net[f] = np.where(t >= 1, t - 1, -1)
-        pin[f] = np.where(t >= 1, np.maximum(info[:, 2] - 1, -1), -1)
-    return pack_records(ntype, used, net, pin)
+    if not len(data[1]):
+        return records_from_entries(n, [], [], [], [])
+    maze = np.array([v[0] for v in data[1]], dtype=np.int64).reshape(-1, 3)
+    info = np.array([v[2] for v in data[1]], dtype=np.int64).reshape(-1, 3)
+    f = (maze[:, 0] * Y + maze[:, 1]) * Z + maze[:, 2]
+    t = info[:, 1]
+    if ((t < -1)).any():
+        raise AssertionError("Net must be -1, 0 or >= 1")      # build_3Dgrid.py:32 asserts the same
+    return records_from_entries(n, f, t, info[:, 0], info[:, 2])      # `bool_occupy == 1` (:24,:34)
 
 
 def legal_nets(records: np.ndarray, routed_nets: Iterable[int], bool_inference: bool,

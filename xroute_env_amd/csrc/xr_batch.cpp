@@ -556,8 +556,11 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     // FULL-rewrite queue launch of a very large batch, where the line-segment sweeps are ahead (same box, DESIGN.md §5.1:
     // 1.727-1.730 ms against 1.773-1.775 ms per 4096-env step; at 2048 envs the frontier router wins, 0.921 against 0.945-0.954 ms)
     b->sweep_lds = std::max(lds_need, b->stream_ok && !mult4 ? stream_bytes : ids_bytes);
+    // (round 3, same box: synthetic 24x40x9 regions 1.681 ms with the sweeps against 1.700 ms with the frontier router; the regions
+    //  extracted from ispd18_test1 — unaligned planes, 3.5 pins per net, K up to 77: their step is bound by routing, not by the write
+    //  stream — 2.40 ms against 2.05 ms: the sweeps are only chosen for aligned planes)
     b->sweep_full = b->cfg.router == 0 && (b->kzch == -1 || b->kzch == -3) && b->lds_dist && sweep_lds_ok && b->cfg.block_threads == 0 &&
-                    b->cfg.n_envs >= 4096 && b->sweep_lds + kLdsStatic <= kLdsLimit;
+                    b->cfg.n_envs >= 4096 && mult4 && b->sweep_lds + kLdsStatic <= kLdsLimit;
     if (b->route_lds + kLdsStatic > kLdsLimit)
         return fail(XR_ERR_RANGE, "route kernel needs %zu bytes of LDS (line bitmasks of the largest region)", b->route_lds);
     if (std::max(b->route_lds, b->sweep_full ? b->sweep_lds : 0) > 64 * 1024)

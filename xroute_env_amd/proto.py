@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .regions import ACCESS, BLOCKAGE, NORMAL, pack_records
+from .regions import ACCESS, BLOCKAGE, NORMAL, pack_records, records_from_entries
 
 KIND_EMPTY, KIND_REQUEST, KIND_RESPONSE = 0, 1, 2
 
@@ -150,8 +150,8 @@ def request_records(msg: DecodedMessage):
         t[acc & (f[:, 8] == -2)] = BLOCKAGE        # Net == -1: an obstacle
         acc = t == ACCESS
         flat = (f[:, 0] * Y + f[:, 1]) * Z + f[:, 2]
-        ntype[flat] = t
-        used[flat] = f[:, 7]
-        net[flat] = np.where(acc, f[:, 8], -1)
-        pin[flat] = np.where(acc, f[:, 9], -1)
+        # handle_messange's `Net` / `Pin` of every entry (1-based for access points), then the reference's per-entry meaning of a
+        # list that names a vertex twice (obstacle / access point if ANY entry says so)
+        Net = np.where(acc, f[:, 8] + 1, np.where(t == BLOCKAGE, -1, 0))
+        return records_from_entries(n, flat, Net, f[:, 7], np.where(acc, f[:, 9] + 1, -1))
     return pack_records(ntype, used, net, pin)

@@ -46,6 +46,40 @@ def pack_records(ntype, used, net, pin) -> np.ndarray:
     return rec.astype(np.uint32)
 
 
+def records_from_entries(n: int, flat, Net, used, Pin) -> np.ndarray:
+    """Dense packed records from a node LIST that may name a vertex more than once, with the meaning the reference gives such a
+    list (baseline/build_3Dgrid.py:18-43 looks at every entry on its own): the vertex is an obstacle if ANY of its entries is
+    (Net == -1, or occupied), and an access point of net n if ANY of its entries says so.  `Net` follows handle_messange:
+    -1 blockage, 0 plain node, >= 1 the 1-based net of an access point; `Pin` 1-based or -1.  In dense form an obstacle that is also
+    an access point is a used ACCESS node — the same observation.  Not representable (ValueError): one vertex as an access point
+    of two different nets.  Vertices the list does not mention are unused NORMAL nodes."""
+    flat = np.asarray(flat, np.int64)
+    Net = np.asarray(Net, np.int64)
+    used = np.asarray(used, np.int64) == 1
+    Pin = np.asarray(Pin, np.int64)
+    ntype = np.full(n, NORMAL, np.int64)
+    u = np.zeros(n, np.int64)
+    net = np.full(n, -1, np.int64)
+    pin = np.full(n, -1, np.int64)
+    if len(flat):
+        acc, blk = Net >= 1, Net == -1
+        any_acc = np.zeros(n, bool); any_blk = np.zeros(n, bool); any_used = np.zeros(n, bool)
+        np.logical_or.at(any_acc, flat, acc)
+        np.logical_or.at(any_blk, flat, blk)
+        np.logical_or.at(any_used, flat, used)
+        lo = np.full(n, np.iinfo(np.int64).max, np.int64); hi = np.full(n, -1, np.int64)
+        np.minimum.at(lo, flat[acc], Net[acc])
+        np.maximum.at(hi, flat[acc], Net[acc])
+        if (any_acc & (lo != hi)).any():
+            raise ValueError("a vertex is listed as an access point of two different nets: not representable as one node record")
+        ntype[any_blk] = BLOCKAGE
+        ntype[any_acc] = ACCESS
+        u[any_used | (any_blk & any_acc)] = 1
+        net[flat[acc]] = Net[acc] - 1
+        pin[flat[acc]] = np.maximum(Pin[acc] - 1, -1)
+    return pack_records(ntype, u, net, pin)
+
+
 def unpack_records(rec: np.ndarray):
     rec = np.asarray(rec, dtype=np.uint32).astype(np.int64)
     ntype = rec & 3
