@@ -177,6 +177,8 @@ typedef struct xr_region_desc {
                                                  router: the work it really did; 0 for the other forms) */
 #define XR_FETCH_UNITS    17   /* uint32[1]     net-plane units (7 planes of one net of one env) the last xr_batch_step_observe* planned */
 #define XR_FETCH_ROUTE_ORDER 18 /* int32[B]     env slots in the order the last longest-first route-only launch handed them out (xr_config.launch_order) */
+#define XR_FETCH_REPLAY   19   /* int32 [B]     replays of the current region so far (region rotation, examples/launch_training.py:28-46) */
+#define XR_FETCH_ENV_STEPS 20  /* int64 [B]     real steps of every env slot since create */
 #define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
                                                  built with -DXR_PHASE_TIMING) */
 
@@ -312,6 +314,14 @@ int32_t xr_batch_observation(xr_batch* b, float* out_dev, int64_t env_stride, in
                              int32_t env_hi, void* stream);
 
 int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_bytes, void* stream);
+
+/* Env-state restore: the inverse of xr_batch_fetch for the arrays that ARE the state of the env slots — XR_FETCH_OWNER, _LEGAL,
+ * _NLEGAL, _CUM, _DELTA, _REWARD, _DONE, _STATUS, _PATH_LEN, _HASH, _REGION, _REPLAY, _ENV_STEPS, _RECORD (any other selector:
+ * XR_ERR_INVALID).  src_dev: a DEVICE buffer or pinned host memory of exactly the array's size; async on `stream`.  The
+ * reference never checkpoints its env (the state lives in the simulator process; its agents do: baseline/DQN/DQN.py:236-242):
+ * here the whole batch state is a handful of device arrays, so a dump (fetch) / restore (store) pair is the env checkpoint —
+ * a batch restored into a twin created with the same config and regions continues bit-identically (hash chains included). */
+int32_t xr_batch_store(xr_batch* b, int32_t what, const void* src_dev, size_t src_bytes, void* stream);
 
 /* ---- stateless observation build --------------------------------------------------------- */
 /* Replaces build_3Dgrid(data, routed_nets, bool_inference) for a caller that already holds the

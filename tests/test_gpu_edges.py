@@ -134,3 +134,39 @@ def test_config_limits():
     cfg.device = 99
     h = C.c_void_p()
     assert L.xr_batch_create(C.byref(cfg), C.byref(h)) == _lib.XR_ERR_HIP
+
+
+@pytest.mark.gpu
+def test_env_state_dump_and_restore_continues_bit_identically():
+    """RegionBatch.state_dict() / load_state_dict() (xr_batch_fetch / xr_batch_store of the arrays that are the env state): a twin
+    restored from a mid-episode dump — after resets, rotation and rejected actions — continues exactly like the original: records,
+    owners, legal sets, hash chains, and the observation."""
+    import numpy as np
+    import torch
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import generate_region
+    regions = [generate_region(6100 + i, dims=(10, 9, 4), k_range=(2, 5), net_span=5) for i in range(6)]
+    kw = dict(n_envs=16, device="cuda:0", auto_reset=True, max_route_count=2)
+    a = RegionBatch(regions, **kw)
+    a.reset(rotate=True)
+    acts = torch.empty(16, dtype=torch.int32, device="cuda:0")
+    for i in range(9):
+        a.random_actions(70 + i, acts)
+        if i == 4:
+            acts[::3] = 99          # rejected actions are state too (status bits)
+        a.step(acts)
+    dump = a.state_dict()
+    b = RegionBatch(regions, **kw)
+    b.load_state_dict(dump)
+    for k in RegionBatch._STATE:
+        assert torch.equal(a.fetch(k), b.fetch(k)), k
+    for i in range(12):
+        a.random_actions(90 + i, acts)
+        a.step(acts)
+        b.step(acts)
+        assert np.array_equal(a.records(), b.records())
+    for k in RegionBatch._STATE:
+        assert torch.equal(a.fetch(k), b.fetch(k)), k
+    assert torch.equal(a.observation(), b.observation())
+    with pytest.raises(Exception):
+        RegionBatch(regions[:3], n_envs=16, device="cuda:0").load_state_dict(dump)

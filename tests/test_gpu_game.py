@@ -137,3 +137,36 @@ def test_gym_facade_and_vector_env():
         for i, e in enumerate(ob.envs):
             ro = e.observation()
             assert np.array_equal(ro.ravel(), o[i, :ro.size])
+
+
+def test_fixed_shape_dict_spaces_on_the_device():
+    """fixed_shape=True: observations are {"grid": the reference tensor zero-padded to 2+7*Kmax channels, "legal_mask"} and lie in
+    the Dict space defined at construction; the vector env's legal_mask() is the same mask for every slot."""
+    from xroute_env_amd.envs import OrderingTrainingEnv, XRouteVectorEnv
+    regions = [generate_region(7400 + i, dims=(8, 7, 3), k_range=(2, 5)) for i in range(4)]
+    env = OrderingTrainingEnv(regions, fixed_shape=True)
+    kmax = max(r.n_nets for r in regions)
+    assert env.observation_space["grid"].shape == (2 + 7 * kmax, 3, 7, 8) and env.action_space.n == kmax
+    obs, info = env.reset()
+    plain = OrderingTrainingEnv(regions)
+    pobs, pinfo = plain.reset()
+    for _ in range(3):
+        assert obs in env.observation_space
+        k = len(info["legal_actions"])
+        assert sorted(np.nonzero(obs["legal_mask"])[0] + 1) == info["legal_actions"] == pinfo["legal_actions"]
+        assert torch.equal(obs["grid"][:2 + 7 * k], pobs) and float(obs["grid"][2 + 7 * k:].abs().sum()) == 0.0
+        assert pobs in plain.observation_space                    # per-episode form: the Box of the current shape
+        a = info["legal_actions"][-1]
+        assert a in env.action_space
+        obs, rew, term, _, info = env.step(a)
+        pobs, prew, pterm, _, pinfo = plain.step(a)
+        assert rew == prew and term == pterm
+        if term:
+            break
+    venv = XRouteVectorEnv(regions)
+    venv.reset()
+    m = venv.legal_mask().cpu().numpy()
+    assert m.shape == (4, kmax) and m in venv.observation_space["legal_mask"]
+    for e, s in enumerate(venv.batch.legal_sets()):
+        assert sorted(np.nonzero(m[e])[0] + 1) == sorted(s)
+    assert venv.observation_space["grid"].shape[0] == 4 and venv.single_observation_space["grid"].shape == (2 + 7 * kmax, 3, 7, 8)

@@ -84,3 +84,48 @@ def test_recorded_pmc_traffic_file_is_quotable():
         k = r["xr_step_queue_kernel"]
         assert k["hbm_total_bytes"] == pytest.approx(k["hbm_read_bytes"] + k["hbm_write_bytes"])
         assert 0.98 < k["hbm_total_bytes"] / k["algorithmic_bytes"] < 1.10
+
+
+def test_fixed_shape_spaces_with_and_without_gymnasium():
+    """The façade's spaces (Dict{grid: Box[Cmax,Z,Y,X], legal_mask: MultiBinary(Kmax)}; the reference only reserves
+    the gymnasium id, xroute_env/__init__.py:3-6): built from the stand-ins when gymnasium is absent and from gymnasium.spaces when it
+    is importable (a stub module here: the image has no gymnasium)."""
+    import sys
+    import types
+    import numpy as np
+    from xroute_env_amd.envs import spaces as sp
+    obs_space, act_space = sp.fixed_spaces((24, 40, 9), 36, sp=sp)
+    assert obs_space["grid"].shape == (2 + 7 * 36, 9, 40, 24) and obs_space["legal_mask"].shape == (36,)
+    assert act_space.n == 36 and act_space.start == 1 and 1 in act_space and 36 in act_space and 0 not in act_space and 37 not in act_space
+    ok = {"grid": np.zeros((254, 9, 40, 24), np.float32), "legal_mask": np.ones(36, np.int8)}
+    assert ok in obs_space
+    assert {"grid": np.zeros((253, 9, 40, 24), np.float32), "legal_mask": np.ones(36, np.int8)} not in obs_space
+    assert {"grid": ok["grid"], "legal_mask": np.full(36, 2, np.int8)} not in obs_space
+    vec, _ = sp.fixed_spaces((24, 40, 9), 36, batch=8, sp=sp)
+    assert vec["grid"].shape == (8, 254 * 8640) and vec["legal_mask"].shape == (8, 36)
+    box, act = sp.episode_spaces((16, 5, 5, 5), 2, sp=sp)
+    assert box.shape == (16, 5, 5, 5) and act.n == 2
+    # a stub `gymnasium` that records what it is asked for: backend() must pick it up
+    made = []
+    stub = types.ModuleType("gymnasium")
+    gs = types.ModuleType("gymnasium.spaces")
+    for name in ("Box", "Discrete", "MultiBinary", "Dict"):
+        def mk(name=name):
+            def ctor(*a, **k):
+                made.append((name, a, k))
+                return (name, a, k)
+            return ctor
+        setattr(gs, name, mk())
+    stub.spaces = gs
+    sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = stub, gs
+    try:
+        assert sp.backend() is gs
+        o, a = sp.fixed_spaces((3, 4, 5), 7)
+        assert o[0] == "Dict" and a[0] == "Discrete" and a[1] == (7,) and a[2] == {"start": 1}
+        kinds = [m[0] for m in made]
+        assert kinds.count("Box") == 1 and kinds.count("MultiBinary") == 1
+        boxk = [m for m in made if m[0] == "Box"][0][2]
+        assert boxk["shape"] == (2 + 7 * 7, 5, 4, 3) and boxk["dtype"] == np.float32
+    finally:
+        del sys.modules["gymnasium"], sys.modules["gymnasium.spaces"]
+    assert sp.backend() is sp

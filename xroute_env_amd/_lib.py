@@ -20,13 +20,13 @@ XR_OWNER_FOREIGN = 0x7FFF
 (XR_FETCH_CUM, XR_FETCH_DELTA, XR_FETCH_REWARD, XR_FETCH_DONE, XR_FETCH_NLEGAL, XR_FETCH_STATUS,
  XR_FETCH_LEGAL, XR_FETCH_PATH_LEN, XR_FETCH_PATH, XR_FETCH_OWNER, XR_FETCH_HASH, XR_FETCH_REGION,
  XR_FETCH_STEPS, XR_FETCH_SWEEPS, XR_FETCH_PHASES, XR_FETCH_RECORD, XR_FETCH_TOUCHED, XR_FETCH_UNITS,
- XR_FETCH_ROUTE_ORDER) = range(19)
+ XR_FETCH_ROUTE_ORDER, XR_FETCH_REPLAY, XR_FETCH_ENV_STEPS) = range(21)
 
 # every symbol include/xroute_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "xr_abi_version", "xr_last_error", "xr_config_default", "xr_device_count",
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
-    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_step_observe_inplace", "xr_batch_step_compact", "xr_batch_net_planes", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch",
+    "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_step_observe_inplace", "xr_batch_step_compact", "xr_batch_net_planes", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch", "xr_batch_store",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 
@@ -101,6 +101,7 @@ def lib():
     L.xr_batch_random_actions.argtypes = [vp, vp, C.c_uint64, vp]
     L.xr_batch_observation.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.xr_batch_fetch.argtypes = [vp, C.c_int32, vp, C.c_size_t, vp]
+    L.xr_batch_store.argtypes = [vp, C.c_int32, vp, C.c_size_t, vp]
     L.xr_observation_from_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
     L.xr_proto_decode.argtypes = [vp, C.c_size_t, vp, vp, vp, vp]
     L.xr_proto_encode_response.argtypes = [C.c_int32, vp, C.POINTER(C.c_size_t)]

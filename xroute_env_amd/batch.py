@@ -279,7 +279,12 @@ class RegionBatch:
         "route_order": (_lib.XR_FETCH_ROUTE_ORDER, torch.int32, lambda s: (s.n_envs,)),
         "touched": (_lib.XR_FETCH_TOUCHED, torch.int32, lambda s: (s.n_envs,)),
         "record": (_lib.XR_FETCH_RECORD, torch.uint8, lambda s: (s.n_envs, _lib.RECORD_BYTES)),
+        "replay": (_lib.XR_FETCH_REPLAY, torch.int32, lambda s: (s.n_envs,)),
+        "env_steps": (_lib.XR_FETCH_ENV_STEPS, torch.int64, lambda s: (s.n_envs,)),
     }
+    # the arrays that ARE the env state (xr_batch_store accepts exactly these)
+    _STATE = ("owner", "legal", "nlegal", "cum", "delta", "reward", "done", "status", "path_len", "hash", "region", "replay",
+              "env_steps", "record")
 
     def fetch(self, what: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Copy one result array into a device tensor (async on the current stream)."""
@@ -301,6 +306,29 @@ class RegionBatch:
             _lib.check(self.L.xr_batch_fetch(self._h, sel, C.c_void_p(out.data_ptr()),
                                              out.numel() * out.element_size(), _stream_ptr(self.device)))
         return out
+
+    def state_dict(self) -> dict:
+        """Env checkpoint: every array that is state of the env slots, as CPU tensors (+ the sizes a restore must match).  The
+        reference never checkpoints its env — the state lives in the simulator process; only its agents are saved
+        (baseline/DQN/DQN.py:236-242)."""
+        d = {k: self.fetch(k).cpu() for k in self._STATE}
+        d["_meta"] = torch.tensor([self.n_envs, self.n_regions, self.n_max, self.legal_words], dtype=torch.int64)
+        return d
+
+    def load_state_dict(self, d: dict):
+        """Restore a state_dict() into a batch created with the same regions and config: it continues bit-identically."""
+        meta = [int(v) for v in d["_meta"]]
+        if meta != [self.n_envs, self.n_regions, self.n_max, self.legal_words]:
+            raise ValueError(f"state of a different batch: (n_envs, n_regions, n_max, legal_words) = {meta}")
+        with torch.cuda.device(self.device):
+            for k in self._STATE:
+                sel, dtype, shape = self._FETCH[k]
+                t = d[k].to(device=self.device, dtype=dtype).contiguous()
+                if tuple(t.shape) != tuple(shape(self)):
+                    raise ValueError(f"state array {k}: shape {tuple(t.shape)} != {tuple(shape(self))}")
+                _lib.check(self.L.xr_batch_store(self._h, sel, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                                 _stream_ptr(self.device)))
+            torch.cuda.current_stream(self.device).synchronize()          # the staging tensors die with this frame
 
     def legal_sets(self) -> List[set]:
         """netSet of every env as Python sets of 1-based ids (host sync)."""

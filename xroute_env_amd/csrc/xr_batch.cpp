@@ -1034,6 +1034,8 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_TOUCHED: src = b->touched.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;
     case XR_FETCH_PHASES: src = b->phase_cycles.p; bytes = B * 8 * sizeof(long long); break;
+    case XR_FETCH_REPLAY: src = b->env_replay.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_ENV_STEPS: src = b->env_steps.p; bytes = B * sizeof(int64_t); break;
     default: return fail(XR_ERR_INVALID, "xr_batch_fetch: unknown selector %d", what);
     }
     if (dst_bytes < bytes)
@@ -1042,6 +1044,37 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     // (hipMemcpyDefault: the destination may be a device buffer or PINNED host memory — one copy straight to the host for
     // the small-batch path)
     XR_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_store(xr_batch* b, int32_t what, const void* src_dev, size_t src_bytes, void* stream) {
+    if (!b || !src_dev) return fail(XR_ERR_INVALID, "xr_batch_store: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_store: load regions first");
+    const size_t B = (size_t)b->cfg.n_envs;
+    void* dst = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+    case XR_FETCH_CUM: dst = b->cum.p; bytes = B * 3 * sizeof(int32_t); break;
+    case XR_FETCH_DELTA: dst = b->delta.p; bytes = B * 3 * sizeof(int32_t); break;
+    case XR_FETCH_REWARD: dst = b->reward.p; bytes = B * sizeof(double); break;
+    case XR_FETCH_DONE: dst = b->done.p; bytes = B; break;
+    case XR_FETCH_NLEGAL: dst = b->nlegal.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_STATUS: dst = b->status.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_LEGAL: dst = b->legal.p; bytes = B * b->legal_words * sizeof(uint64_t); break;
+    case XR_FETCH_PATH_LEN: dst = b->path_len.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_OWNER: dst = b->owner.p; bytes = B * b->n_max * sizeof(int16_t); break;
+    case XR_FETCH_HASH: dst = b->hash.p; bytes = B * sizeof(uint64_t); break;
+    case XR_FETCH_REGION: dst = b->env_region.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_REPLAY: dst = b->env_replay.p; bytes = B * sizeof(int32_t); break;
+    case XR_FETCH_ENV_STEPS: dst = b->env_steps.p; bytes = B * sizeof(int64_t); break;
+    case XR_FETCH_RECORD: dst = b->records.p; bytes = B * sizeof(XrStepRecord); break;
+    default: return fail(XR_ERR_INVALID, "xr_batch_store: selector %d is not part of the env state", what);
+    }
+    if (src_bytes != bytes)
+        return fail(XR_ERR_RANGE, "xr_batch_store(%d): source holds %zu bytes, the array has %zu", what, src_bytes, bytes);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    b->obs_valid_ptr = nullptr;                       // whatever observation a caller holds no longer describes the batch
+    XR_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 

@@ -12,13 +12,13 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from . import spaces as xr_spaces
+
 try:                                    # gymnasium is not installed in the build image
     import gymnasium as gym
-    from gymnasium import spaces
     _HAVE_GYM = True
 except Exception:                       # pragma: no cover - exercised when gymnasium is absent
     gym = None
-    spaces = None
     _HAVE_GYM = False
 
 
@@ -38,32 +38,50 @@ class XRouteEnv(EnvBase):
     """reset(seed, options) -> (obs, info);  step(action) -> (obs, reward, terminated, truncated, info).
 
     * action: 1-based net id, must be in info["legal_actions"] (the reference's netSet);
-    * obs: fp32 [2+7K, Z, Y, X] in the reference layout (K shrinks as nets are routed); with
-      pad_channels=True it is zero-padded to the episode's initial channel count so that
-      `observation_space` is a fixed Box;
+    * obs: fp32 [2+7K, Z, Y, X] in the reference layout (K shrinks as nets are routed; `observation_space` is the Box of the
+      current shape); with pad_channels=True it is zero-padded to the episode's initial channel count; with fixed_shape=True
+      it is {"grid": [2+7*Kmax, Z, Y, X] (zero-padded), "legal_mask": [Kmax]} and the spaces are the fixed
+      Dict{grid: Box, legal_mask: MultiBinary(Kmax)} / Discrete(Kmax, start=1) of envs/spaces.py, defined at construction;
     * reward = -(500*d_violation + 4*d_via + 0.5*d_wirelength)  (baseline/DQN/train_DQN.py:98-99).
     """
 
     def __init__(self, regions: Sequence, device="cuda:0", pad_channels: bool = False, max_route_count: int = 10,
-                 **router_kw):
+                 fixed_shape: bool = False, **router_kw):
         from ..game import Game
-        self.game = Game(regions=list(regions), device=device, max_route_count=max_route_count, **router_kw)
+        regions = list(regions)
+        self.game = Game(regions=regions, device=device, max_route_count=max_route_count, **router_kw)
         self.pad_channels = pad_channels
+        self.fixed_shape = fixed_shape
         self._c0 = None
-        self.observation_space = None
+        self.kmax = max(max(int(r.n_nets) for r in regions), 1)
+        self.observation_space = None            # per-episode form: a Box of the current tensor's shape, set by reset()
         self.action_space = None
+        if fixed_shape:
+            # Dict{grid: Box[Cmax, Z, Y, X], legal_mask: MultiBinary(Kmax)} — defined before the first reset (spaces.py)
+            dims = set(tuple(int(v) for v in r.dims) for r in regions)
+            if len(dims) != 1:
+                raise ValueError("fixed_shape=True needs regions of one size (the grid Box has one shape); use the per-episode form")
+            self.dims = dims.pop()
+            self.observation_space, self.action_space = xr_spaces.fixed_spaces(self.dims, self.kmax)
 
     def _spaces(self, obs):
-        if not _HAVE_GYM:
+        if self.fixed_shape:
             return
         kmax = max(self.game.action_space) if self.game.action_space else 1
-        self.observation_space = spaces.Box(low=0.0, high=float(kmax), shape=tuple(obs.shape), dtype=np.float32)
-        self.action_space = spaces.Discrete(kmax, start=1)
+        self.observation_space, self.action_space = xr_spaces.episode_spaces(obs.shape, kmax)
 
     def _fmt(self, obs):
+        import torch
         obs = obs[0]
+        if self.fixed_shape:
+            cmax = 2 + 7 * self.kmax
+            grid = torch.zeros((cmax,) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
+            grid[:obs.shape[0]] = obs
+            mask = np.zeros(self.kmax, np.int8)
+            for n in self.game.legal_action_set:
+                mask[n - 1] = 1
+            return {"grid": grid, "legal_mask": mask}
         if self.pad_channels and obs.shape[0] < self._c0:
-            import torch
             pad = torch.zeros((self._c0 - obs.shape[0],) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
             obs = torch.cat([obs, pad], dim=0)
         return obs

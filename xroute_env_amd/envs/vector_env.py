@@ -31,6 +31,23 @@ class XRouteVectorEnv:
         self.done = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
         self.legal = torch.empty((self.n_envs, self.batch.legal_words), dtype=torch.int64, device=self.device)
         self.region = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        # fixed-shape spaces (envs/spaces.py): grid rows are the device buffer's own flat rows [B, stride >= (2+7*Kmax)*N]
+        from . import spaces as xr_spaces
+        self.kmax = max(self.batch.k_max, 1)
+        dims = set(tuple(int(v) for v in r.dims) for r in self.batch.regions)
+        self.single_observation_space = self.single_action_space = self.observation_space = self.action_space = None
+        if len(dims) == 1:
+            d = dims.pop()
+            self.single_observation_space, self.single_action_space = xr_spaces.fixed_spaces(d, self.kmax)
+            self.observation_space, _ = xr_spaces.fixed_spaces(d, self.kmax, batch=self.n_envs)
+            self.action_space = self.single_action_space
+
+    def legal_mask(self) -> torch.Tensor:
+        """uint8 [B, Kmax] (the `legal_mask` of the Dict space): bit n-1 of an env's row <=> net n is in its netSet; a device op on
+        the bitmasks of the last step / reset."""
+        bits = torch.arange(64, device=self.device, dtype=torch.int64)
+        m = ((self.legal.unsqueeze(-1) >> bits) & 1).reshape(self.n_envs, -1)
+        return m[:, :self.kmax].to(torch.uint8)
 
     def _collect(self, observe: bool):
         b = self.batch
