@@ -126,17 +126,23 @@ __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int 
     return true;
 }
 
-// Game.step bookkeeping (reference baseline/baseline_utils.py:412, :426-438) + reward, by thread 0
+// Game.step bookkeeping (reference baseline/baseline_utils.py:412, :426-438) + reward, by one thread.  The state it needs is
+// loaded up front (one round trip), everything after that is a store — the packed record is written from registers, not read
+// back from the arrays just written (that second round trip was 2 % of a route).
 __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int e, const int a, int d_vio, int d_wl, int d_via,
                                                  int plen, int status, int nrounds, uint64_t h, int ntouched = 0) {
     if (plen > b.path_cap) status |= XR_ENV_PATH_TRUNC;
-    b.cum[3 * e + 0] += d_vio; b.cum[3 * e + 1] += d_wl; b.cum[3 * e + 2] += d_via;
-    b.delta[3 * e + 0] = d_vio; b.delta[3 * e + 1] = d_wl; b.delta[3 * e + 2] = d_via;
+    uint64_t* lw = b.legal + (int64_t)e * b.legal_words + ((a - 1) >> 6);
+    const int c0 = b.cum[3 * e + 0], c1 = b.cum[3 * e + 1], c2 = b.cum[3 * e + 2];
+    const int nl = b.nlegal[e] - 1;
+    const uint64_t lword = *lw;
+    const int64_t steps = b.env_steps[e] + 1;
     // reward = -1 * (violation*500 + via*4 + wirelength*0.5)   (train_DQN.py:98-99), in double
     const double s = b.w_violation * (double)d_vio + b.w_via * (double)d_via + b.w_wirelength * (double)d_wl;
+    b.cum[3 * e + 0] = c0 + d_vio; b.cum[3 * e + 1] = c1 + d_wl; b.cum[3 * e + 2] = c2 + d_via;
+    b.delta[3 * e + 0] = d_vio; b.delta[3 * e + 1] = d_wl; b.delta[3 * e + 2] = d_via;
     b.reward[e] = -1.0 * s;
-    b.legal[(int64_t)e * b.legal_words + ((a - 1) >> 6)] &= ~(1ULL << ((a - 1) & 63));
-    const int nl = b.nlegal[e] - 1;
+    *lw = lword & ~(1ULL << ((a - 1) & 63));
     b.nlegal[e] = nl;
     b.done[e] = (nl == 0);
     b.status[e] = status;
@@ -147,9 +153,17 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
     fnv_mix(h, (uint32_t)d_vio); fnv_mix(h, (uint32_t)d_wl); fnv_mix(h, (uint32_t)d_via);
     fnv_mix(h, (uint32_t)plen);
     b.hash[e] = h;
-    b.env_steps[e] += 1;
+    b.env_steps[e] = steps;
     atomicAdd(b.total_steps, 1ULL);
-    xr_publish_record(b, e);
+    XrStepRecord* r = b.records + e;              // (= xr_publish_record, from registers)
+    r->reward = -1.0 * s;
+    r->delta[0] = d_vio; r->delta[1] = d_wl; r->delta[2] = d_via;
+    r->cum[0] = c0 + d_vio; r->cum[1] = c1 + d_wl; r->cum[2] = c2 + d_via;
+    r->nlegal = nl;
+    r->env_steps = (int32_t)steps;
+    r->path_len = plen;
+    r->done = (nl == 0); r->pad = 0;
+    r->status = (uint16_t)status;
 }
 
 
