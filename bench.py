@@ -92,7 +92,7 @@ def parse():
 def source_sha():
     """Identity of the kernels being measured (profiles/pmc_traffic.json is only quoted for the same build)."""
     h = hashlib.sha256()
-    for f in ("xr_kernels.hip", "xr_dial.h", "xr_device.h", "xr_batch.cpp"):
+    for f in ("xr_kernels.hip", "xr_dial.h", "xr_dial3.h", "xr_device.h", "xr_batch.cpp"):
         with open(os.path.join(ROOT, "xroute_env_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -928,6 +928,20 @@ def config5_leg(args, c5_regions, dev):
                        "router's algorithmic bytes); `bytes_8d_full_sweep_formula` = what SURVEY §8(d)'s full-sweep form (4·N + 9·N·S + 10·L, "
                        "S = rounds) would move for the same routes; env_steps_per_s is the figure of merit")
     ent["bytes_8d_full_sweep_formula"] = formula_8d
+    # the roofline that bounds this kernel: L2 atomics.  Ceilings from tools/micro/atomic_rate.hip on this pool; the per-launch
+    # atomic count from the TCC counters of a rocprofv3 --pmc pass — quoted only for the same build and batch size
+    ent["l2_atomic_roofline"] = {"bound": "l2-atomic", "peak": 27.0, "peak_hbm_resident": 18.0, "unit": "G atomics/s", "achieved": None, "frac": None,
+                                 "dependent_atomic_latency_ns": [309, 436],
+                                 "note": "peak: sustained agent-scope returning atomics on random words, footprint <= 256 MiB (4 GiB: 18 G/s); a route is a "
+                                         "chain of DEPENDENT atomics (309-436 ns each), so the launch is as long as its longest chain, not atomics / peak"}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "config5_atomics.json")))
+        if pj.get("source_sha") == source_sha() and pj.get("envs") == Bc and pj.get("tcc_atomic_per_launch"):
+            ach = pj["tcc_atomic_per_launch"] / (ms * 1e-3) / 1e9
+            ent["l2_atomic_roofline"].update(achieved=round(ach, 3), frac=round(ach / 27.0, 4), atomics_per_launch=pj["tcc_atomic_per_launch"],
+                                             l2_requests_per_launch=pj.get("tcc_req_per_launch"))
+    except Exception:
+        pass
     ent["mean_rounds"] = sweeps / (n_t * Bc)
     ent["mean_path_nodes"] = plen / (n_t * Bc)
     ent["mean_touched_nodes"] = touched / (n_t * Bc)
