@@ -681,7 +681,9 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.nlegal = b->nlegal.p; d.cum = b->cum.p; d.delta = b->delta.p; d.reward = b->reward.p; d.done = b->done.p;
     d.status = b->status.p; d.path = b->path.p; d.path_len = b->path_len.p; d.hash = b->hash.p;
     d.env_steps = b->env_steps.p; d.total_steps = b->total_steps.p; d.sweeps = b->sweeps.p; d.touched = b->touched.p; d.records = b->records.p;
-    d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
+    // (round 3's LDS form, same-box A/B profiles/r03_l_ab_bucket_width.txt: 12 against 8 — route-only 512 / 4096 envs 0.211 / 0.381 ->
+    //  0.203 / 0.372 ms, 512-env step 0.315 -> 0.306 ms; 16 the same, 24 slower; round 2's form and the HBM-scratch form keep 8)
+    d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : ((b->kzch == -3 || b->kzch == -4) ? 12 : 8);
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.round_cap = b->cfg.debug_round_cap;
     d.guide_cost = b->cfg.guide_cost; d.guide_margin = b->cfg.guide_margin; d.maze_end_iter = b->cfg.maze_end_iter;

@@ -97,7 +97,10 @@ class XRouteEnv(EnvBase):
         from ..game import reward_from_deltas
         obs, done, dv, dw, dvia = self.game.step(int(action))
         info = {"legal_actions": sorted(self.game.legal_action_set), "violation": dv, "wirelength": dw, "via": dvia}
-        return self._fmt(obs), reward_from_deltas(dv, dw, dvia), bool(done), False, info
+        out = self._fmt(obs)
+        if not self.fixed_shape and not self.pad_channels:
+            self._spaces(out)         # the reference tensor loses 7 channels per routed net: the per-episode Box follows its shape
+        return out, reward_from_deltas(dv, dw, dvia), bool(done), False, info
 
 
 class OrderingTrainingEnv(XRouteEnv):
