@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -258,6 +259,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<int32_t> hinfo;          // per (region, net): static facts for xr_dial3.h (XrBatchDev::net_info)
     std::vector<uint8_t> hap_flags;      // per access point: bit 0 = its pin sits in a closed pocket
     int64_t edge_max = b->cfg.via_cost;  // longest edge of any region graph (distance range check of xr_dial3.h)
+    std::map<uint64_t, uint64_t> magic_cache;   // (divisor, limit) -> multiplier << 8 | shift (0xFF: none)
+    bool div24_all = true;               // every region has its exact 24-bit division constants
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
@@ -292,6 +295,28 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             R.magic_z = zz >= 2 ? (uint32_t)((1ULL << 32) / zz) : 0xFFFFFFFFu;
             const uint32_t mwv = (uint32_t)((n64 + 31) / 32);
             R.magic_mw = mwv >= 2 ? (uint32_t)((1ULL << 32) / mwv) : 0xFFFFFFFFu;
+            // exact 24-bit magics (largest shift whose multiplier and products fit, then checked for every n below `lim`)
+            auto magic24 = [&](uint32_t dv, uint32_t lim, uint32_t& M, uint32_t& S) -> bool {
+                const uint64_t key = ((uint64_t)dv << 32) | lim;
+                auto it = magic_cache.find(key);
+                if (it != magic_cache.end()) { M = (uint32_t)(it->second >> 8); S = (uint32_t)(it->second & 0xFF); return S != 0xFF; }
+                bool found = false;
+                if (lim <= (1u << 24))
+                    for (int sh = 31; sh >= 0 && !found; sh--) {
+                        const uint64_t m = (((uint64_t)1 << sh) + dv - 1) / dv;
+                        if (m >= (1u << 24) || (uint64_t)(lim > 0 ? lim - 1 : 0) * m >= ((uint64_t)1 << 32)) continue;
+                        bool ok = true;
+                        for (uint32_t nn = 0; nn < lim && ok; nn++) ok = (uint32_t)(((uint64_t)nn * m) >> sh) == nn / dv;
+                        if (ok) { M = (uint32_t)m; S = (uint32_t)sh; found = true; }
+                    }
+                magic_cache[key] = found ? (((uint64_t)M << 8) | S) : 0xFF;
+                return found;
+            };
+            uint32_t s_yz = 0, s_z = 0, s_mw = 0;
+            const bool okd = n64 < 65536 && magic24(yz, (uint32_t)n64, R.m24_yz, s_yz) && magic24(zz, yz, R.m24_z, s_z) &&
+                             magic24(std::max(1u, mwv), (uint32_t)n64, R.m24_mw, s_mw);
+            R.s24 = s_yz | (s_z << 8) | (s_mw << 16) | ((okd ? 1u : 0u) << 24);
+            if (!okd) div24_all = false;
         }
         R.xs_off = (int32_t)hcoords.size();
         hcoords.insert(hcoords.end(), d.xs_host, d.xs_host + d.dim_x);
@@ -530,7 +555,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             const size_t d3_lds = XR3_LDS_BYTES(b->n_max, x_max, y_max);
             const int64_t pen_max = ((int64_t)b->cfg.drc_cost * b->cfg.drc_unit) << (b->cfg.maze_end_iter - 1);
             const bool range_ok = ((int64_t)b->n_max + 1) * (edge_max + pen_max + b->cfg.guide_cost) < XR3_DIST_LIMIT;
-            if (b->kzch == -1 && b->lds_dist && b->cfg.router != XR_ROUTER_DIAL_R2 && range_ok && b->n_max < 65536 &&
+            if (b->kzch == -1 && b->lds_dist && b->cfg.router != XR_ROUTER_DIAL_R2 && range_ok && b->n_max < 65536 && div24_all &&
                 d3_lds + kLdsStatic <= kLdsLimit) {
                 b->kzch = -3;
                 b->route_lds = d3_lds;

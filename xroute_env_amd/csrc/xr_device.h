@@ -45,6 +45,11 @@ struct XrRegionDev {
     uint32_t magic_yz;     // floor(2^32 / (Y*Z)) and floor(2^32 / Z) (0xFFFFFFFF for a divisor of 1): flat index -> (x, y, z)
     uint32_t magic_z;
     uint32_t magic_mw;     // floor(2^32 / mw), mw = ceil(N / 32): node f <-> (word f % mw, bit f / mw) of the node bitmasks
+    // exact 24-bit magic division for the round-3 LDS router (xr_dial3.h): n / d == (n * m24) >> s24 with full-rate 24-bit multiplies,
+    // verified at load for every n the kernel can ask for (f < N for Y*Z and mw, r < Y*Z for Z); div24_ok = 0: not found (the host then
+    // keeps round 2's form)
+    uint32_t m24_yz, m24_z, m24_mw;
+    uint32_t s24;          // shift of yz | z << 8 | mw << 16 | div24_ok << 24
 };
 
 // Packed per-env result of the last step / reset (XR_FETCH_RECORD; layout = xr_step_record of include/xroute_hip.h)

@@ -47,6 +47,13 @@ __device__ __forceinline__ uint32_t xr3_wave_min(uint32_t v) {
 __device__ __forceinline__ uint32_t xr3_wave_min(uint32_t v) { return xr_wave_min_u32(v); }
 #endif
 
+// n / d and n % d by the region's exact 24-bit magic (XrRegionDev::m24_*: verified at load for every n asked here): two full-rate
+// 24-bit multiplies instead of a 32-bit mul_hi / mul_lo pair plus fix-up
+__device__ __forceinline__ void xr3_divmod(uint32_t n, uint32_t d, uint32_t m24, uint32_t sh, uint32_t& q, uint32_t& r) {
+    q = (uint32_t)__umul24(n, m24) >> sh;          // (the intrinsic's return type is signed here: shift the unsigned value)
+    r = n - (uint32_t)__umul24(q, d);
+}
+
 __device__ __forceinline__ int xr3_mbcnt(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -74,7 +81,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     const int YZ = Y * Z;
     const uint32_t ldir = R.ldir_mask;
     const int mw = (N + 31) >> 5;
-    const uint32_t umw = (uint32_t)mw, magic_mw = R.magic_mw;
+    const uint32_t umw = (uint32_t)mw;
     const uint32_t uYZ = (uint32_t)YZ, uZ = (uint32_t)Z;
     const int round_cap = b.round_cap > 0 ? b.round_cap : 1024 + N;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
@@ -200,16 +207,19 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     // predecessor direction stored in the NEIGHBOUR's word (pointing back at the quad's node), E,S,W,N,U,D = 0..5
     const uint32_t pdH = (planar ? (sgn > 0 ? 2u : 0u) : (sgn > 0 ? 5u : 4u)) << 2, pdV = (planar ? (sgn > 0 ? 1u : 3u) : (sgn > 0 ? 5u : 4u)) << 2;
 
+    const uint32_t sh_yz = R.s24 & 31u, sh_z = (R.s24 >> 8) & 31u, sh_mw = (R.s24 >> 16) & 31u;
     auto node_xyz = [&](uint32_t f, int& x, int& y, int& z) __attribute__((always_inline)) {
         uint32_t ux, ur, uy, uz;
-        xr_divmod(f, uYZ, R.magic_yz, ux, ur);
-        xr_divmod(ur, uZ, R.magic_z, uy, uz);
+        xr3_divmod(f, uYZ, R.m24_yz, sh_yz, ux, ur);
+        xr3_divmod(ur, uZ, R.m24_z, sh_z, uy, uz);
         x = (int)ux; y = (int)uy; z = (int)uz;
     };
+    // node f <-> (word f % mw, bit f / mw) of the node bitmasks
+    auto mask_pos = [&](uint32_t f, uint32_t& q, uint32_t& r) __attribute__((always_inline)) { xr3_divmod(f, umw, R.m24_mw, sh_mw, q, r); };
     // a node becomes a source: distance 0, open
     auto make_source = [&](uint32_t f) __attribute__((always_inline)) {
         uint32_t q, r;
-        xr_divmod(f, umw, magic_mw, q, r);
+        mask_pos(f, q, r);
         field[f] &= 3u;
         atomicOr(&s_open[r], 1u << q);
         s_wmin[r] = 0u;                       // (racing plain stores of the same value)
@@ -349,7 +359,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
                     for (int nhop = 0;; nhop++) {
                         if (nhop >= round_cap) {          // (every hop lowers a field word: finite anyway; the cap is the hang guard)
-                            if (gf >= 0 && dir == 0) { uint32_t oq, orr; xr_divmod((uint32_t)gf, umw, magic_mw, oq, orr); atomicOr(&s_open[orr], 1u << oq); s_abort = 1; }
+                            if (gf >= 0 && dir == 0) { uint32_t oq, orr; mask_pos((uint32_t)gf, oq, orr); atomicOr(&s_open[orr], 1u << oq); s_abort = 1; }
                             break;
                         }
                         const unsigned long long idle_g = __ballot(gf < 0) & 0x1111111111111111ULL;       // one bit per idle quad
@@ -391,18 +401,19 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const int win = c4 ? __ffs((int)c4) - 1 : -1;                          // the chain goes on with the first lowered direction
                         if (improved && dir != win) {                                          // the others become open
                             uint32_t oq, orr;
-                            xr_divmod((uint32_t)nf, umw, magic_mw, oq, orr);
+                            mask_pos((uint32_t)nf, oq, orr);
                             atomicOr(&s_open[orr], 1u << oq);
                             atomicMin(&s_wmin[orr], key);
                             lmin = key < lmin ? key : lmin;
                         }
                         if (act) {
-                            if (r4 && dir == 0) { uint32_t oq, orr; xr_divmod((uint32_t)gf, umw, magic_mw, oq, orr); atomicOr(&s_defer[orr], 1u << oq); }
+                            if (r4 && dir == 0) { uint32_t oq, orr; mask_pos((uint32_t)gf, oq, orr); atomicOr(&s_defer[orr], 1u << oq); }
                             if (win >= 0) {                                 // every lane of the quad moves to the winner's node
                                 const int sw_ = (win & 1) ? -1 : 1;
-                                const int wx = (win < 2 && !vert) ? sw_ : 0, wy = (win < 2 && vert) ? sw_ : 0, wz = win < 2 ? 0 : sw_;
-                                gf += wx * YZ + wy * Z + wz;
-                                gx += wx; gy += wy; gz += wz;
+                                const bool wpl = win < 2;
+                                const int stp = wpl ? (vert ? Z : YZ) : 1;             // (no multiplies: the step is one of three constants)
+                                gf += sw_ > 0 ? stp : -stp;
+                                gx += (wpl && !vert) ? sw_ : 0; gy += (wpl && vert) ? sw_ : 0; gz += wpl ? 0 : sw_;
                             } else gf = -1;
                         }
                     }
