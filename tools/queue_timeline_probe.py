@@ -8,7 +8,7 @@ from xroute_env_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libxroute_hip_timeline.so")
 from xroute_env_amd.batch import RegionBatch
 from xroute_env_amd.regions import config_regions
-B = 4096
+B = int(os.environ.get("XR_TL_ENVS", "4096"))
 pm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 pack = len(sys.argv) > 2 and sys.argv[2] == "pack"
 if pack:

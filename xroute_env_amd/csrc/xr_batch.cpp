@@ -870,14 +870,6 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         b->last_obs_inplace = d.obs_incremental;
         b->obs_valid_ptr = nullptr;                 // (set again below once every launch of this call has been enqueued without error)
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
-        XR_HIP(xr_launch_plan(&d, actions_dev, st));
-        // (route tasks in slot order: longest-first measured SLOWER in the queue forms, full rewrite 1.72 -> 1.83 ms, in-place
-        //  1.06 -> 1.09 ms — the launch is bound by its write stream, and long routes up front delay the first units)
-        // which router runs the route tasks of this launch (auto: sweeps for the full rewrite of a large batch, see load)
-        const bool use_sweep = b->sweep_full && !d.obs_incremental;
-        b->last_obs_sweeps = use_sweep ? 1 : 0;
-        const int kz = use_sweep ? b->zch : b->kzch;
-        const size_t klds = use_sweep ? b->sweep_lds : b->route_lds;
         if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel (both variants)
             hipDeviceProp_t prop;
             XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));
@@ -891,6 +883,28 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
                 b->queue_blocks_sweep = std::max(1, per_cu) * b->n_cus;
             }
         }
+        XR_HIP(xr_launch_plan(&d, actions_dev, st));
+        // Route tasks: slot order for large batches (longest-first measured SLOWER there, full rewrite 1.72 -> 1.83 ms, in-place
+        // 1.06 -> 1.09 ms — the launch is bound by its write stream, and long routes up front delay the first units).  A batch of at
+        // most ~2 routes per resident workgroup is different: its launch ends with the longest route, and a workgroup that starts
+        // with units takes its route ~125 us late (tools/queue_timeline_probe.py, 1024 envs: the last route ends at 100 % of the
+        // launch) — there the tasks are handed out longest predicted route first (xr_route_order_kernel, ~10 us).
+        // Measured (profiles/r03_o_ab_queue_task_order.txt, same box, ms per step, slot order -> longest first): synthetic regions 512 /
+        // 1024 / 2048 / 4096 envs 0.324 / 0.518 / 0.939 / 1.749 -> 0.318 / 0.513 / 0.945 / 1.849; the regions extracted from ispd18_test1
+        // (heavier, more varied routes: their step is bound by routing) 1024 / 2048 / 4096 / 8192 slots 1.097 / 1.391 / 2.071 / 3.556 ->
+        // 0.931 / 1.023 / 1.951 / 3.829.  Hence: up to 2 routes per resident workgroup, 4 for regions with unaligned planes.
+        const int lpt_limit = (b->all_n_mult4 ? 2 : 4) * b->queue_blocks;
+        const bool lpt_tasks = b->cfg.launch_order == 2 ||
+                               (b->cfg.launch_order == 0 && b->queue_blocks > 0 && b->cfg.n_envs <= lpt_limit && b->cfg.n_envs > 64);
+        if (lpt_tasks) {
+            XR_HIP(xr_launch_route_order(&d, actions_dev, b->route_order.p, st));
+            d.route_order = b->route_order.p;
+        }
+        // which router runs the route tasks of this launch (auto: sweeps for the full rewrite of a large batch, see load)
+        const bool use_sweep = b->sweep_full && !d.obs_incremental;
+        b->last_obs_sweeps = use_sweep ? 1 : 0;
+        const int kz = use_sweep ? b->zch : b->kzch;
+        const size_t klds = use_sweep ? b->sweep_lds : b->route_lds;
         const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : (use_sweep ? b->queue_blocks_sweep : b->queue_blocks);
         // helper writers (aligned planes only): LDS-free workgroups on the internal stream draining the same unit queue;
         // forked after the plan, joined before the call returns the stream (events, no host wait)

@@ -1528,7 +1528,10 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
 #endif
     while (routes_left || units_left) {
         if (routes_left && !skip_route) {
-            if (tid == 0) s_task = (int)atomicAdd(&b.queue[0], 1u);
+            if (tid == 0) {
+                const int t = (int)atomicAdd(&b.queue[0], 1u);
+                s_task = (t < B && b.route_order) ? b.route_order[t] : t;      // (small batches: longest predicted route first)
+            }
             __syncthreads();
             const int e = s_task;
             __syncthreads();
