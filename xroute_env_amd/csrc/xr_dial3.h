@@ -273,7 +273,12 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             const uint32_t m = s_min[cur], best = s_bst[cur];
             if (m == XR_DIAL_INF || m > best) break;                 // uniform
             if (nsr >= round_cap || s_abort) { aborted = true; break; }   // uniform (s_abort: written before the last barrier)
+#ifdef XR3_GROW_AFTER        // A/B only (profiles/r03_q_ab_growing_bucket_width.txt: wider late buckets cost 3-18 % --
+                             // the extra re-expansions outweigh the rounds saved); off in the shipped build
+            const uint32_t hi = m + (nsr >= XR3_GROW_AFTER ? delta * XR3_GROW_BY : delta);
+#else
             const uint32_t hi = m + delta;
+#endif
             uint32_t lmin = XR_DIAL_INF;
             if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; }
             // bound for the next round: smallest tentative distance of an unconnected target
