@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 4
+#define XR_ABI_VERSION 5
 
 /* status codes */
 #define XR_OK            0
@@ -322,6 +322,19 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
  * here the whole batch state is a handful of device arrays, so a dump (fetch) / restore (store) pair is the env checkpoint —
  * a batch restored into a twin created with the same config and regions continues bit-identically (hash chains included). */
 int32_t xr_batch_store(xr_batch* b, int32_t what, const void* src_dev, size_t src_bytes, void* stream);
+
+/* ---- XR-Maze v2: global-route guides (optional) ---------------------------------------------- */
+/* The reference's simulator runs with `-follow_guide 1` (ispd/ispd18_test1/run-net-ordering-training.tcl:3) on the guide file
+ * it ships (ispd/ispd18_test1/ispd18_test1.input.guide: per net, rectangles per metal layer).  With xr_config.guide_cost > 0 a
+ * net's guide is, by default, the bounding box of its access points; this call replaces it, per (region, net), by up to
+ * XR_GUIDE_MAX_BOXES boxes (x0, y0, x1, y1, z0, z1: track / layer indices of the region's grid, inclusive — the guide
+ * rectangles clipped to the region, xroute_env_amd/lefdef.py): a node is inside the guide when it lies in any box inflated by
+ * guide_margin tracks in x and y.  box_off_host[r] = int32[n_nets(r) + 1] offsets (0-based nets) into boxes_host[r] =
+ * int16[boxes][6]; box_off_host[r] == NULL: region r keeps the default guides; box_off_host == NULL: drop every guide.
+ * A net with no box keeps the default guide.  Call after xr_batch_load_regions (a reload drops the guides); host pointers,
+ * copied before the call returns.  Build-defined like the rest of XR-Maze (parity unpinned against the reference's router). */
+#define XR_GUIDE_MAX_BOXES 8
+int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, const int16_t* const* boxes_host, void* stream);
 
 /* ---- stateless observation build --------------------------------------------------------- */
 /* Replaces build_3Dgrid(data, routed_nets, bool_inference) for a caller that already holds the

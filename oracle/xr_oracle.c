@@ -140,7 +140,8 @@ struct xro_env {
     /* XR-Maze v2 knobs, all neutral by default: guide_cost 0, maze_end_iter 1 */
     int guide_cost, guide_margin, maze_end_iter;
     int pen_now;           /* penalty of the current attempt: pen_cost << attempt */
-    int gx0, gx1, gy0, gy1; /* guide box of the net being routed (track indices) */
+    int n_gb; int gb[XRO_GUIDE_MAX_BOXES][6]; /* guide of the net being routed: boxes x0,x1,y0,y1,z0,z1 (track / layer indices, margin applied) */
+    int32_t* guide_off; int16_t* guide_box;   /* optional per-net guide boxes (xro_env_set_guides): CSR over nets, 6 int16 per box */
     /* static derived */
     int16_t* node_net;     /* Net of handle_messange: -1 / 0 / net id (1-based) */
     int* net_off;          /* [n_nets+2] CSR into ap_node/ap_pin, by 1-based net id */
@@ -221,7 +222,7 @@ void xro_env_destroy(xro_env* e) {
     if (!e) return;
     free(e->xs); free(e->ys); free(e->ldir); free(e->rec0); free(e->node_net); free(e->owner);
     free(e->legal); free(e->dist); free(e->comp); free(e->heap_node); free(e->heap_key);
-    free(e->net_off); free(e->ap_node); free(e->ap_pin);
+    free(e->net_off); free(e->ap_node); free(e->ap_pin); free(e->guide_off); free(e->guide_box);
     free(e);
 }
 
@@ -306,8 +307,29 @@ static int node_pen(const xro_env* e, int v, int net) {
  * not forbidden). */
 static uint32_t node_guide(const xro_env* e, int v) {
     if (e->guide_cost == 0) return 0u;
-    int y = (v / e->Z) % e->Y, x = v / (e->Y * e->Z);
-    return (x < e->gx0 || x > e->gx1 || y < e->gy0 || y > e->gy1) ? (uint32_t)e->guide_cost : 0u;
+    int z = v % e->Z, y = (v / e->Z) % e->Y, x = v / (e->Y * e->Z);
+    for (int i = 0; i < e->n_gb; i++) {
+        const int* g = e->gb[i];
+        if (x >= g[0] && x <= g[1] && y >= g[2] && y <= g[3] && z >= g[4] && z <= g[5]) return 0u;
+    }
+    return (uint32_t)e->guide_cost;
+}
+
+/* Optional: the global-route guide of every net as boxes (x0, y0, x1, y1, z0, z1; track / layer indices, inclusive), at most
+ * XRO_GUIDE_MAX_BOXES per net: what `-follow_guide 1` reads from ispd18_test1.input.guide, clipped to the region
+ * (xroute_env_amd/lefdef.py).  A node is inside the guide when it is inside any box inflated by guide_margin in x and y.
+ * A net without boxes keeps the default guide (bounding box of its access points, every layer).  Returns 0, or -1 when a
+ * net has too many boxes. */
+int xro_env_set_guides(xro_env* e, const int32_t* box_off, const int16_t* boxes) {
+    free(e->guide_off); free(e->guide_box); e->guide_off = NULL; e->guide_box = NULL;
+    if (!box_off) return 0;
+    for (int n = 0; n < e->n_nets; n++) if (box_off[n + 1] - box_off[n] > XRO_GUIDE_MAX_BOXES || box_off[n + 1] < box_off[n]) return -1;
+    const int nb = box_off[e->n_nets];
+    e->guide_off = (int32_t*)malloc(sizeof(int32_t) * (e->n_nets + 1));
+    e->guide_box = (int16_t*)malloc(sizeof(int16_t) * 6 * (nb > 0 ? nb : 1));
+    memcpy(e->guide_off, box_off, sizeof(int32_t) * (e->n_nets + 1));
+    if (nb > 0) memcpy(e->guide_box, boxes, sizeof(int16_t) * 6 * nb);
+    return 0;
 }
 
 void xro_env_set_v2(xro_env* e, int guide_cost, int guide_margin, int maze_end_iter) {
@@ -404,14 +426,28 @@ int xro_env_step(xro_env* e, int action, int32_t delta[3], int* done, int32_t* p
         for (int j = 0; j < npins; j++) if (pins[j] == p) { seen = 1; break; }
         if (!seen) pins[npins++] = p;
     }
-    /* guide box of the net (v2) */
-    e->gx0 = e->gy0 = 1 << 30; e->gx1 = e->gy1 = -1;
-    for (int i = lo; i < hi; i++) {
-        int f = e->ap_node[i], y = (f / e->Z) % e->Y, x = f / (e->Y * e->Z);
-        if (x < e->gx0) e->gx0 = x; if (x > e->gx1) e->gx1 = x;
-        if (y < e->gy0) e->gy0 = y; if (y > e->gy1) e->gy1 = y;
+    /* guide of the net (v2): its boxes when the region carries them, else the bounding box of its access points on every layer */
+    e->n_gb = 0;
+    if (e->guide_off && e->guide_off[net] > e->guide_off[net - 1]) {
+        for (int i = e->guide_off[net - 1]; i < e->guide_off[net]; i++) {
+            const int16_t* g = e->guide_box + 6 * (size_t)i;
+            int* o = e->gb[e->n_gb++];
+            o[0] = g[0] - e->guide_margin; o[1] = g[2] + e->guide_margin; o[2] = g[1] - e->guide_margin; o[3] = g[3] + e->guide_margin;
+            o[4] = g[4]; o[5] = g[5];
+        }
+    } else {
+        int gx0 = 1 << 30, gy0 = 1 << 30, gx1 = -1, gy1 = -1;
+        for (int i = lo; i < hi; i++) {
+            int f = e->ap_node[i], y = (f / e->Z) % e->Y, x = f / (e->Y * e->Z);
+            if (x < gx0) gx0 = x;
+            if (x > gx1) gx1 = x;
+            if (y < gy0) gy0 = y;
+            if (y > gy1) gy1 = y;
+        }
+        int* o = e->gb[e->n_gb++];
+        o[0] = gx0 - e->guide_margin; o[1] = gx1 + e->guide_margin; o[2] = gy0 - e->guide_margin; o[3] = gy1 + e->guide_margin;
+        o[4] = 0; o[5] = e->Z - 1;
     }
-    e->gx0 -= e->guide_margin; e->gx1 += e->guide_margin; e->gy0 -= e->guide_margin; e->gy1 += e->guide_margin;
     /* XR-Maze v2 rip-up and reroute (`-maze_end_iter`, `-ripup_mode 1`): attempt t routes the whole net with the penalty
      * pen_cost << t; an attempt whose path uses a node held by another net is ripped up (owners restored, nothing
      * recorded) unless it is the last one.  maze_end_iter 1 = XR-Maze v1. */

@@ -41,6 +41,10 @@ xro_env* xro_env_create(int X, int Y, int Z, const int32_t* xs, const int32_t* y
                         const int32_t* metrics0, int via_cost, int drc_cost, int drc_unit);
 /* XR-Maze v2 knobs: guide cost / margin, rip-up-and-reroute attempts; (0, 0, 1) = XR-Maze v1 */
 void xro_env_set_v2(xro_env* e, int guide_cost, int guide_margin, int maze_end_iter);
+/* XR-Maze v2, optional: the nets' global-route guides as boxes (x0, y0, x1, y1, z0, z1: track / layer indices, inclusive), CSR over
+ * the nets (box_off[n_nets + 1], 0-based), at most XRO_GUIDE_MAX_BOXES per net; NULL = none (guide = bbox of the access points) */
+#define XRO_GUIDE_MAX_BOXES 8
+int xro_env_set_guides(xro_env* e, const int32_t* box_off, const int16_t* boxes);
 void xro_env_destroy(xro_env* e);
 void xro_env_reset(xro_env* e);   /* reference Game.reset bookkeeping, baseline_utils.py:466-473 */
 /* reference Game.step bookkeeping (baseline_utils.py:409-438) around the XR-Maze v1 router.

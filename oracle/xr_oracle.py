@@ -40,6 +40,8 @@ def lib():
     L.xro_env_create.restype = vp
     L.xro_env_set_v2.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.xro_env_set_v2.restype = None
+    L.xro_env_set_guides.argtypes = [vp, vp, vp]
+    L.xro_env_set_guides.restype = C.c_int
     L.xro_env_destroy.argtypes = [vp]
     L.xro_env_destroy.restype = None
     L.xro_env_reset.argtypes = [vp]
@@ -119,6 +121,13 @@ class OracleEnv:
             raise MemoryError("xro_env_create failed")
         if guide_cost or maze_end_iter != 1:
             lib().xro_env_set_v2(self.h, int(guide_cost), int(guide_margin), int(maze_end_iter))
+        if getattr(region, "guide_off", None) is not None:
+            off = np.ascontiguousarray(region.guide_off, np.int32)
+            box = np.ascontiguousarray(region.guide_box, np.int16).reshape(-1, 6)
+            if off.size != region.n_nets + 1 or off[-1] != box.shape[0]:
+                raise ValueError("region guides: guide_off must have n_nets + 1 entries and end at the number of boxes")
+            if lib().xro_env_set_guides(self.h, _p(off), _p(box)) != 0:
+                raise ValueError("region guides: more than 8 boxes for one net")
         self.n = lib().xro_env_n_nodes(self.h)
 
     def __del__(self):

@@ -43,6 +43,7 @@ def test_bench_json_contract(extra):
         assert any("in-place" in n for n in names)
         # the REAL ispd18_test1 regions (extracted from the reference's LEF/DEF/guide) with their own oracle replay
         pk = [k for k in d["kernels"] if "design-derived" in k["kernel"]][0]
+        assert any("guide rectangles" in n for n in names)          # ... and XR-Maze v2 on them with the design's own guides
         assert pk["parity"]["hash_chains_equal"] is True and pk["parity"]["cumulative_metrics_equal"] is True and pk["form"]["form"] == 3
         assert "queue form" in d["config"]["workload"]
         for k in d["kernels"]:

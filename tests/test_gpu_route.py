@@ -1,5 +1,7 @@
 """GPU parity: xr_batch_step (XR-Maze v1 on the MI355X) == CPU oracle, bit-exact, on the same seeded
 inputs: routed path node lists, metric deltas, done flags, owner grids, legal sets, hash chains."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -271,6 +273,92 @@ def test_xr_maze_v2_matches_the_oracle(v2, form):
     hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
     assert [int(h) for h in hashes] == [e.hash() for e in envs]
     assert differs > 0
+
+
+def _random_guides(region, seed, empty_every=4):
+    """Guide boxes for a synthetic region: per net 1..8 boxes, each a random window around one of its access points on a layer
+    range; every `empty_every`-th net gets none (default guide)."""
+    from xroute_env_amd.regions import unpack_records
+    rng = np.random.default_rng(seed)
+    X, Y, Z = region.dims
+    ntype, _, nn, _ = unpack_records(region.nodes)
+    off, boxes = [0], []
+    for n in range(region.n_nets):
+        idx = np.nonzero((ntype == ACCESS) & (nn == n))[0]
+        if len(idx) and n % empty_every != empty_every - 1:
+            for _ in range(int(rng.integers(1, 9))):
+                x, y, z = region.unflat(int(rng.choice(idx)))
+                x0, y0 = max(0, int(x) - int(rng.integers(0, 6))), max(0, int(y) - int(rng.integers(0, 8)))
+                x1, y1 = min(X - 1, int(x) + int(rng.integers(0, 6))), min(Y - 1, int(y) + int(rng.integers(0, 8)))
+                z0 = max(0, int(z) - int(rng.integers(0, 3)))
+                boxes.append((x0, y0, x1, y1, z0, min(Z - 1, int(z) + int(rng.integers(0, 3)))))
+        off.append(len(boxes))
+    region.guide_off = np.asarray(off, np.int32)
+    region.guide_box = np.asarray(boxes, np.int16).reshape(-1, 6)
+    return region
+
+
+@pytest.mark.parametrize("form", ["lds", "lds-round2", "scratch", "pack"])
+def test_xr_maze_v2_guide_boxes_match_the_oracle(form):
+    """XR-Maze v2 with per-net guide BOXES (xr_batch_load_guides: what `-follow_guide 1` reads from ispd18_test1.input.guide,
+    clipped to the region by lefdef.RegionExtractor) instead of the default bounding box: GPU == oracle bit for bit in every
+    form of the frontier router, on synthetic regions with random boxes (nets without boxes mixed in) and on regions of the
+    design-derived pack with their real guides — and the boxes really change routes relative to the default guide."""
+    import copy
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    v2 = dict(guide_cost=1000, guide_margin=1, maze_end_iter=3 if form != "lds-round2" else 1)
+    if form == "pack":
+        from xroute_env_amd import lefdef
+        regions = lefdef.load_region_pack(os.path.join(os.path.dirname(__file__), "golden", "ispd18_test1_regions.npz"))[5:200:13]
+        assert all(r.guide_off is not None and r.guide_off[-1] > 0 for r in regions)
+    else:
+        regions = [_random_guides(generate_region(3600 + i), 77 + i) for i in range(16)]
+    plain = [copy.copy(r) for r in regions]
+    for r in plain:
+        r.guide_off = r.guide_box = None
+    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), router=3 if form == "lds-round2" else 0, **v2)
+    envs = [orc.OracleEnv(r, **v2) for r in regions]
+    base = [orc.OracleEnv(r, **v2) for r in plain]
+    batch.reset()
+    differs = 0
+    for _ in range(90):
+        legal = batch.legal_sets()
+        if not any(legal):
+            break
+        acts = [max(s) if s else 0 for s in legal]
+        batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+        rec = batch.records()
+        plen = batch.fetch("path_len").cpu().numpy()
+        path = batch.fetch("path").cpu().numpy()
+        for i, env in enumerate(envs):
+            if not acts[i]:
+                continue
+            ref = env.step(acts[i])
+            ref0 = base[i].step(acts[i])
+            assert rec["delta"][i].tolist() == ref["delta"].tolist(), (i, acts[i], rec["delta"][i], ref["delta"])
+            assert rec["status"][i] == ref["status"] and plen[i] == ref["path_len"]
+            assert path[i, :plen[i]].tolist() == ref["path"].tolist()
+            differs += int(ref["path"].tolist() != ref0["path"].tolist())
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
+    assert [int(h) for h in hashes] == [e.hash() for e in envs]
+    assert differs > 0
+
+
+def test_guide_boxes_are_validated():
+    from xroute_env_amd._lib import XRouteError
+    from xroute_env_amd.batch import RegionBatch
+    reg = generate_region(2, dims=(12, 10, 5), k_range=(2, 3))
+    reg.guide_off = np.array([0] + [9] * reg.n_nets, np.int32)                     # nine boxes for net 1
+    reg.guide_box = np.tile(np.array([0, 0, 3, 3, 0, 1], np.int16), (9, 1))
+    with pytest.raises(XRouteError):
+        RegionBatch([reg], device="cuda:0", guide_cost=500)
+    reg.guide_off = np.array([0] + [1] * reg.n_nets, np.int32)
+    reg.guide_box = np.array([[0, 0, 12, 3, 0, 1]], np.int16)                      # x1 = 12 is outside a 12-track grid
+    with pytest.raises(XRouteError):
+        RegionBatch([reg], device="cuda:0", guide_cost=500)
+    reg.guide_box = np.array([[0, 0, 11, 3, 0, 1]], np.int16)
+    RegionBatch([reg], device="cuda:0", guide_cost=500).close()
 
 
 def test_xr_maze_v2_refused_where_unsupported():

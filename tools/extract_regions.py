@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extract per-GCell regions from a LEF/DEF/guide triple (xroute_env_amd/lefdef.py) into a compact region pack.
 
-    python tools/extract_regions.py --out tests/golden/ispd18_test1_regions.npz --count 256 --stride 17
+    python tools/extract_regions.py --out tests/golden/ispd18_test1_regions.npz --count 256 --stride 16
 
 Default inputs are the reference's ispd18_test1 files (build container only).  The pack is DATA derived from the
 reference's benchmark input files (tracks, placed pin / obstruction shapes, guides), not source."""
@@ -16,7 +16,7 @@ ap.add_argument("--def", dest="deff", default=REF + ".def")
 ap.add_argument("--guide", default=REF + ".guide")
 ap.add_argument("--out", required=True)
 ap.add_argument("--count", type=int, default=256)
-ap.add_argument("--stride", type=int, default=17, help="keep every stride-th non-empty region (spreads over the die)")
+ap.add_argument("--stride", type=int, default=16, help="keep every stride-th non-empty region (spreads over the die)")
 ap.add_argument("--min-nets", type=int, default=2)
 args = ap.parse_args()
 t0 = time.time()

@@ -17,7 +17,7 @@ python3 $R/tools/pmc_parse.py $(ls $OUT/pmcF/*/*counter_collection.csv $OUT/pmcF
         $(ls $OUT/pmcW/*/*counter_collection.csv $OUT/pmcW/*counter_collection.csv 2>/dev/null | head -1) $OUT/pmcF.log > $OUT/pmc_traffic.json 2> $OUT/pmc_parse.err
 head -c 600 $OUT/pmc_traffic.json; echo
 # the pack (driver-line leg) on its own: kernel stats + traffic
-PACK="--region-pack tests/golden/ispd18_test1_regions.npz"
+PACK="--region-pack $R/tests/golden/ispd18_test1_regions.npz"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pack_trace -o t -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs $PACK > $OUT/pack_trace.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pack_pmcF -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --pmc-calibrate $PACK > $OUT/pack_pmcF.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pack_pmcW -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --pmc-calibrate $PACK > $OUT/pack_pmcW.log 2>&1

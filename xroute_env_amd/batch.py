@@ -93,11 +93,32 @@ class RegionBatch:
             for j in range(3):
                 d.metrics0[j] = int(r.metrics0[j])
         _lib.check(self.L.xr_batch_load_regions(self._h, descs, len(self.regions), _stream_ptr(self.device)))
+        self._load_guides()
         sz = [C.c_int32() for _ in range(6)]
         stride = C.c_int64()
         _lib.check(self.L.xr_batch_sizes(self._h, *[C.byref(s) for s in sz], C.byref(stride)))
         (_, self.n_regions, self.n_max, self.k_max, self.legal_words, self.path_cap) = (s.value for s in sz)
         self.obs_env_stride = stride.value
+
+    def _load_guides(self):
+        """XR-Maze v2: regions that carry global-route guide boxes (`Region.guide_off / guide_box`, lefdef.RegionExtractor) hand
+        them to the device (xr_batch_load_guides); the others keep the default guide (bounding box of the net's access points)."""
+        if not any(getattr(r, "guide_off", None) is not None for r in self.regions):
+            return
+        n = len(self.regions)
+        offs, boxes, keep = (C.c_void_p * n)(), (C.c_void_p * n)(), []
+        for i, r in enumerate(self.regions):
+            if getattr(r, "guide_off", None) is None:
+                continue
+            off = np.ascontiguousarray(r.guide_off, np.int32)
+            box = np.ascontiguousarray(r.guide_box, np.int16).reshape(-1, 6)
+            if off.size != r.n_nets + 1 or int(off[-1]) != box.shape[0]:
+                raise ValueError(f"region {i}: guide_off must have n_nets + 1 entries and end at the number of boxes")
+            if box.shape[0] == 0:
+                box = np.zeros((1, 6), np.int16)
+            keep += [off, box]
+            offs[i], boxes[i] = off.ctypes.data, box.ctypes.data
+        _lib.check(self.L.xr_batch_load_guides(self._h, offs, boxes, _stream_ptr(self.device)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -106,6 +107,10 @@ struct xr_batch {
     DevBuf<int32_t> coords, net_csr, ap_node, ap_feat, net_info;
     DevBuf<uint8_t> ap_flags;
     DevBuf<int16_t> ap_pin;
+    DevBuf<int32_t> guide_csr;            // XR-Maze v2, optional (xr_batch_load_guides): boxes of (region, net), indexed like net_csr
+    DevBuf<int16_t> guide_box;
+    std::vector<int32_t> h_net_off, h_n_nets, h_dims;   // per region: R.net_off, n_nets, (X, Y, Z) — what xr_batch_load_guides validates against
+    size_t h_csr_size = 0;
     DevBuf<uint64_t> legal0;
     // envs
     DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps, touched, route_order;
@@ -249,6 +254,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->obs_valid_ptr = nullptr;
     b->n_cus = 0;
     b->route_slots = 0;
+    b->guide_csr.release(); b->guide_box.release();        // guides belong to the regions they were loaded for
     memset(&b->dev, 0, sizeof(b->dev));
 
     std::vector<XrRegionDev> hreg(n_regions);
@@ -727,7 +733,55 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.via_cost = b->cfg.via_cost; d.pen_cost = b->cfg.drc_cost * b->cfg.drc_unit;
     d.max_route_count = b->cfg.max_route_count; d.auto_reset = b->cfg.auto_reset;
     d.w_violation = b->cfg.w_violation; d.w_via = b->cfg.w_via; d.w_wirelength = b->cfg.w_wirelength;
+    b->h_net_off.resize(n_regions); b->h_n_nets.resize(n_regions); b->h_dims.resize(3 * (size_t)n_regions);
+    for (int r = 0; r < n_regions; r++) {
+        b->h_net_off[r] = hreg[r].net_off; b->h_n_nets[r] = hreg[r].n_nets;
+        b->h_dims[3 * r] = hreg[r].X; b->h_dims[3 * r + 1] = hreg[r].Y; b->h_dims[3 * r + 2] = hreg[r].Z;
+    }
+    b->h_csr_size = hcsr.size();
     b->loaded = true;
+    return XR_OK;
+}
+
+// XR-Maze v2, optional: the nets' global-route guides as boxes.  Indexed like net_csr (boxes of net n of region r:
+// [guide_csr[R.net_off + n], guide_csr[R.net_off + n + 1]) into guide_box, 6 int16 per box); a net without boxes keeps the default
+// guide (bounding box of its access points).  Replaces every guide loaded before; a reload of the regions drops them.
+int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, const int16_t* const* boxes_host, void* stream) {
+    if (!b) return fail(XR_ERR_INVALID, "xr_batch_load_guides: null batch");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_load_guides: load regions first");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    b->dev.guide_csr = nullptr; b->dev.guide_box = nullptr;
+    if (!box_off_host) { b->guide_csr.release(); b->guide_box.release(); return XR_OK; }      // back to the default guides
+    std::vector<int32_t> csr(b->h_csr_size, 0);
+    std::vector<int16_t> box;
+    for (int r = 0; r < b->n_regions; r++) {
+        const int K = b->h_n_nets[r], X = b->h_dims[3 * r], Y = b->h_dims[3 * r + 1], Z = b->h_dims[3 * r + 2];
+        int32_t* c = csr.data() + b->h_net_off[r];                 // c[n] .. c[n + 1], n = 1 .. K (slot 0 unused, like net_csr)
+        const int32_t* off = box_off_host[r];
+        const int16_t* bx = boxes_host ? boxes_host[r] : nullptr;
+        for (int n = 1; n <= K; n++) {
+            c[n] = (int32_t)(box.size() / 6);
+            if (!off) continue;
+            const int lo = off[n - 1], hi = off[n];
+            if (lo < 0 || hi < lo || hi - lo > XR_GUIDE_MAX_BOXES || (hi > lo && !bx))
+                return fail(XR_ERR_RANGE, "xr_batch_load_guides: region %d net %d: %d boxes (0..%d, offsets ascending)", r, n, hi - lo, XR_GUIDE_MAX_BOXES);
+            for (int i = lo; i < hi; i++) {
+                const int16_t* g = bx + 6 * (size_t)i;     // x0, y0, x1, y1, z0, z1, inclusive
+                if (g[0] < 0 || g[2] < g[0] || g[2] >= X || g[1] < 0 || g[3] < g[1] || g[3] >= Y || g[4] < 0 || g[5] < g[4] || g[5] >= Z)
+                    return fail(XR_ERR_RANGE, "xr_batch_load_guides: region %d net %d box %d (%d,%d)-(%d,%d) layers %d..%d outside the %dx%dx%d grid",
+                                r, n, i - lo, g[0], g[1], g[2], g[3], g[4], g[5], X, Y, Z);
+                box.insert(box.end(), g, g + 6);
+            }
+        }
+        c[K + 1] = (int32_t)(box.size() / 6);
+    }
+    if (b->guide_csr.alloc(csr.size()) != hipSuccess || b->guide_box.alloc(std::max<size_t>(6, box.size())) != hipSuccess)
+        return fail(XR_ERR_HIP, "xr_batch_load_guides: hipMalloc failed");
+    XR_HIP(hipMemcpyAsync(b->guide_csr.p, csr.data(), csr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!box.empty()) XR_HIP(hipMemcpyAsync(b->guide_box.p, box.data(), box.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here
+    b->dev.guide_csr = b->guide_csr.p; b->dev.guide_box = b->guide_box.p;
     return XR_OK;
 }
 
@@ -870,6 +924,14 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         b->last_obs_inplace = d.obs_incremental;
         b->obs_valid_ptr = nullptr;                 // (set again below once every launch of this call has been enqueued without error)
         d.queue_quota_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 750;
+        {
+            // which workgroups start with units instead of a route: bit 5 of the workgroup index.  Bit 0 (rounds 1-2) put every
+            // route-first workgroup on the even XCDs (workgroup i runs on XCD i % 8).  Same box, ms per step kernel, bit 0 -> 3 -> 5 ->
+            // 8 -> none: 512 envs 0.296 -> 0.291 -> 0.290 -> 0.296 -> 0.302; 1024 envs 0.500 -> 0.489 -> 0.487 -> 0.485 -> 0.525;
+            // 4096 envs 1.741 -> 1.736 -> 1.730 -> 1.733 -> 1.797 (profiles/r03_r_ab_queue_unit_first_workgroups.txt)
+            static const int skip_env = [] { const char* v = getenv("XR_QUEUE_SKIP_SHIFT"); return v ? atoi(v) : -2; }();      // experiments only
+            d.queue_skip_shift = skip_env != -2 ? skip_env : 5;
+        }
         if (b->n_cus == 0) {            // once per batch: CUs x resident workgroups per CU of the step kernel (both variants)
             hipDeviceProp_t prop;
             XR_HIP(hipGetDeviceProperties(&prop, b->cfg.device));

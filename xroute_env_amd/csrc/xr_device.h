@@ -85,6 +85,8 @@ struct XrBatchDev {
     const int32_t* net_info; // [like net_csr] static facts of net n: lowest pin id (pin + 1, 14 bits) | distinct pins << 14 | pins in closed
                              // pockets (never reachable) << 22 | the lowest pin itself is in one << 30   (xr_dial3.h)
     const uint8_t* ap_flags; // [like ap_node] bit 0: the access point's pin sits in a closed pocket (isolated)
+    const int32_t* guide_csr; // [like net_csr] XR-Maze v2, optional (null: none): boxes of net n are [guide_csr[n], guide_csr[n + 1]) of guide_box
+    const int16_t* guide_box; // [boxes][6] x0, y0, x1, y1, z0, z1 (track / layer indices, inclusive)
     int32_t n_regions;
     // envs (mutable)
     int32_t n_envs;
@@ -136,6 +138,7 @@ struct XrBatchDev {
     int32_t* plan_unit_net;  // [B*k_max] 1-based net id of that unit
     uint32_t* queue;         // [3] next env to route, next unit to write (queue form); number of units (written by xr_plan_kernel)
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
+    int32_t queue_skip_shift; // workgroups with bit `shift` of their index set start with units instead of a route (-1: none)
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     const int32_t* route_order;   // route kernel: workgroup i routes env route_order[i] (null: env_base + i); longest predicted first

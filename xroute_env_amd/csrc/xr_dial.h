@@ -258,6 +258,41 @@ __device__ __forceinline__ void xr_mark_isolated_pins(int nap, const ApT* ap_f_o
 }
 
 // ------------------------------------------------------------------------------------------------
+// XR-Maze v2 guide of the net being routed, in LDS: up to XR_GUIDE_MAX_BOXES boxes packed as x0 | x1 << 16, y0 | y1 << 16,
+// z0 | z1 << 16 (margin applied, clamped to 0..0x7FFF).  The region's own boxes for the net when it carries any
+// (xr_batch_load_guides: the global-route guide rectangles clipped to the region), else ONE box: the bounding box
+// s_bb = {x0, x1, y0, y1} of the net's access points on every layer.  Every thread calls xr_guide_load after s_bb is complete
+// and visible; a barrier must follow.  
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xr_guide_load(const XrBatchDev& b, const XrRegionDev& R, int a, const int* s_bb, int Z,
+                                              int4* s_gbx, int* s_ngb, int tid) {
+    int lo = 0, hi = 0;
+    if (b.guide_csr) { lo = b.guide_csr[R.net_off + a]; hi = b.guide_csr[R.net_off + a + 1]; }
+    const int n = hi - lo, m = b.guide_margin;
+    auto pack = [](int c0, int c1) { return (int)((uint32_t)max(c0, 0) | ((uint32_t)min(c1, 0x7FFF) << 16)); };
+    if (n > 0) {
+        if (tid < n) {
+            const int16_t* __restrict__ g = b.guide_box + 6 * (int64_t)(lo + tid);
+            s_gbx[tid] = make_int4(pack(g[0] - m, g[2] + m), pack(g[1] - m, g[3] + m), pack(g[4], g[5]), 0);
+        }
+        if (tid == 0) *s_ngb = n;
+    } else if (tid == 0) {
+        s_gbx[0] = make_int4(pack(s_bb[0] - m, s_bb[1] + m), pack(s_bb[2] - m, s_bb[3] + m), pack(0, Z - 1), 0);
+        *s_ngb = 1;
+    }
+}
+__device__ __forceinline__ bool xr_guide_in(const int4 g, int x, int y, int z) {
+    return x >= (g.x & 0xFFFF) && x <= (int)((uint32_t)g.x >> 16) && y >= (g.y & 0xFFFF) && y <= (int)((uint32_t)g.y >> 16) &&
+           z >= (g.z & 0xFFFF) && z <= (int)((uint32_t)g.z >> 16);
+}
+// g0 = box 0 in (scalar) registers: the common case of one box costs no LDS read
+__device__ __forceinline__ bool xr_guide_has(const int4* s_gbx, int n, const int4 g0, int x, int y, int z) {
+    bool in = xr_guide_in(g0, x, y, z);
+    for (int i = 1; i < n; i++) in = in || xr_guide_in(s_gbx[i], x, y, z);
+    return in;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS form.  LDS carve (dynamic):  field u32[n_max] | open | defer | claim | wmin  (u32[mw_max] each, mw_max =
 // n_max / 32 + 1) | el4x | el4y.
 //   wmin[w]  lower bound of the distances of the open nodes of word w (XR_DIAL_INF: none): a round reads ONE word per
@@ -274,7 +309,8 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     __shared__ int s_hb[6];                                   // bounding box of the unconnected targets: x, y (coordinates x4), z
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
-    __shared__ int s_gb[4], s_retry;                          // XR-Maze v2: guide box of the net (track indices), rip-up decision
+    __shared__ int s_gb[4], s_retry, s_ngb;                   // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
+    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                // ... and its guide (xr_guide_load)
     __shared__ int s_abort;                                   // a hop loop hit the round cap
 
     const int tid = threadIdx.x;
@@ -506,10 +542,19 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
     // XR-Maze v2, neutral by default.  Guide: entering a node outside the net's guide box costs guide_cost.
     const uint32_t guide4 = V2 ? (uint32_t)b.guide_cost << 2 : 0u;
-    const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
-    auto guide_of = [&](int x, int y) -> uint32_t {
+    if (V2 && b.guide_cost) {
+        xr_guide_load(b, R, a, s_gb, Z, s_gbx, &s_ngb, tid);
+        __syncthreads();
+    }
+    const int ngb = (V2 && b.guide_cost) ? s_ngb : 0;
+    int4 gb0 = make_int4(0, 0, 0, 0);
+    if (V2 && b.guide_cost) {
+        const int4 t = s_gbx[0];
+        gb0 = make_int4(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y), __builtin_amdgcn_readfirstlane(t.z), 0);
+    }
+    auto guide_of = [&](int x, int y, int z) -> uint32_t {
         if (!V2) return 0u;
-        return (guide4 != 0u && (x < gx0 || x > gx1 || y < gy0 || y > gy1)) ? guide4 : 0u;
+        return (guide4 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide4 : 0u;
     };
     // Rip-up and reroute: claims of an attempt are tentative (owner = -a) until the attempt stands
     const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
@@ -697,7 +742,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         const uint32_t ca = vert ? yq : xq;
                         const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
                         gd4 = gw & ~3u;
-                        const uint32_t cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny);
+                        const uint32_t cand4 = gd4 + len4 + ((wn & 2u) ? pen4 : 0u) + guide_of(nx, ny, nz);
                         const uint32_t cw = cand4 | (wn & 3u);
                         const uint32_t key = (cand4 >> 2) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
                         // blockage, a distance that does not exist (>= XR_DIST_CAP, spec), or no improvement: nothing to do
@@ -809,9 +854,9 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                         uint32_t key[4], gcost[4];
                         {   // h of the four neighbours (coordinates differ from f's in one component)
                             const int ix = (int)x, iy = (int)y, iz = (int)z;
-                            gcost[0] = vert ? guide_of(ix, iy + 1) : guide_of(ix + 1, iy);
-                            gcost[1] = vert ? guide_of(ix, iy - 1) : guide_of(ix - 1, iy);
-                            gcost[2] = gcost[3] = guide_of(ix, iy);
+                            gcost[0] = vert ? guide_of(ix, iy + 1, iz) : guide_of(ix + 1, iy, iz);
+                            gcost[1] = vert ? guide_of(ix, iy - 1, iz) : guide_of(ix - 1, iy, iz);
+                            gcost[2] = guide_of(ix, iy, iz + 1); gcost[3] = guide_of(ix, iy, iz - 1);
                             key[0] = vert ? heur(ix, min(iy + 1, Y - 1), iz) : heur(min(ix + 1, X - 1), iy, iz);
                             key[1] = vert ? heur(ix, max(iy - 1, 0), iz) : heur(max(ix - 1, 0), iy, iz);
                             key[2] = heur(ix, iy, min(iz + 1, Z - 1));
@@ -939,7 +984,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                 };
                 for (int nt = 0; (vw >> 2) > 0; nt++) {
                     if (nt > N) { if (tid == 0) status |= 0x100; break; }    // (distances strictly decrease: a path is simple; hang guard)
-                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);   // pred distance + edge, x4
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y, z);   // pred distance + edge, x4
                     uint32_t len1 = 0, len2 = 0;
                     const int u1 = pred_of(v, x, y, z, d1, len1);
                     const int x1 = x + (d1 == 0) - (d1 == 2), y1 = y + (d1 == 3) - (d1 == 1), z1 = z + (d1 == 4) - (d1 == 5);
@@ -950,7 +995,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
                     const bool use1 = (uw1 - 1u) < (XR_W_USABLE_END - 1u);
                     const bool ok1 = tid < 6 && use1 && (uw1 & ~3u) + len1 == need4;
                     const bool ok2 = use1 && (uw2 - 1u) < (XR_W_USABLE_END - 1u) &&
-                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1);
+                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1, z1);
                     const unsigned long long mm = __ballot(ok1), mm2 = __ballot(ok2);
                     if (mm == 0) { if (tid == 0) status |= 0x100; break; }     // inconsistent field: cannot happen
                     const int src = __ffsll((long long)mm) - 1;                // wave-uniform
@@ -1096,7 +1141,8 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
     __shared__ int s_nG, s_nA, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
-    __shared__ int s_gb[4], s_retry;                          // XR-Maze v2: guide box of the net (track indices), rip-up decision
+    __shared__ int s_gb[4], s_retry, s_ngb;                   // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
+    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                // ... and its guide (xr_guide_load)
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -1212,10 +1258,19 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     // XR-Maze v2, neutral by default: guide cost outside the net's guide box; tentative claims (owner = -a) until
     // the attempt stands
     const uint32_t guide4 = V2 ? (uint32_t)b.guide_cost << 2 : 0u;
-    const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
-    auto guide_of = [&](int x, int y) -> uint32_t {
+    if (V2 && b.guide_cost) {
+        xr_guide_load(b, R, a, s_gb, Z, s_gbx, &s_ngb, tid);
+        __syncthreads();
+    }
+    const int ngb = (V2 && b.guide_cost) ? s_ngb : 0;
+    int4 gb0 = make_int4(0, 0, 0, 0);
+    if (V2 && b.guide_cost) {
+        const int4 t = s_gbx[0];
+        gb0 = make_int4(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y), __builtin_amdgcn_readfirstlane(t.z), 0);
+    }
+    auto guide_of = [&](int x, int y, int z) -> uint32_t {
         if (!V2) return 0u;
-        return (guide4 != 0u && (x < gx0 || x > gx1 || y < gy0 || y > gy1)) ? guide4 : 0u;
+        return (guide4 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide4 : 0u;
     };
     const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
     int attempt = 0;
@@ -1393,7 +1448,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
 #endif
                             if (fl == 0u) continue;
                         } else fl = wn & 3u;
-                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + guide_of(nx, ny);
+                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + guide_of(nx, ny, nz);
                         if (cand4 >= XR_W_USABLE_END) continue;
                         const uint32_t cw = cand4 | fl;
                         if (cw >= wn) continue;
@@ -1496,7 +1551,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 };
                 for (int nt = 0; (vw >> 2) > 0; nt++) {
                     if (nt > N) { if (tid == 0) status |= 0x100; break; }    // (hang guard: distances strictly decrease)
-                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y);
+                    const uint32_t need4 = (vw & ~3u) - ((vw & 2u) ? pen4 : 0u) - guide_of(x, y, z);
                     uint32_t len1 = 0, len2 = 0;
                     const int u1 = pred_of(v, x, y, z, d1, len1);
                     const int x1 = x + (d1 == 0) - (d1 == 2), y1 = y + (d1 == 3) - (d1 == 1), z1 = z + (d1 == 4) - (d1 == 5);
@@ -1506,7 +1561,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     const bool use1 = (uw1 - 1u) < (XR_W_USABLE_END - 1u);
                     const bool ok1 = tid < 6 && use1 && (uw1 & ~3u) + len1 == need4;
                     const bool ok2 = use1 && (uw2 - 1u) < (XR_W_USABLE_END - 1u) &&
-                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1);
+                                     (uw2 & ~3u) + len2 == (uw1 & ~3u) - ((uw1 & 2u) ? pen4 : 0u) - guide_of(x1, y1, z1);
                     const unsigned long long mm = __ballot(ok1), mm2 = __ballot(ok2);
                     if (mm == 0) { if (tid == 0) status |= 0x100; break; }
                     const int src = __ffsll((long long)mm) - 1;

@@ -69,7 +69,8 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
     __shared__ unsigned short s_qn[XR_QUAD_POOL];
     __shared__ int s_remaining, s_abort;
-    __shared__ int s_gb[4], s_retry;                            // XR-Maze v2: guide box of the net (track indices), rip-up decision
+    __shared__ int s_gb[4], s_retry, s_ngb;                     // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
+    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                  // ... and its guide (xr_guide_load, xr_dial.h)
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -189,10 +190,19 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     uint32_t pen5 = (uint32_t)b.pen_cost << 5;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
     const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;  // bucket width (keys f = d + h, DBU)
     const uint32_t guide5 = V2 ? (uint32_t)b.guide_cost << 5 : 0u;
-    const int gx0 = s_gb[0] - b.guide_margin, gx1 = s_gb[1] + b.guide_margin, gy0 = s_gb[2] - b.guide_margin, gy1 = s_gb[3] + b.guide_margin;
-    auto guide_of = [&](int x, int y) __attribute__((always_inline)) -> uint32_t {
+    if (V2 && b.guide_cost) {
+        xr_guide_load(b, R, a, s_gb, Z, s_gbx, &s_ngb, tid);
+        __syncthreads();
+    }
+    const int ngb = (V2 && b.guide_cost) ? s_ngb : 0;
+    int4 gb0 = make_int4(0, 0, 0, 0);
+    if (V2 && b.guide_cost) {
+        const int4 t = s_gbx[0];
+        gb0 = make_int4(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y), __builtin_amdgcn_readfirstlane(t.z), 0);
+    }
+    auto guide_of = [&](int x, int y, int z) __attribute__((always_inline)) -> uint32_t {
         if (!V2) return 0u;
-        return (guide5 != 0u && (x < gx0 || x > gx1 || y < gy0 || y > gy1)) ? guide5 : 0u;
+        return (guide5 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide5 : 0u;
     };
     const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);   // rip-up: claims are tentative (-a) until the attempt stands
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
@@ -389,7 +399,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const uint32_t dlt = cb - ca, adl = (int)dlt < 0 ? 0u - dlt : dlt;
                         const uint32_t len5 = planar ? adl : via5;
                         const int nx = gx + ((planar && !vert) ? sgn : 0), ny = gy + ((planar && vert) ? sgn : 0), nz = gz + (planar ? 0 : sgn);
-                        const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + guide_of(nx, ny);
+                        const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + guide_of(nx, ny, nz);
                         const uint32_t cw = cand5 | (vert ? pdV : pdH) | (wn & 3u);
                         const uint32_t key = (cand5 >> 5) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
                         // blockage, or no improvement of the WORD (distance, then predecessor direction): nothing to do
@@ -483,13 +493,13 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const int off = pd == 0u ? YZ : pd == 1u ? -Z : pd == 2u ? -YZ : pd == 3u ? Z : pd == 4u ? 1 : -1;
                         const int u = v + off;
                         const uint32_t uw = field[u];
-                        const uint32_t step5 = (vw & ~31u) - (uw & ~31u) - ((vw & 2u) ? pen5 : 0u) - guide_of(x, y);   // the edge itself, x32
+                        const uint32_t step5 = (vw & ~31u) - (uw & ~31u) - ((vw & 2u) ? pen5 : 0u) - guide_of(x, y, z);   // the edge itself, x32
                         if (vw & 2u) { d_vio += 1; d_held += 1; }
                         if (pd >= 4u) d_via += 1; else d_wl += (int)(step5 >> 5);
                         if (lane == 0) { if (plen < b.path_cap) path[plen] = v; s_tmp[np] = (unsigned short)v; }
                         plen++; np++;
                         fnv_mix(h, (uint32_t)v);
-                        if (V2) { x += (pd == 0u) - (pd == 2u); y += (pd == 3u) - (pd == 1u); }
+                        if (V2) { x += (pd == 0u) - (pd == 2u); y += (pd == 3u) - (pd == 1u); z += (pd == 4u) - (pd == 5u); }
                         v = u; vw = uw;
                         if (np == XR3_TMP) flush();
                     }

@@ -1497,8 +1497,8 @@ __global__ void __launch_bounds__(256) xr_netplane_stream_kernel(XrBatchDev b) {
 // (xr_plan_kernel), so they are the filler that keeps HBM busy while other workgroups route, and the tail of the
 // launch is one 20 us unit instead of one whole env.  A workgroup alternates one route task with `quota` units (a little
 // under the average units per env, so that the routes run out first and the launch ends in a pure-write drain);
-// odd workgroups start with units so that the launch writes from its first microseconds.  No workgroup ever
-// waits for another one.
+// half of the workgroups (bit 5 of the workgroup index: spread over every XCD and CU) start with units so that the launch writes
+// from its first microseconds.  No workgroup ever waits for another one.
 // ------------------------------------------------------------------------------------------------
 #ifndef XR_QUEUE_WAVES_PER_SIMD
 #define XR_QUEUE_WAVES_PER_SIMD 4      // register budget of the persistent step kernel: 4 waves per SIMD = its own 4 workgroups per CU.
@@ -1518,7 +1518,7 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
 #ifndef XR_QUEUE_BATCH
 #define XR_QUEUE_BATCH 1
 #endif
-    bool skip_route = XR_QUEUE_SKIP == 1 ? (blockIdx.x & 1) != 0 : XR_QUEUE_SKIP == 2 ? (blockIdx.x & 3) == 3
+    bool skip_route = XR_QUEUE_SKIP == 1 ? (b.queue_skip_shift >= 0 && ((blockIdx.x >> b.queue_skip_shift) & 1) != 0) : XR_QUEUE_SKIP == 2 ? (blockIdx.x & 3) == 3
                     : XR_QUEUE_SKIP == 3 ? (blockIdx.x & 3) != 0 : false;
 #ifdef XR_TIMELINE     // per workgroup (slot blockIdx.x of phase_cycles): start, end, time routing, time writing units, routes, units,
                        // time of the last route's end (100 MHz ticks)

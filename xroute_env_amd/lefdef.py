@@ -254,6 +254,33 @@ def _track_coords(design: Design, axis: str, lo: int, hi: int) -> np.ndarray:
     return np.unique(np.concatenate(vals)) if vals else np.zeros(0, np.int64)
 
 
+GUIDE_MAX_BOXES = 8        # XR_GUIDE_MAX_BOXES of include/xroute_hip.h
+
+
+def merge_guide_boxes(boxes, limit: int = GUIDE_MAX_BOXES):
+    """At most `limit` boxes (x0, y0, x1, y1, z0, z1) covering the given ones: duplicates dropped, equal footprints on adjacent
+    layers joined into one layer range (a guide usually repeats a GCell footprint on the layers a via stack crosses); if that is
+    still too many, one bounding box per layer range, then one box around everything.  Each step only ever GROWS the guide."""
+    boxes = sorted(set(boxes), key=lambda g: (g[0], g[1], g[2], g[3], g[4]))
+    out: List[Tuple[int, int, int, int, int, int]] = []
+    for g in boxes:
+        if out and out[-1][:4] == g[:4] and g[4] <= out[-1][5] + 1:
+            out[-1] = out[-1][:5] + (max(out[-1][5], g[5]),)
+        else:
+            out.append(tuple(g))
+    if len(out) <= limit:
+        return out
+    by_z: Dict[Tuple[int, int], List] = {}
+    for g in out:
+        by_z.setdefault((g[4], g[5]), []).append(g)
+    out = [(min(g[0] for g in gs), min(g[1] for g in gs), max(g[2] for g in gs), max(g[3] for g in gs), z0, z1)
+           for (z0, z1), gs in sorted(by_z.items())]
+    if len(out) <= limit:
+        return out
+    return [(min(g[0] for g in out), min(g[1] for g in out), max(g[2] for g in out), max(g[3] for g in out),
+             min(g[4] for g in out), max(g[5] for g in out))]
+
+
 class RegionExtractor:
     """Spatial index over the placed design + per-box region extraction."""
 
@@ -400,8 +427,25 @@ class RegionExtractor:
                         ntype[xi, yj, z] = BLOCKAGE
         used = (ntype == BLOCKAGE).astype(np.int64)
         rec = pack_records(ntype.reshape(-1), used.reshape(-1), net.reshape(-1), pin.reshape(-1))
-        return Region((X, Y, Z), xs.astype(np.int32), ys.astype(np.int32), np.asarray(d.layer_dir, np.uint8), rec,
-                      len(routed_nets), np.zeros(3, np.int32), name or f"box{bx0}_{by0}")
+        # the routed nets' global-route guides inside the box, as boxes of track / layer indices (XR-Maze v2 `guide_cost`)
+        guide_off = np.zeros(len(routed_nets) + 1, np.int32)
+        guide_box: List[Tuple[int, int, int, int, int, int]] = []
+        if d.guides:
+            names = [d.nets[ni][0] for ni in routed_nets]
+            for k, nm in enumerate(names):
+                boxes = []
+                for (gx0, gy0, gx1, gy1, z) in d.guides.get(nm, ()):
+                    a, b = span(xs, max(gx0, bx0), min(gx1, bx1)); c, e = span(ys, max(gy0, by0), min(gy1, by1))
+                    if b > a and e > c:
+                        boxes.append((a, c, b - 1, e - 1, z, z))
+                guide_box += merge_guide_boxes(boxes)
+                guide_off[k + 1] = len(guide_box)
+        reg = Region((X, Y, Z), xs.astype(np.int32), ys.astype(np.int32), np.asarray(d.layer_dir, np.uint8), rec,
+                     len(routed_nets), np.zeros(3, np.int32), name or f"box{bx0}_{by0}")
+        if d.guides:
+            reg.guide_off = guide_off
+            reg.guide_box = np.asarray(guide_box, np.int16).reshape(-1, 6)
+        return reg
 
     def gcell_regions(self, gcell=(6000, 5700), halo: int = 2000, limit: Optional[int] = None, min_nets: int = 1):
         """Regions of 1x1 GCell + halo over the die, row-major, skipping boxes with fewer than `min_nets` routed nets."""
@@ -431,6 +475,9 @@ def save_region_pack(path: str, regions: List[Region]):
         out[f"r{i}_ldir"] = r.layer_dir
         out[f"r{i}_idx"], out[f"r{i}_rec"] = idx, r.nodes[idx]
         out[f"r{i}_k"] = np.array(r.n_nets)
+        if r.guide_off is not None:
+            out[f"r{i}_goff"] = np.asarray(r.guide_off, np.int32)
+            out[f"r{i}_gbox"] = np.asarray(r.guide_box, np.int16).reshape(-1, 6)
     np.savez_compressed(path, **out)
 
 
@@ -443,4 +490,6 @@ def load_region_pack(path: str) -> List[Region]:
         nodes[z[f"r{i}_idx"]] = z[f"r{i}_rec"]
         regs.append(Region(dims, z[f"r{i}_xs"], z[f"r{i}_ys"], z[f"r{i}_ldir"], nodes, int(z[f"r{i}_k"]),
                            np.zeros(3, np.int32), f"pack{i}"))
+        if f"r{i}_goff" in z.files:
+            regs[-1].guide_off, regs[-1].guide_box = z[f"r{i}_goff"], z[f"r{i}_gbox"]
     return regs

@@ -101,6 +101,10 @@ class Region:
     n_nets: int                      # nets are 0..n_nets-1 on the wire (1-based in the env API)
     metrics0: np.ndarray = field(default_factory=lambda: np.zeros(3, np.int32))  # cum. (vio, wl, via)
     name: str = ""
+    # optional global-route guides (XR-Maze v2 `guide_cost`): boxes (x0, y0, x1, y1, z0, z1) in track / layer indices, inclusive,
+    # CSR over the nets (guide_off int32[n_nets + 1], guide_box int16[n_boxes, 6], at most 8 per net); None = the default guide
+    guide_off: Optional[np.ndarray] = None
+    guide_box: Optional[np.ndarray] = None
 
     @property
     def n_nodes(self) -> int:
