@@ -41,3 +41,12 @@ print(f"per workgroup: routing {ph[:,2].mean()/100:.0f} us ({ph[:,4].mean():.2f}
       f"units {ph[:,3].mean()/100:.0f} us ({ph[:,5].mean():.1f} units, {ph[:,3].sum()/max(ph[:,5].sum(),1)/100:.1f} us each), "
       f"other {(end-start).mean() - (ph[:,2].mean()+ph[:,3].mean())/100:.0f} us")
 print(f"last route task finished at {last_route.max():.0f} us (routes run out at {100*last_route.max()/span:.0f} % of the launch)")
+one = ph[ph[:, 4] == 1]                     # workgroups that routed exactly one env: that route's start / duration are known
+if len(one):
+    dur = one[:, 2] / 100.0
+    r_end = (one[:, 6] - t0) / 100.0
+    r_start = r_end - dur
+    order = np.argsort(-r_end)[:5]
+    print(f"single-route workgroups {len(one)}: route duration p50 {np.percentile(dur,50):.0f} p90 {np.percentile(dur,90):.0f} max {dur.max():.0f} us; "
+          f"route start p50 {np.percentile(r_start,50):.0f} p90 {np.percentile(r_start,90):.0f} max {r_start.max():.0f} us")
+    print("last routes to finish (start -> end, us): " + ", ".join(f"{r_start[i]:.0f} -> {r_end[i]:.0f}" for i in order))

@@ -23,7 +23,7 @@ hipError_t xr_launch_reset(const XrBatchDev*, const uint8_t*, int, hipStream_t);
 hipError_t xr_route_set_max_lds(size_t);
 hipError_t xr_launch_route(const XrBatchDev*, const int32_t*, int, int, size_t, int, hipStream_t);
 hipError_t xr_route_occupancy(int, int, size_t, int, int*, size_t*);
-hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, hipStream_t);
+hipError_t xr_launch_plan(const XrBatchDev*, const int32_t*, uint32_t*, int32_t*, int*, hipStream_t);
 hipError_t xr_launch_route_order(const XrBatchDev*, const int32_t*, int32_t*, hipStream_t);
 hipError_t xr_launch_step_queue(const XrBatchDev*, const int32_t*, int, int, size_t, int, int, hipStream_t);
 hipError_t xr_launch_netplanes(const XrBatchDev*, int, int, hipStream_t);
@@ -129,7 +129,9 @@ struct xr_batch {
     DevBuf<unsigned short> list_scratch;
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net;
-    DevBuf<uint32_t> plan_units, queue;
+    DevBuf<uint32_t> plan_units, queue;         // queue: two banks of 4 counters (route tasks, units, planned units, -), alternating per call
+    int queue_bank = 0;
+    uint32_t* queue_last = nullptr;             // the bank of the last planning call (XR_FETCH_UNITS)
     int n_cus = 0, queue_blocks = 0, queue_blocks_sweep = 0;
     bool sweep_full = false;     // auto router: the full-rewrite queue launch of a large batch takes the line-segment sweeps
     size_t sweep_lds = 0;
@@ -639,7 +641,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->total_steps, 1);
     XR_ALLOC(b->phase_cycles, (size_t)B * 8);
     XR_ALLOC(b->plan_region, B);
-    XR_ALLOC(b->queue, 3);
+    XR_ALLOC(b->queue, 8);
     XR_ALLOC(b->plan_units, (size_t)B * std::max(1, k_max));
     XR_ALLOC(b->plan_unit_net, (size_t)B * std::max(1, k_max));
     if (b->dial_big) {
@@ -700,6 +702,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<uint64_t> hhash(B, 0xcbf29ce484222325ULL);
     XR_HIP(hipMemcpyAsync(b->hash.p, hhash.data(), (size_t)B * sizeof(uint64_t), hipMemcpyHostToDevice, st));
 
+    XR_HIP(hipMemsetAsync(b->queue.p, 0, 8 * sizeof(uint32_t), st));       // both banks start clean; from then on every plan zeroes the other bank
+    b->queue_bank = 0; b->queue_last = b->queue.p;
     XR_HIP(xr_launch_ingest(b->rg_rec.p, b->rg_node_net.p, b->rg_owner0.p, (int64_t)hrec.size(), st));
     XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here
 
@@ -721,6 +725,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;
     d.obs_out = nullptr; d.obs_stride = 0; d.obs_vec4 = 0; d.obs_head_only = 0; d.obs_split_pm = 1000; d.obs_incremental = 0;
+    d.obs_lds_bytes = (int32_t)std::min<size_t>(b->route_lds, 1u << 30);      // (every launch of the default router carries route_lds)
     d.env_base = 0; d.env_count = 0;
     d.plan_region = b->plan_region.p; d.plan_units = b->plan_units.p; d.plan_unit_net = b->plan_unit_net.p; d.queue = b->queue.p; d.queue_quota_pm = 750;
     if (!b->aux_stream) {
@@ -945,7 +950,11 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
                 b->queue_blocks_sweep = std::max(1, per_cu) * b->n_cus;
             }
         }
-        XR_HIP(xr_launch_plan(&d, actions_dev, st));
+        // this call's counters / the other bank (zeroed by this call's plan for the next one: no memset per call)
+        d.queue = b->queue.p + 4 * b->queue_bank;
+        uint32_t* const next_queue = b->queue.p + 4 * (b->queue_bank ^ 1);
+        b->queue_bank ^= 1;
+        b->queue_last = d.queue;
         // Route tasks: slot order for large batches (longest-first measured SLOWER there, full rewrite 1.72 -> 1.83 ms, in-place
         // 1.06 -> 1.09 ms — the launch is bound by its write stream, and long routes up front delay the first units).  A batch of at
         // most ~2 routes per resident workgroup is different: its launch ends with the longest route, and a workgroup that starts
@@ -958,8 +967,10 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         const int lpt_limit = (b->all_n_mult4 ? 2 : 4) * b->queue_blocks;
         const bool lpt_tasks = b->cfg.launch_order == 2 ||
                                (b->cfg.launch_order == 0 && b->queue_blocks > 0 && b->cfg.n_envs <= lpt_limit && b->cfg.n_envs > 64);
+        int order_done = 0;       // (a batch of <= 1024 envs: plan and order are ONE launch; every dependent dispatch costs a small batch ~8 us)
+        XR_HIP(xr_launch_plan(&d, actions_dev, next_queue, lpt_tasks ? b->route_order.p : nullptr, &order_done, st));
         if (lpt_tasks) {
-            XR_HIP(xr_launch_route_order(&d, actions_dev, b->route_order.p, st));
+            if (!order_done) XR_HIP(xr_launch_route_order(&d, actions_dev, b->route_order.p, st));
             d.route_order = b->route_order.p;
         }
         // which router runs the route tasks of this launch (auto: sweeps for the full rewrite of a large batch, see load)
@@ -967,6 +978,7 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
         b->last_obs_sweeps = use_sweep ? 1 : 0;
         const int kz = use_sweep ? b->zch : b->kzch;
         const size_t klds = use_sweep ? b->sweep_lds : b->route_lds;
+        d.obs_lds_bytes = (int32_t)std::min<size_t>(klds, 1u << 30);
         const int blocks = b->cfg.obs_writer_blocks > 0 ? b->cfg.obs_writer_blocks : (use_sweep ? b->queue_blocks_sweep : b->queue_blocks);
         // helper writers (aligned planes only): LDS-free workgroups on the internal stream draining the same unit queue;
         // forked after the plan, joined before the call returns the stream (events, no host wait)
@@ -976,8 +988,8 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
             XR_HIP(hipEventRecord(b->ev_fork, st));
             XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
         }
-        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, kz, klds, b->route_threads,
-                                    std::min(blocks, 4 * b->cfg.n_envs), st));
+        d.queue_grid = std::min(blocks, 4 * b->cfg.n_envs);
+        XR_HIP(xr_launch_step_queue(&d, actions_dev, b->lds_dist ? 1 : 0, kz, klds, b->route_threads, d.queue_grid, st));
         if (use_helpers) {
             XR_HIP(xr_launch_unit_helpers(&d, helpers, b->aux_stream));
             XR_HIP(hipEventRecord(b->ev_join, b->aux_stream));
@@ -998,7 +1010,10 @@ int32_t step_observe_impl(xr_batch* b, const int32_t* actions_dev, float* out_de
     // caller's stream -> join.  Everything is ordered by events; the host never waits.
     d.obs_head_only = 1;
     d.obs_split_pm = b->cfg.obs_split_permille > 0 ? b->cfg.obs_split_permille : 1000;
-    XR_HIP(xr_launch_plan(&d, actions_dev, st));
+    d.queue = b->queue.p + 4 * b->queue_bank;
+    XR_HIP(xr_launch_plan(&d, actions_dev, b->queue.p + 4 * (b->queue_bank ^ 1), nullptr, nullptr, st));
+    b->queue_bank ^= 1;
+    b->queue_last = d.queue;
     XR_HIP(hipEventRecord(b->ev_fork, st));
     XR_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
     XR_HIP(xr_launch_route(&d, actions_dev, b->lds_dist ? 1 : 0, b->kzch, b->route_lds, b->route_threads, st));
@@ -1132,7 +1147,7 @@ int32_t xr_batch_fetch(xr_batch* b, int32_t what, void* dst_dev, size_t dst_byte
     case XR_FETCH_REGION: src = b->env_region.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_STEPS: src = b->total_steps.p; bytes = sizeof(int64_t); break;
     case XR_FETCH_SWEEPS: src = b->sweeps.p; bytes = B * sizeof(int32_t); break;
-    case XR_FETCH_UNITS: src = b->queue.p + 2; bytes = sizeof(uint32_t); break;
+    case XR_FETCH_UNITS: src = (b->queue_last ? b->queue_last : b->queue.p) + 2; bytes = sizeof(uint32_t); break;
     case XR_FETCH_ROUTE_ORDER: src = b->route_order.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_TOUCHED: src = b->touched.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_RECORD: src = b->records.p; bytes = B * sizeof(XrStepRecord); break;

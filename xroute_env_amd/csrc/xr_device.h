@@ -52,6 +52,14 @@ struct XrRegionDev {
     uint32_t s24;          // shift of yz | z << 8 | mw << 16 | div24_ok << 24
 };
 
+// Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over global memory too: the wave first waits for
+// every global store it has in flight (s_waitcnt vmcnt(0)), and under a saturated write stream a store takes ~1.5 us to be acknowledged —
+// after every back-trace of a route, between two units of the observation.  Where the barrier only hands LDS data (or nothing but
+// control) from wave to wave, this one is enough; global data written before it is NOT visible to the other waves after it.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void xr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 // Packed per-env result of the last step / reset (XR_FETCH_RECORD; layout = xr_step_record of include/xroute_hip.h)
 struct XrStepRecord {
     double reward;
@@ -139,6 +147,8 @@ struct XrBatchDev {
     uint32_t* queue;         // [3] next env to route, next unit to write (queue form); number of units (written by xr_plan_kernel)
     int32_t queue_quota_pm;  // units a workgroup writes after each route task, per mille of the average units per env
     int32_t queue_skip_shift; // workgroups with bit `shift` of their index set start with units instead of a route (-1: none)
+    int32_t obs_lds_bytes;   // dynamic LDS of the launch that runs xr_obs_epilogue (0: unknown -> the epilogue reads the state rows from global memory)
+    int32_t queue_grid;      // workgroups of the queue-form step kernel of this call (their first tasks are static: xr_queue_first)
     // parameters
     int32_t via_cost, pen_cost, max_route_count, auto_reset;
     const int32_t* route_order;   // route kernel: workgroup i routes env route_order[i] (null: env_base + i); longest predicted first

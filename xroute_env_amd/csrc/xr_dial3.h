@@ -64,6 +64,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ unsigned short s_ap_f[XR_MAX_AP_PER_NET];
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];      // 0 target, 1 connected, 2 isolated (static, from the load)
+    __shared__ unsigned char s_ap_own[XR_MAX_AP_PER_NET];       // the access point's node had an owner when the route began (a used access point of this net)
     __shared__ uint32_t s_min[3], s_bst[3];                     // rotating per round: smallest open key, smallest target distance
     __shared__ int s_hb[6];                                     // bounding box of the unconnected targets: x, y (coordinates x32), z
     __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
@@ -153,6 +154,10 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_wmin[i] = XR_DIAL_INF; }
     };
     build_field();
+    // (consumed after the barrier below; under a saturated write stream every dependent global round trip of a route costs ~1 us,
+    //  so the searches themselves never read global memory: what they need to know about `owner` is in the field words)
+    int my_ap_own = 0;
+    if (tid < nap) my_ap_own = owner[my_ap_f];
     if (tid <= X + 1) s_tab[tid] = my_xc;
     if (tid <= Y + 1) s_tab[XO + tid] = my_yc;
     for (int i = tid + nthr; i <= X + 1; i += nthr)
@@ -168,6 +173,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         s_ap_f[i] = (unsigned short)apf;
         s_ap_pin[i] = (short)pin;
         s_ap_conn[i] = (unsigned char)((iso & 1) ? 2 : (pin == first_pin ? 1 : 0));
+        s_ap_own[i] = (unsigned char)((i < nthr ? my_ap_own : (int)owner[apf]) != 0);
         if (V2 && b.guide_cost) {                // XR-Maze v2: the net's guide = bounding box of all its access points (+ margin)
             const int gy = (apf / Z) % Y, gx = apf / YZ;
             atomicMin(&s_gb[0], gx); atomicMax(&s_gb[1], gx); atomicMin(&s_gb[2], gy); atomicMax(&s_gb[3], gy);
@@ -227,10 +233,14 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     // node f <-> (word f % mw, bit f / mw) of the node bitmasks
     auto mask_pos = [&](uint32_t f, uint32_t& q, uint32_t& r) __attribute__((always_inline)) { xr3_divmod(f, umw, R.m24_mw, sh_mw, q, r); };
     // a node becomes a source: distance 0, open
-    auto make_source = [&](uint32_t f) __attribute__((always_inline)) {
+    // a node becomes a source: distance 0.  Bits 2..4 of a source word carry no predecessor; bit 2 = "the node has an owner" (it was
+    // claimed by this route, or was held before it began): the terminal node of a trace is claimed iff it has none, and the answer must
+    // not cost a global load.  A node that already is a source keeps its bit.
+    auto make_source = [&](uint32_t f, bool owned) __attribute__((always_inline)) {
         uint32_t q, r;
         mask_pos(f, q, r);
-        field[f] &= 3u;
+        const uint32_t w0 = field[f];
+        field[f] = (w0 & ((w0 >> 5) == 0u ? 7u : 3u)) | (owned ? 4u : 0u);
         atomicOr(&s_open[r], 1u << q);
         s_wmin[r] = 0u;                       // (racing plain stores of the same value)
     };
@@ -238,7 +248,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     // component = all access points of the lowest pin id
     for (int i = tid; i < nap; i += nthr)
-        if (s_ap_conn[i] == 1) make_source((uint32_t)s_ap_f[i]);
+        if (s_ap_conn[i] == 1) make_source((uint32_t)s_ap_f[i], s_ap_own[i] != 0);
     if (tid == 0) { s_remaining = npins - 1 - n_isolated; s_abort = 0; }
     // the tracing wave's bookkeeping (uniform over that wave; meaningless in the others)
     int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0, nrounds = 0;
@@ -255,7 +265,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             const uint32_t m = s_defer[i];
             if (m) { atomicOr(&s_open[i], m); s_defer[i] = 0; s_wmin[i] = 0u; }   // (0: a lower bound; the first scan fixes it)
         }
-        __syncthreads();
+        xr_lds_barrier();
         if (s_remaining <= 0) break;          // uniform: written before the barrier above
         // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
         for (int i = tid; i < nap; i += nthr)
@@ -266,7 +276,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                 atomicMin(&s_hb[0], cx); atomicMax(&s_hb[1], cx); atomicMin(&s_hb[2], cy); atomicMax(&s_hb[3], cy);
                 atomicMin(&s_hb[4], az); atomicMax(&s_hb[5], az);
             }
-        __syncthreads();
+        xr_lds_barrier();
         const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
         // h(v): distance to that box — coordinate differences + one via cost per layer (a consistent lower bound), from
         // coordinates x32
@@ -441,7 +451,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
 #ifdef XR_PHASE_TIMING
             if (tid == XR_TIMING_TID) _ph[7] += 1;
 #endif
-            __syncthreads();
+            xr_lds_barrier();
             XR_LAP(6);
             cur = nx1;
         }
@@ -479,10 +489,18 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     if (V2) node_xyz((uint32_t)v, x, y, z);
                     auto flush = [&]() __attribute__((always_inline)) {        // the listed path nodes: sources of the next search, claimed if nobody holds them
                         XR3_WSYNC();
+                        const int pl0 = plen - np;              // (the listed nodes are path[pl0 .. plen): one coalesced store per 64 nodes —
+                                                                //  a store per hop queues behind the unit writers' stores of the same CU)
                         for (int i = lane; i < np; i += 64) {
                             const uint32_t f = s_tmp[i];
-                            make_source(f);
-                            if (owner[f] == 0) owner[f] = claim_val;
+                            const uint32_t w0 = field[f];
+                            if (pl0 + i < b.path_cap) path[pl0 + i] = (int)f;
+                            make_source(f, true);               // (whatever it was before: it has an owner from here on)
+                            // claimed if nobody holds it.  Not held (bit 1 clear) = owner 0 or this net itself (a used access point of
+                            // it): the store of `a` is right in both cases and needs no load.  XR-Maze v2's claims are tentative (-a,
+                            // undone by a rip-up), so there the owner is read.
+                            if (!V2 && !(w0 & 2u)) owner[f] = claim_val;
+                            else if (owner[f] == 0) owner[f] = claim_val;
                         }
                         XR3_WSYNC();
                         np = 0;
@@ -496,7 +514,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const uint32_t step5 = (vw & ~31u) - (uw & ~31u) - ((vw & 2u) ? pen5 : 0u) - guide_of(x, y, z);   // the edge itself, x32
                         if (vw & 2u) { d_vio += 1; d_held += 1; }
                         if (pd >= 4u) d_via += 1; else d_wl += (int)(step5 >> 5);
-                        if (lane == 0) { if (plen < b.path_cap) path[plen] = v; s_tmp[np] = (unsigned short)v; }
+                        if (lane == 0) s_tmp[np] = (unsigned short)v;
                         plen++; np++;
                         fnv_mix(h, (uint32_t)v);
                         if (V2) { x += (pd == 0u) - (pd == 2u); y += (pd == 3u) - (pd == 1u); z += (pd == 4u) - (pd == 5u); }
@@ -507,21 +525,22 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     if (status & 0x100) remaining = 0;
                     else {
                         // terminal node of the component: claimed (and recorded) only if nobody holds it yet
-                        if (owner[v] == 0) {
-                            if (lane == 0) { owner[v] = claim_val; if (plen < b.path_cap) path[plen] = v; }
+                        // (a source: not held and no owner bit <=> owner[v] == 0, see make_source; XR-Maze v2 reads the owner)
+                        if (V2 ? owner[v] == 0 : (vw & 6u) == 0u) {
+                            if (lane == 0) { owner[v] = claim_val; if (plen < b.path_cap) path[plen] = v; field[v] = vw | 4u; }
                             plen++;
                             fnv_mix(h, (uint32_t)v);
                         }
                         remaining -= 1;
                         // the reached pin joins the component with all of its access points
                         for (int i = lane; i < nap; i += 64)
-                            if (s_ap_pin[i] == (short)tpin) { s_ap_conn[i] = 1; make_source((uint32_t)s_ap_f[i]); }
+                            if (s_ap_pin[i] == (short)tpin) { s_ap_conn[i] = 1; make_source((uint32_t)s_ap_f[i], s_ap_own[i] != 0); }
                     }
                 }
             }
             if (lane == 0) s_remaining = remaining;
         }
-        __syncthreads();      // every thread has left the round loop (its exit test reads s_min / s_bst) before the next search resets them
+        xr_lds_barrier();      // every thread has left the round loop (its exit test reads s_min / s_bst) before the next search resets them
         XR_LAP(3);
     }
     // ---- does the attempt stand (XR-Maze v2)?  Its path uses a node held by another net and attempts are left: rip it up ----

@@ -1050,6 +1050,26 @@ __device__ __forceinline__ void xr_obs_env_stream(const Src& src, int X, int Y, 
 }
 
 // legal bitmask -> ascending id list in LDS (== sorted(list(netSet)), build_3Dgrid.py:177)
+// (the same with the thread's legal word already in a register — thread t holds word t, words <= blockDim.x — and barriers that order
+//  LDS only: nothing here waits for global stores in flight)
+__device__ __forceinline__ int xr_legal_ids_pre(uint64_t my_m, int words, int* s_ids, int* s_pref) {
+    const int tid = threadIdx.x;
+    if (tid < words) s_pref[tid] = __popcll(my_m);
+    xr_lds_barrier();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < words; w++) { const int c = s_pref[w]; s_pref[w] = acc; acc += c; }
+        s_pref[words] = acc;
+    }
+    xr_lds_barrier();
+    if (tid < words) {
+        uint64_t m = my_m;
+        int o = s_pref[tid];
+        while (m) { const int bit = __ffsll((long long)m) - 1; s_ids[o++] = tid * 64 + bit + 1; m &= m - 1; }
+    }
+    xr_lds_barrier();
+    return s_pref[words];
+}
 __device__ __forceinline__ int xr_legal_ids(const uint64_t* __restrict__ lw, int words, int* s_ids, int* s_pref) {
     const int tid = threadIdx.x;
     for (int w = tid; w < words; w += blockDim.x) s_pref[w] = __popcll(lw[w]);
@@ -1115,9 +1135,48 @@ __device__ __forceinline__ void xr_obs_epilogue(const XrBatchDev& b, int e, char
     const XrRegionDev R = b.regions[b.env_region[e]];
     int* s_ids = reinterpret_cast<int*>(smem);              // the field is dead: reuse its LDS
     int* s_pref = s_ids + b.legal_words * 64;
-    const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
     XrStateSrc src{b.rg_node_net + R.node_off, b.owner + (int64_t)e * b.n_max};
     float* __restrict__ out = b.obs_out + (int64_t)e * b.obs_stride;
+    // Aligned planes, and the env's two state rows fit the launch's LDS beside the id list: the rows (node_net, owner: 2 bytes per node
+    // each) first go to LDS with 16-byte loads that are all in flight together with the legal words, and the features come from there.
+    // Read straight from global memory, every 1024-node chunk is its own chain of dependent loads (node -> up to six neighbours)
+    // before its stores — ~9 chains per env, each several microseconds while the unit writers of the other workgroups saturate the
+    // memory pipeline (tools/queue_timeline_probe.py: 85 us per env at 512 envs, more than the route before it).
+    const int ids_bytes = ((b.legal_words * 64 + b.legal_words + 1) * 4 + 15) & ~15;
+    const int npad = (R.N + 7) & ~7;
+    if (b.obs_vec4 == 1 && ids_bytes + 4 * npad <= b.obs_lds_bytes && b.legal_words <= (int)blockDim.x) {
+        const int tid = threadIdx.x, nthr = (int)blockDim.x;
+        const uint64_t my_m = tid < b.legal_words ? b.legal[(int64_t)e * b.legal_words + tid] : 0ull;
+        int16_t* l_nn = reinterpret_cast<int16_t*>(smem + ids_bytes);
+        int16_t* l_ow = l_nn + npad;
+        const int nchunk = npad >> 3;
+        for (int c0 = tid; c0 < nchunk; c0 += 4 * nthr) {
+            int4 vn[4], vo[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ci = c0 + u * nthr;
+                if (ci < nchunk) {
+                    vn[u] = *reinterpret_cast<const int4*>(src.node_net + (ci << 3));
+                    vo[u] = *reinterpret_cast<const int4*>(src.owner + (ci << 3));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ci = c0 + u * nthr;
+                if (ci < nchunk) {
+                    *reinterpret_cast<int4*>(l_nn + (ci << 3)) = vn[u];
+                    *reinterpret_cast<int4*>(l_ow + (ci << 3)) = vo[u];
+                }
+            }
+        }
+        const int K = xr_legal_ids_pre(my_m, b.legal_words, s_ids, s_pref);        // (its barriers also publish the rows)
+        const int knets = head_only ? XR_SPLIT_KEEP(b, K) : K;
+        XrStateSrc lsrc{l_nn, l_ow};
+        for (int cb = 0; cb < R.N; cb += nthr * 4)
+            xr_obs_write<XrStateSrc, 4>(lsrc, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
+        return;
+    }
+    const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
     if (b.obs_vec4 == 1) {
         const int knets = head_only ? XR_SPLIT_KEEP(b, K) : K;
         for (int cb = 0; cb < R.N; cb += (int)blockDim.x * 4)
@@ -1224,13 +1283,19 @@ __global__ void __launch_bounds__(1024, 4) xr_route_kernel(XrBatchDev b, const i
 // Units are equal-sized and visited in address order by the whole grid, so the write stream is balanced and
 // globally sequential (measured: the fastest write pattern on this device, tools/micro/write_bw.hip).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_t* __restrict__ actions) {
-    // one env per thread; the units of a workgroup's 256 envs are contiguous and in env order (block scan), the
-    // workgroups reserve their runs with one atomic each (queue[2], zeroed by the host before this launch)
-    __shared__ int s_wsum[4];
+// BT threads per workgroup.  `next_queue`: the counters of the NEXT call (the two banks alternate, xr_batch.cpp) are zeroed here, so no
+// call needs a memset of its own.  `order` (single-workgroup launches only, n_envs <= BT): the route tasks' longest-predicted-first
+// order of xr_route_order_kernel, computed by the same launch — a small batch pays for every dependent dispatch (~8 us each).
+template <int BT>
+__global__ void __launch_bounds__(BT) xr_plan_kernel(XrBatchDev b, const int32_t* __restrict__ actions, uint32_t* __restrict__ next_queue,
+                                                     int32_t* __restrict__ order) {
+    // one env per thread; the units of a workgroup's BT envs are contiguous and in env order (block scan), the
+    // workgroups reserve their runs with one atomic each (queue[2], zero when this launch starts)
+    __shared__ int s_wsum[BT / 64];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int e = blockIdx.x * 256 + tid;
+    const int e = blockIdx.x * BT + tid;
+    if (blockIdx.x == 0 && tid < 3 && next_queue) next_queue[tid] = 0u;
     int k = 0, r = 0;
     const uint64_t* lsrc = nullptr;        // where the post-step legal words come from
     int clear_bit = -1;
@@ -1287,7 +1352,7 @@ __global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wv; w++) woff += s_wsum[w];
-    if (tid == 255) s_base = (int)atomicAdd(&b.queue[2], (unsigned)(woff + incl));
+    if (tid == BT - 1) s_base = (int)atomicAdd(&b.queue[2], (unsigned)(woff + incl));
     __syncthreads();
     const int off = s_base + woff + incl - kw;
     if (e < b.n_envs) {
@@ -1305,6 +1370,33 @@ __global__ void __launch_bounds__(256) xr_plan_kernel(XrBatchDev b, const int32_
                 j++;
             }
         }
+    }
+    if (order) {                // (gridDim.x == 1, n_envs <= BT) counting sort of the env slots by descending work class: xr_route_order_kernel
+        __shared__ uint32_t s_cnt[256];
+        __shared__ uint32_t s_csum[4];
+        if (tid < 256) s_cnt[tid] = 0;
+        __syncthreads();
+        const int cls = e < b.n_envs ? xr_route_work_class(b, actions, e) : -1;
+        if (cls >= 0) atomicAdd(&s_cnt[cls], 1u);
+        __syncthreads();
+        uint32_t v = 0, inc = 0;
+        if (tid < 256) {
+            v = s_cnt[255 - tid];
+            inc = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += u;
+            }
+            if (lane == 63) s_csum[wv] = inc;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t base = 0;
+            for (int w = 0; w < wv; w++) base += s_csum[w];
+            s_cnt[255 - tid] = base + inc - v;
+        }
+        __syncthreads();
+        if (cls >= 0) order[atomicAdd(&s_cnt[cls], 1u)] = e;
     }
 }
 
@@ -1410,12 +1502,12 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
     const bool has_ap = ap_lo + tid < ap_hi;                   // (<= XR_MAX_AP_PER_NET = 128 access points: one per thread)
     if (has_ap) my_ap = b.ap_feat[R.ap_off + ap_lo + tid];      // issued before the zero fill
     for (int w = tid; w <= nwords; w += 256) s_m[w] = 0u;      // one spare word: the funnel shift reads w + 1
-    __syncthreads();
+    xr_lds_barrier();
     if (has_ap) {
         const int f = my_ap & 0x7FFFFFFF;
         atomicOr(&s_m[f >> 4], (my_ap < 0 ? 3u : 1u) << ((f & 15) << 1));
     }
-    __syncthreads();
+    xr_lds_barrier();
     // The unit's 7 planes are ONE contiguous run of 7*N floats at float (2 + 7*rank)*N of the env's row — plane boundaries only
     // matter for the VALUE of a float (plane = offset / N, node = offset % N), not for where it is written.  So the run is written
     // exactly like an aligned unit: cut at 128-byte-aligned multiples of 4 KB into 7 pieces, slot t of every piece in rotation,
@@ -1465,7 +1557,21 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
     if (tid < head && tid < total) run[tid] = one(tid);
     const int tail0 = head + (nslot << 2);
     if (tid >= 64 && tail0 + (tid - 64) < total) run[tail0 + (tid - 64)] = one(tail0 + (tid - 64));
-    __syncthreads();
+    xr_lds_barrier();
+}
+
+#ifndef XR_QUEUE_SKIP
+#define XR_QUEUE_SKIP 1
+#endif
+#ifndef XR_QUEUE_BATCH
+#define XR_QUEUE_BATCH 1
+#endif
+// Static first tasks of the queue form (see xr_step_queue_kernel): of G workgroups, those with bit `sh` of their index clear start with
+// a route (first_r of them), the others with a unit (first_u); sh < 0: every workgroup starts with a route.
+__device__ __forceinline__ void xr_queue_first(int G, int sh, int& first_r, int& first_u) {
+    if (sh < 0) { first_r = G; first_u = 0; return; }
+    first_r = ((G >> (sh + 1)) << sh) + min(G & ((2 << sh) - 1), 1 << sh);
+    first_u = G - first_r;
 }
 
 // Helper writers of the queue form: workgroups WITHOUT LDS that drain the same unit queue (queue[1]) as the persistent step
@@ -1475,8 +1581,10 @@ __device__ __forceinline__ void xr_unit_stream(const XrBatchDev& b, int u, uint3
 __global__ void __launch_bounds__(256) xr_unit_helper_kernel(XrBatchDev b) {
     __shared__ int s_u;
     const int total = (int)b.queue[2];
+    int first_r, first_u;
+    xr_queue_first(b.queue_grid, XR_QUEUE_SKIP == 1 ? b.queue_skip_shift : -1, first_r, first_u);     // (units 0 .. first_u - 1 belong to the step kernel)
     for (;;) {
-        if (threadIdx.x == 0) s_u = (int)atomicAdd(&b.queue[1], 1u);
+        if (threadIdx.x == 0) s_u = first_u + (int)atomicAdd(&b.queue[1], 1u);
         __syncthreads();
         const int u = s_u;
         __syncthreads();
@@ -1512,14 +1620,19 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
     const int total = (int)b.queue[2];
     const int quota = max(1, (int)(((int64_t)total * b.queue_quota_pm) / (1000 * (int64_t)B)));
     bool routes_left = true, units_left = total > 0;
-#ifndef XR_QUEUE_SKIP
-#define XR_QUEUE_SKIP 1
-#endif
-#ifndef XR_QUEUE_BATCH
-#define XR_QUEUE_BATCH 1
-#endif
     bool skip_route = XR_QUEUE_SKIP == 1 ? (b.queue_skip_shift >= 0 && ((blockIdx.x >> b.queue_skip_shift) & 1) != 0) : XR_QUEUE_SKIP == 2 ? (blockIdx.x & 3) == 3
                     : XR_QUEUE_SKIP == 3 ? (blockIdx.x & 3) != 0 : false;
+    // The FIRST task of every workgroup is static — the route-first workgroups take route tasks 0, 1, 2, ... by their rank among
+    // themselves, the unit-first ones units 0, 1, 2, ... — and the two counters hand out what follows: a thousand workgroups opening
+    // the launch with an atomic on the same word serialise in L2 (tools/queue_timeline_probe.py: the first routes started 6-12 us into
+    // the launch).
+    int first_r = 0, first_u = 0, my_first = -1;          // tasks handed out statically; this workgroup's own one (-1: taken)
+    const bool unit_first = skip_route;
+    if (XR_QUEUE_SKIP == 1) {
+        const int sh = b.queue_skip_shift, G = (int)gridDim.x, i = (int)blockIdx.x;
+        xr_queue_first(G, sh, first_r, first_u);
+        my_first = sh < 0 ? i : ((i >> (sh + 1)) << sh) + (i & ((1 << sh) - 1));          // rank among the workgroups of its kind
+    }
 #ifdef XR_TIMELINE     // per workgroup (slot blockIdx.x of phase_cycles): start, end, time routing, time writing units, routes, units,
                        // time of the last route's end (100 MHz ticks)
     long long tl_start = wall_clock64(), tl_route = 0, tl_unit = 0, tl_last_route = 0;
@@ -1529,19 +1642,26 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
     while (routes_left || units_left) {
         if (routes_left && !skip_route) {
             if (tid == 0) {
-                const int t = (int)atomicAdd(&b.queue[0], 1u);
+                const int t = (my_first >= 0 && !unit_first) ? my_first : first_r + (int)atomicAdd(&b.queue[0], 1u);
                 s_task = (t < B && b.route_order) ? b.route_order[t] : t;      // (small batches: longest predicted route first)
             }
-            __syncthreads();
+            if (!unit_first) my_first = -1;
+            xr_lds_barrier();
             const int e = s_task;
-            __syncthreads();
+            xr_lds_barrier();
             if (e < B) {
 #ifdef XR_TIMELINE
                 const long long t0 = XR_TL_NOW();
 #endif
+#ifdef XR_ROUTE_PRIO      // A/B: routing waves ahead of the unit writers they share a CU with (instruction arbitration)
+                __builtin_amdgcn_s_setprio(XR_ROUTE_PRIO);
+#endif
                 xr_route_dispatch<LDS_DIST, ZCH>(b, e, actions[e], smem);
+#ifdef XR_ROUTE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 xr_obs_epilogue(b, e, smem, true);
-                __syncthreads();
+                xr_lds_barrier();
 #ifdef XR_TIMELINE
                 tl_last_route = XR_TL_NOW(); tl_route += tl_last_route - t0; tl_nr++;
 #endif
@@ -1555,14 +1675,17 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
             // claiming several units at once measured slower (XR_QUEUE_BATCH 2: +1.5 %, 4: +7 %)
             const int nb = routes_left ? max(1, quota / XR_QUEUE_BATCH) : (1 << 30);
             unsigned nx = 0;
-            if (tid == 0) nx = atomicAdd(&b.queue[1], (unsigned)XR_QUEUE_BATCH);
+            const unsigned ubase = (unsigned)first_u * (unsigned)XR_QUEUE_BATCH;
+            if (tid == 0) nx = (my_first >= 0 && unit_first) ? (unsigned)my_first * (unsigned)XR_QUEUE_BATCH
+                                                             : ubase + atomicAdd(&b.queue[1], (unsigned)XR_QUEUE_BATCH);
+            if (unit_first) my_first = -1;
             for (int i = 0; i < nb; i++) {
                 if (tid == 0) s_task = (int)nx;
-                __syncthreads();
+                xr_lds_barrier();
                 const int u0 = s_task;
-                __syncthreads();
+                xr_lds_barrier();
                 if (u0 >= total) { units_left = false; break; }
-                if (tid == 0 && i + 1 < nb) nx = atomicAdd(&b.queue[1], (unsigned)XR_QUEUE_BATCH);     // used after this batch
+                if (tid == 0 && i + 1 < nb) nx = ubase + atomicAdd(&b.queue[1], (unsigned)XR_QUEUE_BATCH);     // used after this batch
 #ifdef XR_TIMELINE
                 const long long t0 = XR_TL_NOW();
 #endif
@@ -1575,7 +1698,7 @@ __global__ void __launch_bounds__(1024, XR_QUEUE_WAVES_PER_SIMD) xr_step_queue_k
                 tl_unit += XR_TL_NOW() - t0; tl_nu += u1 - u0;
 #endif
             }
-            __syncthreads();
+            xr_lds_barrier();
         }
     }
 #ifdef XR_TIMELINE
@@ -1853,10 +1976,17 @@ hipError_t xr_launch_route_order(const XrBatchDev* b, const int32_t* actions, in
     return hipGetLastError();
 }
 
-hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(b->queue, 0, 3 * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(xr_plan_kernel, dim3((b->n_envs + 255) / 256), dim3(256), 0, st, *b, actions);
+// b->queue: this call's counters (zero: the previous call's plan zeroed them); next_queue: the other bank.  order != null: the route
+// tasks' longest-first order is wanted too — by the same launch when the batch fits one workgroup (*order_done = 1), else the
+// caller launches xr_route_order_kernel.
+hipError_t xr_launch_plan(const XrBatchDev* b, const int32_t* actions, uint32_t* next_queue, int32_t* order, int* order_done, hipStream_t st) {
+    if (order_done) *order_done = 0;
+    if (order && b->n_envs <= 1024) {
+        hipLaunchKernelGGL(xr_plan_kernel<1024>, dim3(1), dim3(1024), 0, st, *b, actions, next_queue, order);
+        if (order_done) *order_done = 1;
+    } else {
+        hipLaunchKernelGGL(xr_plan_kernel<256>, dim3((b->n_envs + 255) / 256), dim3(256), 0, st, *b, actions, next_queue, (int32_t*)nullptr);
+    }
     return hipGetLastError();
 }
 
