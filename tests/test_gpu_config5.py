@@ -65,8 +65,10 @@ def test_config5_fullsize_route_order_matches_oracle(regions):
         assert np.array_equal(owner[e, : r.n_nodes], env.owner())
 
 
-@pytest.mark.parametrize("router", [0, 1])       # 0: bucketed frontier, HBM-scratch form (default); 1: line-segment sweeps in scratch
-def test_config5_32_envs_10_steps_match_oracle(router):
+# 0: bucketed frontier, HBM-scratch form (default: 1024-thread workgroups for a batch this small; 512 is what a large batch gets);
+# 1: line-segment sweeps in scratch
+@pytest.mark.parametrize("router,block_threads", [(0, 0), (0, 512), (1, 0)])
+def test_config5_32_envs_10_steps_match_oracle(router, block_threads):
     """32 full-size config 5 envs x 10 batched steps (random net order, K = 32) against the oracle stepped with OpenMP over
     envs: deltas, done, path length, reward of every env at every step; owner grids, cumulative metrics and the hash chains
     (every path node of every step) at the end.  The scratch of the frontier router must be left CLEAN by every route —
@@ -74,7 +76,7 @@ def test_config5_32_envs_10_steps_match_oracle(router):
     from xroute_env_amd.batch import RegionBatch
     B, STEPS = 32, 10
     regs = config_regions(5, B)
-    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router, launch_order=2 if router == 0 else 0)
+    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router, launch_order=2 if router == 0 else 0, block_threads=block_threads)
     batch.reset()
     ob = orc.OracleBatch(regs)
     threads = ob.max_threads()

@@ -555,7 +555,15 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             b->lds_dist = false;
             b->dial_big = true;
             b->route_lds = big_lds;
-            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : 512;       // (256: 4.2-4.7 ms, 512: 3.7-3.9 ms, config 5)
+            // (round 2, config 5: 256 threads 4.2-4.7 ms, 512: 3.7-3.9 ms.  Round 3, same box, ms per launch at 256 / 1024 / 4096 envs: 512 threads
+            //  1.9 / 2.7 / 4.0, 1024 threads 1.8 / 2.4 / 6.5 — a wider workgroup shortens each route's rounds (wide frontiers) but only one
+            //  fits a CU: it pays while the batch is at most ~4 routes per CU, i.e. while the launch is bound by its longest routes)
+            int big_threads = 512;
+            {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, b->cfg.device) == hipSuccess && B <= 4 * prop.multiProcessorCount) big_threads = 1024;
+            }
+            b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : big_threads;
         }
         // round 3's LDS form (xr_dial3.h) where it applies: the field fits with its queues, node ids fit 16 bits, and no distance
         // can exceed the 27 bits its field word holds — (N + 1) x (longest edge + largest penalty) bounds every simple path

@@ -1150,24 +1150,13 @@ __device__ __forceinline__ void xr_obs_epilogue(const XrBatchDev& b, int e, char
         int16_t* l_nn = reinterpret_cast<int16_t*>(smem + ids_bytes);
         int16_t* l_ow = l_nn + npad;
         const int nchunk = npad >> 3;
-        for (int c0 = tid; c0 < nchunk; c0 += 4 * nthr) {
-            int4 vn[4], vo[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ci = c0 + u * nthr;
-                if (ci < nchunk) {
-                    vn[u] = *reinterpret_cast<const int4*>(src.node_net + (ci << 3));
-                    vo[u] = *reinterpret_cast<const int4*>(src.owner + (ci << 3));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ci = c0 + u * nthr;
-                if (ci < nchunk) {
-                    *reinterpret_cast<int4*>(l_nn + (ci << 3)) = vn[u];
-                    *reinterpret_cast<int4*>(l_ow + (ci << 3)) = vo[u];
-                }
-            }
+        // (unrolled by four: the scheduler issues the eight loads of a group together; register arrays here ended up in scratch)
+#pragma unroll 4
+        for (int ci = tid; ci < nchunk; ci += nthr) {
+            const int4 vn = *reinterpret_cast<const int4*>(src.node_net + (ci << 3));
+            const int4 vo = *reinterpret_cast<const int4*>(src.owner + (ci << 3));
+            *reinterpret_cast<int4*>(l_nn + (ci << 3)) = vn;
+            *reinterpret_cast<int4*>(l_ow + (ci << 3)) = vo;
         }
         const int K = xr_legal_ids_pre(my_m, b.legal_words, s_ids, s_pref);        // (its barriers also publish the rows)
         const int knets = head_only ? XR_SPLIT_KEEP(b, K) : K;
