@@ -910,7 +910,8 @@ __device__ __forceinline__ void xr_node_features(const Src& s, int f, int X, int
                                                  int& apnet, bool& adj) {
     if (f >= N) { obst = 0.f; apnet = 0; adj = false; return; }
     const int n = s.net(f);
-    obst = (n == -1 || s.used(f)) ? 1.f : 0.f;
+    const bool used = s.used(f);           // (unconditional: the loads of an unrolled caller are issued together)
+    obst = (n == -1 || used) ? 1.f : 0.f;
     apnet = n > 0 ? n : 0;
     adj = false;
     if (n > 0) {
@@ -1009,6 +1010,7 @@ template <class Src>
 __device__ __forceinline__ void xr_obs_env_stream(const Src& src, int X, int Y, int Z, int N, const int* s_ids, int K,
                                                   float* __restrict__ out, unsigned short* s_feat, int planes = -1) {
     const int tid = threadIdx.x, nthr = blockDim.x;
+#pragma unroll 4
     for (int f = tid; f < N; f += nthr) {
         float obst; int apnet; bool adj;
         xr_node_features(src, f, X, Y, Z, N, obst, apnet, adj);
@@ -1163,6 +1165,24 @@ __device__ __forceinline__ void xr_obs_epilogue(const XrBatchDev& b, int e, char
         XrStateSrc lsrc{l_nn, l_ow};
         for (int cb = 0; cb < R.N; cb += nthr * 4)
             xr_obs_write<XrStateSrc, 4>(lsrc, R.X, R.Y, R.Z, R.N, s_ids, K, out, cb, knets);
+        return;
+    }
+    // Unaligned planes (stream form): the feature pass reads node_net of every node and of up to six neighbours — that row goes to LDS
+    // the same way (behind the 2-byte feature list); `owner` is read once per node, straight from global memory.
+    const int feat_bytes = (b.legal_words * 64 + ((b.legal_words + 1 + 3) & ~3)) * 4;
+    if (b.obs_vec4 == 2 && feat_bytes + 4 * npad <= b.obs_lds_bytes && b.legal_words <= (int)blockDim.x) {
+        const int tid = threadIdx.x, nthr = (int)blockDim.x;
+        const uint64_t my_m = tid < b.legal_words ? b.legal[(int64_t)e * b.legal_words + tid] : 0ull;
+        unsigned short* s_feat = reinterpret_cast<unsigned short*>(smem + feat_bytes);
+        int16_t* l_nn = reinterpret_cast<int16_t*>(smem + feat_bytes + 2 * npad);
+        const int nchunk = npad >> 3;
+#pragma unroll 4
+        for (int ci = tid; ci < nchunk; ci += nthr)
+            *reinterpret_cast<int4*>(l_nn + (ci << 3)) = *reinterpret_cast<const int4*>(src.node_net + (ci << 3));
+        const int K = xr_legal_ids_pre(my_m, b.legal_words, s_ids, s_pref);        // (its barriers also publish the row)
+        XrStateSrc lsrc{l_nn, src.owner};
+        const int planes = head_only ? 2 + 7 * XR_SPLIT_KEEP(b, K) : -1;
+        xr_obs_env_stream(lsrc, R.X, R.Y, R.Z, R.N, s_ids, K, out, s_feat, planes);
         return;
     }
     const int K = xr_legal_ids(b.legal + (int64_t)e * b.legal_words, b.legal_words, s_ids, s_pref);
