@@ -565,22 +565,32 @@ def main():
                     kernels.append({"kernel": "xr_route_kernel (XR-Maze v2 + the design's guide rectangles, ispd18_test1 region pack)", "error": str(ex)})
 
     traffic = None
+    traffic_scaled = False
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes of THIS command (tools/profile_round.sh)
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
             # one entry per measured command (`runs`); the file's top level is the first of them
             for run in [pj] + list(pj.get("runs", [])):
-                same = run.get("source_sha") == source_sha() and run.get("bench_args") == bench_args_key(args, world)
-                if same and isinstance(run.get(dom["kernel"]), dict):
-                    traffic = run[dom["kernel"]].get("hbm_total_bytes")
+                # same build, same workload (launches of the stationary distribution: --steps / --warmup only choose how many of them are averaged)
+                wl = lambda d: {k: v for k, v in (d or {}).items() if k not in ("steps", "warmup")}
+                same = run.get("source_sha") == source_sha() and wl(run.get("bench_args")) == wl(bench_args_key(args, world))
+                ent = run.get(dom["kernel"])
+                if same and isinstance(ent, dict) and ent.get("hbm_total_bytes"):
+                    if run.get("bench_args") == bench_args_key(args, world) or not ent.get("traffic_over_algorithmic"):
+                        traffic = ent.get("hbm_total_bytes")
+                    else:       # other --steps / --warmup: the measured traffic-to-algorithmic ratio on this run's mean launch
+                        traffic = float(ent["traffic_over_algorithmic"]) * float(dom["bytes"])
+                        traffic_scaled = True
                     break
         except Exception:
             traffic = None
     roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(dom["achieved"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this exact command and build "
-                                 "(profiles/pmc_traffic.json)" if traffic is not None else
+                "traffic_note": (("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build and workload with other --steps / --warmup "
+                                  "(profiles/pmc_traffic.json): its measured traffic / algorithmic ratio x this run's algorithmic bytes per launch" if traffic_scaled else
+                                  "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this exact command and build "
+                                  "(profiles/pmc_traffic.json)") if traffic is not None else
                                  "null: no PMC pass recorded for this build + command (profiles/pmc_traffic.json carries the last one with its source hash)"),
                 "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes"])}
 
