@@ -137,7 +137,9 @@ typedef struct xr_config {
                                  which the env slots are handed to workgroups.  0 = default: longest predicted route first when
                                  the batch has more slots than the chip holds workgroups (a ~10 us ordering kernel ahead of the
                                  launch; the prediction is the chosen net's bounding box and pin count), slot order otherwise;
-                                 1 = slot order always; 2 = longest first always.  Results do not depend on it.  (Takes the
+                                 1 = slot order always; 2 = longest first always.  The queue form of xr_batch_step_observe hands its
+                                 ROUTE TASKS out the same way: 0 = longest first for batches of at most 2 routes per resident workgroup (4
+                                 with planes that are not 16-byte aligned), slot order above that; 1 / 2 as above.  Results do not depend on it.  (Takes the
                                  struct's former tail padding: sizeof(xr_config) is unchanged.) */
     int32_t debug_round_cap;  /* 0 = default.  > 0: relaxation rounds one search of the router may take before it aborts with
                                  XR_ENV_ROUTER_ABORT (tests force the abort path with 1) */
