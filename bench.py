@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--agent", choices=["dqn", "ppo"], default=None,
                     help="agent-attached line (BASELINE configs 3 / 4) INSTEAD of the env-only headline: actions from the batched DQN / PPO "
                          "counterpart (random-init weights of the reference architecture), env in compact-consumer mode")
+    ap.add_argument("--agent-lib-tower", action="store_true", help="--agent: the obstacle tower through the framework's convolutions instead of the fused HIP kernel (A/B)")
     ap.add_argument("--agent-full-obs", action="store_true", help="--agent: feed the full fp32 observation (xr_batch_step_observe) instead of the compact mode")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="run 1 GiB fill/add kernels first (known HBM byte counts for rocprofv3 --pmc passes)")
@@ -709,6 +710,8 @@ def agent_leg(args, regions, dev, world):
     from xroute_env_amd.batch import RegionBatch
     B = len(regions)
     torch.manual_seed(0)
+    if os.environ.get("XR_CUDNN_BENCHMARK"):        # experiments: let MIOpen search its convolution algorithms (fixed conv batch shapes)
+        torch.backends.cudnn.benchmark = True
     model = (agents.RepActor() if args.agent == "dqn" else agents.ActorCritic(64)).to(dev).eval()
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
                         launch_order=args.launch_order)
@@ -721,13 +724,18 @@ def agent_leg(args, regions, dev, world):
     else:
         _head_of(batch, buf)
     cache = agents.NetVectorCache(len(regions), batch.k_max, dev)
+    # the obstacle tower as one fused HIP kernel (csrc/xr_agent.hip); --agent-lib-tower keeps the framework's convolutions (A/B)
+    tower = None if args.agent_lib_tower else agents.FusedObstacleTower(model.representation_network, (dims[2], dims[1], dims[0]), dev)
+    head_k = None if (args.agent_lib_tower or full) else agents.FusedActorHead(model.actor, dev)     # (+ the actor MLP and the arg-max as one kernel)
+    if head_k is not None:      # every (region, net) through the net tower once, up front: no cache-miss check (= no host round trip) per step
+        cache.prefill(model.representation_network, [r.n_nets for r in regions], batch.net_planes, dims)
     nl = torch.empty(B, dtype=torch.int32, device=dev)
     reg = torch.empty(B, dtype=torch.int32, device=dev)
 
     def act():
         batch.fetch("nlegal", nl)
         batch.fetch("region", reg)
-        kw = dict(cache=cache, region=reg)
+        kw = dict(cache=cache, region=reg, ob_tower=tower, actor_head=head_k)
         if not full:
             kw["planes_fn"] = batch.net_planes
         if args.agent == "dqn":
@@ -771,6 +779,7 @@ def agent_leg(args, regions, dev, world):
                                       "compact-consumer mode (xr_batch_step_compact: planes 0..1 per step; net planes once per (region, net) via xr_batch_net_planes + NetVectorCache)"),
                        "envs_per_gpu": B, "global_envs": B, "parallelism": "env-shard x1", "mean_nets_left": round(kfloat, 2)},
             "env_share_of_step_time": round(env_ms / max(env_ms + agent_ms, 1e-9), 4),
+            "obstacle_tower": "framework convolutions" if tower is None or not tower.supported else "fused HIP kernel (xr_agent_obstacle_tower)",
             "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(env_ms, 4),
             "net_grids_through_the_tower": cache.computed,
             "roofline": {"kernel": "xr_route_kernel (+ planes 0..1)" if not full else "xr_step_queue_kernel", "bound": "hbm",

@@ -346,6 +346,27 @@ int32_t xr_observation_from_records(const uint32_t* nodes_dev, int32_t dim_x, in
                                     int32_t dim_z, const int32_t* nets_dev, int32_t k,
                                     float* out_dev, void* stream);
 
+/* ---- agent side (a consumer of the path) ----------------------------------- */
+/* The obstacle tower of the reference's RepresentationNetwork (baseline/baseline_utils.py:231-379: ob_conv1 -> ob_align_conv1 ->
+ * ob_conv2 -> ob_align_conv2, what its DQN / PPO agents run on plane 0 of every observation before choosing a net) as one fused
+ * kernel, eval mode: head_dev fp32 [n_envs][head_stride] with plane 0 of every env first (the buffers of xr_batch_step_compact /
+ * xr_batch_step_observe), (D, H, W) = the observation tensor's trailing dims (dim_z, dim_y, dim_x), weights_dev =
+ * xr_agent_obstacle_tower_weights() floats packed by xroute_env_amd/agents.py (BatchNorm folded), out_dev fp32 [n_envs][64]
+ * (normalize != 0: after the reference's row-wise min-max normalisation, baseline/baseline_utils.py:45-63).  XR_ERR_RANGE: a grid shape the kernel does not take (use the framework path). */
+int32_t xr_agent_obstacle_tower_weights(void);
+int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int32_t n_envs, int32_t dim_d, int32_t dim_h, int32_t dim_w,
+                                const float* weights_dev, float* out_dev, int32_t normalize, void* stream);
+/* The actor head (baseline/DQN/DQN.py:27-46 `Actor`: mlp 128 -> 128 -> 64 -> 1, ELU, on [state vector ++ net vector]) for every legal net of
+ * every env + the greedy action (DQN.inference_action; PPO samples from the same logits): state_dev fp32 [n_envs][64] normalised state
+ * vectors, the net ids from the net-order channel of head_dev (plane 1, `ids_off` floats into an env's row), the normalised net vectors from
+ * cache_vec_dev [regions * cache_kmax][64] (row = region * cache_kmax + net - 1: agents.NetVectorCache, complete), weights_dev =
+ * xr_agent_actor_weights() floats (transposed by agents.FusedActorHead).  logits_dev: optional fp32 [n_envs][kcap], -inf beyond an env's
+ * nets; action_dev int32 [n_envs]: first maximum in the channel's order, 0 without nets. */
+int32_t xr_agent_actor_weights(void);
+int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
+                       const int32_t* region_dev, const float* cache_vec_dev, int32_t cache_kmax, const float* weights_dev, int32_t n_envs,
+                       int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream);
+
 /* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
 /* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43).
  * Pass 1 (fields_host == NULL): fills info_host[8] = {kind (1 request, 2 response, 0 empty),

@@ -1,0 +1,355 @@
+// xr_agent.hip — the obstacle tower of the reference's RepresentationNetwork as ONE fused gfx950 kernel (SURVEY.md §8 row f1,
+// a CONSUMER of the env path: with the DQN / PPO counterpart attached, the tower's convolutions through MIOpen cost 15x the env step).
+//
+// What it computes, per env (reference baseline/baseline_utils.py:231-379, `ob_conv1 -> ob_align_conv1 -> ob_conv2 -> ob_align_conv2`,
+// eval mode, BatchNorm folded into the convolutions by the caller — xroute_env_amd/agents.py FusedObstacleTower):
+//   x  [D,H,W]            plane 0 of the env's observation
+//   a  = relu(conv3(relu(conv3(x))) + x)                                   ResidualBlock(1), 3x3x3, zero padding 1
+//   b  = conv5(a), 1 -> 7 channels, stride (sd,sh,sw), padding 1           [7,od,oh,ow]   (no activation)
+//   P  = b zero-padded at the far ends to the standard grid [7,3,64,64]
+//   c  = relu(conv3(relu(conv3(P))) + P)                                   ResidualBlock(7)
+//   v[w] = bias + sum_{ch,d,h,kw} Wal2[ch,d,h,kw] * c[ch,d,h,w+kw-1]       kernel (3,64,3), padding (0,0,1): a 64-vector
+// Outside the cells the data can influence (h < oh + 2, w < ow + 2) c equals the block's response to an all-zero grid, which does not
+// depend on the env: the caller folds that part (and the bias) into `kvec`, the kernel sums the inside cells only.
+//
+// One workgroup of 512 threads per env, everything in LDS (b: 7*od*oh*ow floats, the first activation of the 7-channel block:
+// 7*3*(oh+3)*(ow+3) floats; the 1-channel stages live inside the latter's space), weights through scalar loads (every lane of a wave
+// uses the same weight), 7 output channels per thread and cell so that an LDS read feeds 7 FMAs.  fp32 throughout; the sums run in a
+// fixed order (no atomics): same input, same bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/xroute_hip.h"
+
+namespace {
+
+typedef float xt_f2 __attribute__((ext_vector_type(2)));     // pairs of output channels: v_pk_fma_f32
+
+struct XtDims {
+    int D, H, W;          // input grid
+    int sd, sh, sw;       // stride of the aligning convolution
+    int od, oh, ow;       // its output
+    int cols;             // 32 or 64: columns of the last stage (>= ow + 2)
+};
+
+// packed weights (floats), offsets
+constexpr int XT_A1 = 0;                    // 27 + 1     block(1).conv1 (BatchNorm folded)
+constexpr int XT_A2 = XT_A1 + 28;           // 27 + 1     block(1).conv2
+constexpr int XT_AL1 = XT_A2 + 28;          // 125*8 + 8  align1: [kd][kh][kw][co padded to 8], bias[8]
+constexpr int XT_C1 = XT_AL1 + 1008;        // 7*27*8 + 8 block(7).conv1: [ci][tap][co padded to 8], bias[8]
+constexpr int XT_C2 = XT_C1 + 1520;         // same       block(7).conv2
+constexpr int XT_AL2 = XT_C2 + 1520;        // 7*3*64*3   align2: [ch][d][h][kw]
+constexpr int XT_KV = XT_AL2 + 4032;        // 64         bias + contribution of every cell the data cannot influence
+constexpr int XT_TOTAL = XT_KV + 64;
+
+template <int BT>
+__global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
+                                                          const float* __restrict__ wt, float* __restrict__ out, int normalize) {
+    extern __shared__ __attribute__((aligned(16))) float xt_smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int e = blockIdx.x;
+    if (e >= n_envs) return;
+    const int D = g.D, H = g.H, W = g.W, N = D * H * W, HW = H * W;
+    const int od = g.od, oh = g.oh, ow = g.ow;
+    const int he1 = oh + 3, we1 = ow + 3;            // extent of the block's first activation that the inside cells read
+    const int nB = 7 * od * oh * ow;
+    float* bufB = xt_smem;                            // [7][od][oh][ow]
+    float* bufC1 = xt_smem + nB;                      // [7][3][he1][we1]
+    float* bufX = bufC1;                              // [D][H][W]   (stages of the 1-channel block: dead before bufC1 is written)
+    float* bufY = bufC1 + N;
+
+    // ---- x -------------------------------------------------------------------------------------------------------------------
+    const float* __restrict__ src = head + (int64_t)e * stride;
+    for (int i = tid; i < N; i += nthr) bufX[i] = src[i];
+    __syncthreads();
+    // ---- ResidualBlock(1): y = relu(conv3(x) + b1) ------------------------------------------------------------------------------
+    for (int i = tid; i < N; i += nthr) {
+        const int w = i % W, h = (i / W) % H, d = i / HW;
+        float acc = wt[XT_A1 + 27];
+#pragma unroll
+        for (int kd = 0; kd < 3; kd++)
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int dd = d + kd - 1, hh = h + kh - 1, ww = w + kw - 1;
+                    const bool in = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                    const float v = bufX[in ? (dd * H + hh) * W + ww : i];
+                    acc += wt[XT_A1 + (kd * 3 + kh) * 3 + kw] * (in ? v : 0.f);
+                }
+        bufY[i] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    // a = relu(conv3(y) + b2 + x), in place over x (a thread reads y of its neighbours and only its own x)
+    for (int i = tid; i < N; i += nthr) {
+        const int w = i % W, h = (i / W) % H, d = i / HW;
+        float acc = wt[XT_A2 + 27];
+#pragma unroll
+        for (int kd = 0; kd < 3; kd++)
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int dd = d + kd - 1, hh = h + kh - 1, ww = w + kw - 1;
+                    const bool in = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                    const float v = bufY[in ? (dd * H + hh) * W + ww : i];
+                    acc += wt[XT_A2 + (kd * 3 + kh) * 3 + kw] * (in ? v : 0.f);
+                }
+        bufX[i] = fmaxf(acc + bufX[i], 0.f);
+    }
+    __syncthreads();
+    // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
+    const int ncellB = od * oh * ow;
+    for (int i = tid; i < ncellB; i += nthr) {
+        const int wz = i % ow, hz = (i / ow) % oh, dz = i / (ow * oh);
+        xt_f2 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_AL1 + 1000)[k];
+        for (int kd = 0; kd < 5; kd++) {
+            const int dd = dz * g.sd + kd - 1;
+            if ((unsigned)dd >= (unsigned)D) continue;
+            for (int kh = 0; kh < 5; kh++) {
+                const int hh = hz * g.sh + kh - 1;
+                if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 5; kw++) {
+                    const int ww = wz * g.sw + kw - 1;
+                    const bool in = (unsigned)ww < (unsigned)W;
+                    const float v = in ? bufX[(dd * H + hh) * W + (in ? ww : 0)] : 0.f;
+                    const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_AL1 + ((kd * 5 + kh) * 5 + kw) * 8);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 7; co++) bufB[co * ncellB + i] = acc[co >> 1][co & 1];
+    }
+    __syncthreads();
+    // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
+    // (a "column" form — one thread per (h, w) with its three depth slices, 12 packed FMAs per LDS read — measured 1.5x SLOWER: 1.19 ms
+    //  against 0.79 ms per 1024 envs; so did nothing for the time either way: packed FMAs alone.  One cell per thread it stays.)
+    const int ncellC1 = 3 * he1 * we1;
+    for (int i = tid; i < ncellC1; i += nthr) {
+        const int w = i % we1, h = (i / we1) % he1, d = i / (we1 * he1);
+        xt_f2 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C1 + 1512)[k];
+        for (int kd = 0; kd < 3; kd++) {
+            const int dd = d + kd - 1;
+            if ((unsigned)dd >= (unsigned)od) continue;              // (d >= od: standard padding; d < 0 or >= 3: the convolution's own)
+            for (int kh = 0; kh < 3; kh++) {
+                const int hh = h + kh - 1;
+                if ((unsigned)hh >= (unsigned)oh) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int ww = w + kw - 1;
+                    const bool in = (unsigned)ww < (unsigned)ow;
+                    const int cell = (dd * oh + hh) * ow + (in ? ww : 0);
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+                    for (int ci = 0; ci < 7; ci++) {
+                        const float v = in ? bufB[ci * ncellB + cell] : 0.f;
+                        const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_C1 + (ci * 27 + tap) * 8);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 7; co++) bufC1[co * ncellC1 + i] = fmaxf(acc[co >> 1][co & 1], 0.f);
+    }
+    __syncthreads();
+    // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
+    // thread = (column w', row group); it keeps three sums: what its cells give to out[w' + 1], out[w'], out[w' - 1]
+    const int cols = g.cols, G = nthr / cols;
+    const int wq = tid % cols, gi = tid / cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (wq < ow + 2) {
+        for (int h = gi; h < oh + 2; h += G) {
+            for (int d = 0; d < 3; d++) {
+                xt_f2 acc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C2 + 1512)[k];
+                for (int kd = 0; kd < 3; kd++) {
+                    const int dd = d + kd - 1;
+                    if ((unsigned)dd >= 3u) continue;
+                    for (int kh = 0; kh < 3; kh++) {
+                        const int hh = h + kh - 1;
+                        if (hh < 0) continue;                          // (hh <= oh + 2 < he1: always stored)
+#pragma unroll
+                        for (int kw = 0; kw < 3; kw++) {
+                            const int ww = wq + kw - 1;
+                            const bool in = ww >= 0;                   // (ww <= ow + 2 < we1)
+                            const int cell = (dd * he1 + hh) * we1 + (in ? ww : 0);
+                            const int tap = (kd * 3 + kh) * 3 + kw;
+        #pragma unroll
+                    for (int ci = 0; ci < 7; ci++) {
+                                const float v = in ? bufC1[ci * ncellC1 + cell] : 0.f;
+                                const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_C2 + (ci * 27 + tap) * 8);
+#pragma unroll
+                                for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
+                            }
+                        }
+                    }
+                }
+                const bool inb = d < od && h < oh && wq < ow;
+                const int cellb = inb ? (d * oh + h) * ow + wq : 0;
+#pragma unroll
+                for (int co = 0; co < 7; co++) {
+                    const float p = inb ? bufB[co * ncellB + cellb] : 0.f;
+                    const float c = fmaxf(acc[co >> 1][co & 1] + p, 0.f);
+                    const float* __restrict__ wk = wt + XT_AL2 + ((co * 3 + d) * 64 + h) * 3;
+                    s0 += wk[0] * c; s1 += wk[1] * c; s2 += wk[2] * c;
+                }
+            }
+        }
+    }
+    __syncthreads();                                   // every thread is done with bufB: it becomes the reduction array [G][cols][3]
+    float* red = bufB;
+    red[(gi * cols + wq) * 3 + 0] = s0;
+    red[(gi * cols + wq) * 3 + 1] = s1;
+    red[(gi * cols + wq) * 3 + 2] = s2;
+    __syncthreads();
+    if (tid < 64) {
+        const int w = tid;
+        float v = wt[XT_KV + w];
+        for (int q = 0; q < G; q++) {                  // fixed order
+            if (w < cols) v += red[(q * cols + w) * 3 + 1];
+            if (w >= 1 && w - 1 < cols) v += red[(q * cols + w - 1) * 3 + 0];
+            if (w + 1 < cols) v += red[(q * cols + w + 1) * 3 + 2];
+        }
+        if (normalize) {          // the reference's row-wise min-max normalisation (baseline/baseline_utils.py:45-63), wave 0 holds the 64 values
+            float lo = v, hi = v;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+            float scale = hi - lo;
+            if (scale < 1e-5f) scale += 1e-5f;
+            v = (v - lo) / scale;
+        }
+        out[(int64_t)e * 64 + w] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Actor head (reference baseline/DQN/DQN.py:27-46 `Actor`: mlp 128 -> 128 -> 64 -> 1 with ELU on [state vector ++ net vector]) for every
+// legal net of every env, and the greedy action (first maximum in the order of the net-order channel).  One workgroup of 128 threads per
+// env; the state half of the first layer is computed once per env; the net vectors come from the per-(region, net) cache
+// (agents.NetVectorCache, which must hold every net asked for).  Weights transposed by the caller so that lane j reads element j.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int XA_W1T = 0;                   // [128 in][128 out]  (inputs 0..63: state, 64..127: net vector)
+constexpr int XA_B1 = XA_W1T + 128 * 128;
+constexpr int XA_W2T = XA_B1 + 128;         // [128 in][64 out]
+constexpr int XA_B2 = XA_W2T + 128 * 64;
+constexpr int XA_W3 = XA_B2 + 64;           // [64]
+constexpr int XA_B3 = XA_W3 + 64;
+constexpr int XA_TOTAL = XA_B3 + 1;
+
+__device__ __forceinline__ float xa_elu(float x) { return x > 0.f ? x : expm1f(x); }
+
+__global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__ state, const float* __restrict__ head, int64_t head_stride, int ids_off,
+                                                       const int32_t* __restrict__ nlegal, const int32_t* __restrict__ region,
+                                                       const float* __restrict__ cache_vec, int cache_kmax, const float* __restrict__ wt, int kcap,
+                                                       float* __restrict__ logits, int32_t* __restrict__ action) {
+    __shared__ float s_w1n[64 * 128];       // net half of the first layer, [in][out]
+    __shared__ float s_w2[128 * 64];
+    __shared__ float s_st[64], s_vec[64], s_h1[128];
+    const int j = threadIdx.x, e = blockIdx.x;
+    for (int i = j; i < 64 * 128; i += 128) s_w1n[i] = wt[XA_W1T + 64 * 128 + i];
+    for (int i = j; i < 128 * 64; i += 128) s_w2[i] = wt[XA_W2T + i];
+    if (j < 64) s_st[j] = state[(int64_t)e * 64 + j];
+    __syncthreads();
+    float hs = wt[XA_B1 + j];
+#pragma unroll 8
+    for (int i = 0; i < 64; i++) hs += wt[XA_W1T + i * 128 + j] * s_st[i];
+    const int nl = min(nlegal[e], kcap);
+    const int64_t rbase = (int64_t)region[e] * cache_kmax;
+    const float* __restrict__ ids = head + (int64_t)e * head_stride + ids_off;
+    const float b2 = j < 64 ? wt[XA_B2 + j] : 0.f, w3 = j < 64 ? wt[XA_W3 + j] : 0.f, b3 = wt[XA_B3];
+    float best = -INFINITY;
+    int besta = 0;
+    for (int k = 0; k < nl; k++) {
+        const int id = (int)ids[k];
+        if (j < 64) s_vec[j] = cache_vec[(rbase + id - 1) * 64 + j];
+        __syncthreads();
+        float h1 = hs;
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) h1 += s_w1n[i * 128 + j] * s_vec[i];
+        s_h1[j] = xa_elu(h1);
+        __syncthreads();
+        if (j < 64) {
+            float h2 = b2;
+#pragma unroll 8
+            for (int i = 0; i < 128; i++) h2 += s_w2[i * 64 + j] * s_h1[i];
+            float p = w3 * xa_elu(h2);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
+            const float lg = p + b3;
+            if (j == 0) {
+                if (logits) logits[(int64_t)e * kcap + k] = lg;
+                if (lg > best) { best = lg; besta = id; }
+            }
+        }
+    }
+    if (logits) for (int k = nl + j; k < kcap; k += 128) logits[(int64_t)e * kcap + k] = -INFINITY;
+    if (j == 0) action[e] = besta;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t xr_agent_obstacle_tower_weights(void) { return XT_TOTAL; }
+
+// head_dev: fp32 [n_envs][head_stride], plane 0 of every env's observation first (xr_batch_step_compact / _observe buffers);
+// dims = the observation's (D, H, W) as the reference's networks see it (the tensor is [.., Z, Y, X]: D = dim_z, H = dim_y, W = dim_x);
+// weights_dev: xr_agent_obstacle_tower_weights() floats, packed by xroute_env_amd/agents.py FusedObstacleTower; out_dev: fp32 [n_envs][64].
+// Returns XR_ERR_RANGE for grids this kernel does not take (the caller keeps the library path for those).
+int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int32_t n_envs, int32_t D, int32_t H, int32_t W,
+                                const float* weights_dev, float* out_dev, int32_t normalize, void* stream) {
+    if (!head_dev || !weights_dev || !out_dev || n_envs < 0 || D < 1 || H < 1 || W < 1) return XR_ERR_INVALID;
+    if (n_envs == 0) return XR_OK;
+    XtDims g;
+    g.D = D; g.H = H; g.W = W;
+    auto strd = [](int s, int t) { return (s > t ? (s - t + t - 1) / t : 0) + 1; };           // ceil(max(0, s - t) / t) + 1
+    g.sd = strd(D, 3); g.sh = strd(H, 64); g.sw = strd(W, 64);
+    if (D + 2 < 5 || H + 2 < 5 || W + 2 < 5) return XR_ERR_RANGE;
+    g.od = (D + 2 - 5) / g.sd + 1; g.oh = (H + 2 - 5) / g.sh + 1; g.ow = (W + 2 - 5) / g.sw + 1;
+    if (g.od > 3 || g.oh + 3 > 64 || g.ow + 3 > 64) return XR_ERR_RANGE;
+    g.cols = g.ow + 2 <= 32 ? 32 : 64;
+    const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
+    static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
+    if (2 * N > nC1 || nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
+    const size_t lds = (size_t)(nB + nC1) * sizeof(float);
+    if (lds > 160 * 1024) return XR_ERR_RANGE;
+    const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
+                   : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (threads == 1024) hipLaunchKernelGGL(xr_ob_tower_kernel<1024>, dim3(n_envs), dim3(1024), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
+    else if (threads == 256) hipLaunchKernelGGL(xr_ob_tower_kernel<256>, dim3(n_envs), dim3(256), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
+    else hipLaunchKernelGGL(xr_ob_tower_kernel<512>, dim3(n_envs), dim3(512), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
+    return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
+}
+
+int32_t xr_agent_actor_weights(void) { return XA_TOTAL; }
+
+// state_dev fp32 [n_envs][64] (normalised state vectors), head_dev as above (the net-order channel = plane 1 starts at float ids_off of an env's row),
+// nlegal_dev / region_dev int32 [n_envs], cache_vec_dev fp32 [regions * cache_kmax][64] (normalised net vectors, row = region * cache_kmax + net - 1),
+// weights_dev: xr_agent_actor_weights() floats; logits_dev (optional) fp32 [n_envs][kcap] (-inf beyond an env's nets); action_dev int32 [n_envs]:
+// the greedy net id (0: no nets).
+int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
+                       const int32_t* region_dev, const float* cache_vec_dev, int32_t cache_kmax, const float* weights_dev, int32_t n_envs,
+                       int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream) {
+    if (!state_dev || !head_dev || !nlegal_dev || !region_dev || !cache_vec_dev || !weights_dev || !action_dev || n_envs < 0 || kcap < 1 || cache_kmax < 1 ||
+        ids_off < 0 || head_stride < (int64_t)ids_off + kcap)
+        return XR_ERR_INVALID;
+    if (n_envs == 0) return XR_OK;
+    hipLaunchKernelGGL(xr_actor_kernel, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
+                       region_dev, cache_vec_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+    return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
+}
+
+}  // extern "C"
