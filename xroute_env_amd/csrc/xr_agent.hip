@@ -128,8 +128,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
-    // (a "column" form — one thread per (h, w) with its three depth slices, 12 packed FMAs per LDS read — measured 1.5x SLOWER: 1.19 ms
-    //  against 0.79 ms per 1024 envs; so did nothing for the time either way: packed FMAs alone.  One cell per thread it stays.)
+    // (measured and dropped: a "column" form — one thread per (h, w) with its three depth slices, 12 packed FMAs per LDS read — 1.19 ms against
+    //  0.79 ms per 1024 envs; the convolution's weights in LDS instead of scalar loads — the extra 6 KB push the workgroup past what a CU
+    //  hands out at full speed: 6.1 ms; packed FMAs alone changed nothing.  One cell per thread, weights through the scalar cache it stays.)
     const int ncellC1 = 3 * he1 * we1;
     for (int i = tid; i < ncellC1; i += nthr) {
         const int w = i % we1, h = (i / we1) % he1, d = i / (we1 * he1);
