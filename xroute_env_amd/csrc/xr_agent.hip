@@ -130,7 +130,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
     // (measured and dropped: a "column" form — one thread per (h, w) with its three depth slices, 12 packed FMAs per LDS read — 1.19 ms against
     //  0.79 ms per 1024 envs; the convolution's weights in LDS instead of scalar loads — the extra 6 KB push the workgroup past what a CU
-    //  hands out at full speed: 6.1 ms; packed FMAs alone changed nothing.  One cell per thread, weights through the scalar cache it stays.)
+    //  hands out at full speed: 6.1 ms; packed FMAs alone changed nothing; storing the first activation only where it depends on the data
+    //  (h <= oh, w <= ow; relu(bias) elsewhere) with one thread per (h, w') column in the last stage — 25 % fewer cells, every thread busy —
+    //  0.88 against 0.84 ms per agent step.  One cell per thread, weights through the scalar cache it stays.)
     const int ncellC1 = 3 * he1 * we1;
     for (int i = tid; i < ncellC1; i += nthr) {
         const int w = i % we1, h = (i / we1) % he1, d = i / (we1 * he1);
