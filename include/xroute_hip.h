@@ -359,13 +359,14 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
 /* The actor head (baseline/DQN/DQN.py:27-46 `Actor`: mlp 128 -> 128 -> 64 -> 1, ELU, on [state vector ++ net vector]) for every legal net of
  * every env + the greedy action (DQN.inference_action; PPO samples from the same logits): state_dev fp32 [n_envs][64] normalised state
  * vectors, the net ids from the net-order channel of head_dev (plane 1, `ids_off` floats into an env's row), the normalised net vectors from
- * cache_vec_dev [regions * cache_kmax][64] (row = region * cache_kmax + net - 1: agents.NetVectorCache, complete), weights_dev =
+ * cache_vec_dev [regions * cache_kmax][64] (row = region * cache_kmax + net - 1: agents.NetVectorCache, complete) or, when cache_pre_dev
+ * [regions * cache_kmax][128] is given, from the first layer's net half already applied to them (W1[:, 64:] . vec, once per weight update), weights_dev =
  * xr_agent_actor_weights() floats (transposed by agents.FusedActorHead).  logits_dev: optional fp32 [n_envs][kcap], -inf beyond an env's
  * nets; action_dev int32 [n_envs]: first maximum in the channel's order, 0 without nets. */
 int32_t xr_agent_actor_weights(void);
 int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
-                       const int32_t* region_dev, const float* cache_vec_dev, int32_t cache_kmax, const float* weights_dev, int32_t n_envs,
-                       int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream);
+                       const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
+                       int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream);
 
 /* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
 /* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43).

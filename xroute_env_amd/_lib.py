@@ -107,7 +107,7 @@ def lib():
     L.xr_agent_obstacle_tower_weights.argtypes = []
     L.xr_agent_obstacle_tower.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp]
     L.xr_agent_actor_weights.argtypes = []
-    L.xr_agent_actor.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.xr_agent_actor.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.xr_observation_from_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
     L.xr_proto_decode.argtypes = [vp, C.c_size_t, vp, vp, vp, vp]
     L.xr_proto_encode_response.argtypes = [C.c_int32, vp, C.POINTER(C.c_size_t)]

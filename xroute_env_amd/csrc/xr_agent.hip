@@ -30,7 +30,7 @@ struct XtDims {
     int D, H, W;          // input grid
     int sd, sh, sw;       // stride of the aligning convolution
     int od, oh, ow;       // its output
-    int cols;             // 32 or 64: columns of the last stage (>= ow + 2)
+    int cols;             // columns of the last stage: ow + 2
 };
 
 // packed weights (floats), offsets
@@ -133,9 +133,20 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     //  hands out at full speed: 6.1 ms; packed FMAs alone changed nothing; storing the first activation only where it depends on the data
     //  (h <= oh, w <= ow; relu(bias) elsewhere) with one thread per (h, w') column in the last stage — 25 % fewer cells, every thread busy —
     //  0.88 against 0.84 ms per agent step.  One cell per thread, weights through the scalar cache it stays.)
+    // Only the cells with h <= oh and w <= ow see any data (their taps reach h - 1 < oh, w - 1 < ow); every other stored cell is relu(bias).
+    // 3 x 39 x 23 = 2691 computed cells for a 24x40x9 region: three passes of 1024 threads instead of four (3075 = 3 x 1024 + 3).
     const int ncellC1 = 3 * he1 * we1;
     for (int i = tid; i < ncellC1; i += nthr) {
-        const int w = i % we1, h = (i / we1) % he1, d = i / (we1 * he1);
+        const int w = i % we1, h = (i / we1) % he1;
+        if (h > oh || w > ow) {
+#pragma unroll
+            for (int co = 0; co < 7; co++) bufC1[co * ncellC1 + i] = fmaxf(wt[XT_C1 + 1512 + co], 0.f);
+        }
+    }
+    const int hc = oh + 1, wc = ow + 1, ncomp = 3 * hc * wc;
+    for (int q = tid; q < ncomp; q += nthr) {
+        const int w = q % wc, h = (q / wc) % hc, d = q / (wc * hc);
+        const int i = (d * he1 + h) * we1 + w;
         xt_f2 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C1 + 1512)[k];
@@ -167,12 +178,16 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     __syncthreads();
     // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
     // thread = (column w', row group); it keeps three sums: what its cells give to out[w' + 1], out[w'], out[w' - 1]
+    // (cols = ow + 2 exactly and the (row, depth) pairs dealt round-robin to the row groups: 120 pairs over 42 groups of 24 columns = three cells per
+    //  thread for a 24x40x9 region, where 32 groups of 32 columns walking whole rows took six)
     const int cols = g.cols, G = nthr / cols;
     const int wq = tid % cols, gi = tid / cols;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (wq < ow + 2) {
-        for (int h = gi; h < oh + 2; h += G) {
-            for (int d = 0; d < 3; d++) {
+    if (gi < G) {
+        for (int pr = gi; pr < 3 * (oh + 2); pr += G) {
+            const int h = pr / 3;
+            {
+                const int d = pr - 3 * h;
                 xt_f2 acc[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C2 + 1512)[k];
@@ -212,9 +227,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
     __syncthreads();                                   // every thread is done with bufB: it becomes the reduction array [G][cols][3]
     float* red = bufB;
-    red[(gi * cols + wq) * 3 + 0] = s0;
-    red[(gi * cols + wq) * 3 + 1] = s1;
-    red[(gi * cols + wq) * 3 + 2] = s2;
+    if (gi < G) {
+        red[(gi * cols + wq) * 3 + 0] = s0;
+        red[(gi * cols + wq) * 3 + 1] = s1;
+        red[(gi * cols + wq) * 3 + 2] = s2;
+    }
     __syncthreads();
     if (tid < 64) {
         const int w = tid;
@@ -254,13 +271,13 @@ __device__ __forceinline__ float xa_elu(float x) { return x > 0.f ? x : expm1f(x
 
 __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__ state, const float* __restrict__ head, int64_t head_stride, int ids_off,
                                                        const int32_t* __restrict__ nlegal, const int32_t* __restrict__ region,
-                                                       const float* __restrict__ cache_vec, int cache_kmax, const float* __restrict__ wt, int kcap,
+                                                       const float* __restrict__ cache_vec, const float* __restrict__ cache_pre, int cache_kmax, const float* __restrict__ wt, int kcap,
                                                        float* __restrict__ logits, int32_t* __restrict__ action) {
     __shared__ float s_w1n[64 * 128];       // net half of the first layer, [in][out]
     __shared__ float s_w2[128 * 64];
     __shared__ float s_st[64], s_vec[64], s_h1[128];
     const int j = threadIdx.x, e = blockIdx.x;
-    for (int i = j; i < 64 * 128; i += 128) s_w1n[i] = wt[XA_W1T + 64 * 128 + i];
+    if (!cache_pre) for (int i = j; i < 64 * 128; i += 128) s_w1n[i] = wt[XA_W1T + 64 * 128 + i];
     for (int i = j; i < 128 * 64; i += 128) s_w2[i] = wt[XA_W2T + i];
     if (j < 64) s_st[j] = state[(int64_t)e * 64 + j];
     __syncthreads();
@@ -275,11 +292,16 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     int besta = 0;
     for (int k = 0; k < nl; k++) {
         const int id = (int)ids[k];
-        if (j < 64) s_vec[j] = cache_vec[(rbase + id - 1) * 64 + j];
-        __syncthreads();
         float h1 = hs;
+        if (cache_pre) {                     // the net half of the first layer, precomputed per (region, net): W1[:, 64:] . vec
+            h1 += cache_pre[(rbase + id - 1) * 128 + j];
+            __syncthreads();                 // (the previous net's readers of s_h1 are done)
+        } else {
+            if (j < 64) s_vec[j] = cache_vec[(rbase + id - 1) * 64 + j];
+            __syncthreads();
 #pragma unroll 8
-        for (int i = 0; i < 64; i++) h1 += s_w1n[i * 128 + j] * s_vec[i];
+            for (int i = 0; i < 64; i++) h1 += s_w1n[i * 128 + j] * s_vec[i];
+        }
         s_h1[j] = xa_elu(h1);
         __syncthreads();
         if (j < 64) {
@@ -321,7 +343,7 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     if (D + 2 < 5 || H + 2 < 5 || W + 2 < 5) return XR_ERR_RANGE;
     g.od = (D + 2 - 5) / g.sd + 1; g.oh = (H + 2 - 5) / g.sh + 1; g.ow = (W + 2 - 5) / g.sw + 1;
     if (g.od > 3 || g.oh + 3 > 64 || g.ow + 3 > 64) return XR_ERR_RANGE;
-    g.cols = g.ow + 2 <= 32 ? 32 : 64;
+    g.cols = g.ow + 2;
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
     static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
     if (2 * N > nC1 || nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
@@ -341,17 +363,18 @@ int32_t xr_agent_actor_weights(void) { return XA_TOTAL; }
 
 // state_dev fp32 [n_envs][64] (normalised state vectors), head_dev as above (the net-order channel = plane 1 starts at float ids_off of an env's row),
 // nlegal_dev / region_dev int32 [n_envs], cache_vec_dev fp32 [regions * cache_kmax][64] (normalised net vectors, row = region * cache_kmax + net - 1),
+// cache_pre_dev (optional) fp32 [regions * cache_kmax][128]: the net half of the first layer already applied to every cached vector (W1[:, 64:] . vec),
 // weights_dev: xr_agent_actor_weights() floats; logits_dev (optional) fp32 [n_envs][kcap] (-inf beyond an env's nets); action_dev int32 [n_envs]:
 // the greedy net id (0: no nets).
 int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
-                       const int32_t* region_dev, const float* cache_vec_dev, int32_t cache_kmax, const float* weights_dev, int32_t n_envs,
-                       int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream) {
+                       const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
+                       int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream) {
     if (!state_dev || !head_dev || !nlegal_dev || !region_dev || !cache_vec_dev || !weights_dev || !action_dev || n_envs < 0 || kcap < 1 || cache_kmax < 1 ||
         ids_off < 0 || head_stride < (int64_t)ids_off + kcap)
         return XR_ERR_INVALID;
     if (n_envs == 0) return XR_OK;
     hipLaunchKernelGGL(xr_actor_kernel, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
-                       region_dev, cache_vec_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+                       region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
     return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
 }
 
