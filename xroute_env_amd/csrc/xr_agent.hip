@@ -31,6 +31,7 @@ struct XtDims {
     int sd, sh, sw;       // stride of the aligning convolution
     int od, oh, ow;       // its output
     int cols;             // columns of the last stage: ow + 2
+    int pad_in_b;         // the padded copy of x lives in b's LDS space (else everything of the 1-channel block fits the first activation's)
 };
 
 // packed weights (floats), offsets
@@ -56,47 +57,48 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     const int nB = 7 * od * oh * ow;
     float* bufB = xt_smem;                            // [7][od][oh][ow]
     float* bufC1 = xt_smem + nB;                      // [7][3][he1][we1]
-    float* bufX = bufC1;                              // [D][H][W]   (stages of the 1-channel block: dead before bufC1 is written)
-    float* bufY = bufC1 + N;
+    // The 1-channel block works on ZERO-PADDED copies (a one-voxel halo): a tap is one LDS read at a fixed offset and one FMA — with bounds
+    // checks it was ~10 VALU instructions per FMA and a fifth of the kernel.  x (padded) sits in b's space or, when everything fits there, in the
+    // first activation's space (g.pad_in_b); y (padded) and a (unpadded, what the aligning convolution reads) in the first activation's space.
+    const int Hp = H + 2, Wp = W + 2, Np = (D + 2) * Hp * Wp;
+    float* xpad = g.pad_in_b ? bufB : bufC1;
+    float* ypad = g.pad_in_b ? bufC1 : bufC1 + Np;
+    float* bufX = ypad + Np;                          // a: [D][H][W]
 
-    // ---- x -------------------------------------------------------------------------------------------------------------------
     const float* __restrict__ src = head + (int64_t)e * stride;
-    for (int i = tid; i < N; i += nthr) bufX[i] = src[i];
+    for (int i = tid; i < Np; i += nthr) { xpad[i] = 0.f; ypad[i] = 0.f; }
+    __syncthreads();
+    for (int i = tid; i < N; i += nthr) {
+        const int w = i % W, h = (i / W) % H, d = i / HW;
+        xpad[((d + 1) * Hp + h + 1) * Wp + w + 1] = src[i];
+    }
     __syncthreads();
     // ---- ResidualBlock(1): y = relu(conv3(x) + b1) ------------------------------------------------------------------------------
     for (int i = tid; i < N; i += nthr) {
         const int w = i % W, h = (i / W) % H, d = i / HW;
+        const int pi = (d * Hp + h) * Wp + w;          // index of tap (0,0,0) in the padded grid
         float acc = wt[XT_A1 + 27];
 #pragma unroll
         for (int kd = 0; kd < 3; kd++)
 #pragma unroll
             for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const int dd = d + kd - 1, hh = h + kh - 1, ww = w + kw - 1;
-                    const bool in = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                    const float v = bufX[in ? (dd * H + hh) * W + ww : i];
-                    acc += wt[XT_A1 + (kd * 3 + kh) * 3 + kw] * (in ? v : 0.f);
-                }
-        bufY[i] = fmaxf(acc, 0.f);
+                for (int kw = 0; kw < 3; kw++) acc += wt[XT_A1 + (kd * 3 + kh) * 3 + kw] * xpad[pi + (kd * Hp + kh) * Wp + kw];
+        ypad[pi + (Hp + 1) * Wp + 1] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    // a = relu(conv3(y) + b2 + x), in place over x (a thread reads y of its neighbours and only its own x)
+    // a = relu(conv3(y) + b2 + x)
     for (int i = tid; i < N; i += nthr) {
         const int w = i % W, h = (i / W) % H, d = i / HW;
+        const int pi = (d * Hp + h) * Wp + w;
         float acc = wt[XT_A2 + 27];
 #pragma unroll
         for (int kd = 0; kd < 3; kd++)
 #pragma unroll
             for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const int dd = d + kd - 1, hh = h + kh - 1, ww = w + kw - 1;
-                    const bool in = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                    const float v = bufY[in ? (dd * H + hh) * W + ww : i];
-                    acc += wt[XT_A2 + (kd * 3 + kh) * 3 + kw] * (in ? v : 0.f);
-                }
-        bufX[i] = fmaxf(acc + bufX[i], 0.f);
+                for (int kw = 0; kw < 3; kw++) acc += wt[XT_A2 + (kd * 3 + kh) * 3 + kw] * ypad[pi + (kd * Hp + kh) * Wp + kw];
+        bufX[i] = fmaxf(acc + xpad[pi + (Hp + 1) * Wp + 1], 0.f);
     }
     __syncthreads();
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
@@ -290,18 +292,40 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     const float b2 = j < 64 ? wt[XA_B2 + j] : 0.f, w3 = j < 64 ? wt[XA_W3 + j] : 0.f, b3 = wt[XA_B3];
     float best = -INFINITY;
     int besta = 0;
+    if (cache_pre) {
+        // two nets per round: both waves add their first-layer halves for both nets, then wave 0 runs the second layer of net k and wave 1 that of net
+        // k + 1 (every lane busy, half the barriers); thread 0 takes the two logits in order
+        __shared__ float s_h1b[2][128], s_lg[2];
+        const int wv = j >> 6, o = j & 63;
+        const float b2o = wt[XA_B2 + o], w3o = wt[XA_W3 + o];
+        for (int k = 0; k < nl; k += 2) {
+            const int id0 = (int)ids[k], id1 = k + 1 < nl ? (int)ids[k + 1] : id0;
+            s_h1b[0][j] = xa_elu(hs + cache_pre[(rbase + id0 - 1) * 128 + j]);
+            s_h1b[1][j] = xa_elu(hs + cache_pre[(rbase + id1 - 1) * 128 + j]);
+            __syncthreads();
+            float h2 = b2o;
+#pragma unroll 8
+            for (int i = 0; i < 128; i++) h2 += s_w2[i * 64 + o] * s_h1b[wv][i];
+            float p = w3o * xa_elu(h2);
+#pragma unroll
+            for (int q = 32; q >= 1; q >>= 1) p += __shfl_xor(p, q, 64);
+            if (o == 0) s_lg[wv] = p + b3;
+            __syncthreads();
+            if (j == 0) {
+                const float l0 = s_lg[0], l1 = s_lg[1];
+                if (logits) { logits[(int64_t)e * kcap + k] = l0; if (k + 1 < nl) logits[(int64_t)e * kcap + k + 1] = l1; }
+                if (l0 > best) { best = l0; besta = id0; }
+                if (k + 1 < nl && l1 > best) { best = l1; besta = id1; }
+            }
+        }
+    } else
     for (int k = 0; k < nl; k++) {
         const int id = (int)ids[k];
         float h1 = hs;
-        if (cache_pre) {                     // the net half of the first layer, precomputed per (region, net): W1[:, 64:] . vec
-            h1 += cache_pre[(rbase + id - 1) * 128 + j];
-            __syncthreads();                 // (the previous net's readers of s_h1 are done)
-        } else {
-            if (j < 64) s_vec[j] = cache_vec[(rbase + id - 1) * 64 + j];
-            __syncthreads();
+        if (j < 64) s_vec[j] = cache_vec[(rbase + id - 1) * 64 + j];
+        __syncthreads();
 #pragma unroll 8
-            for (int i = 0; i < 64; i++) h1 += s_w1n[i * 128 + j] * s_vec[i];
-        }
+        for (int i = 0; i < 64; i++) h1 += s_w1n[i * 128 + j] * s_vec[i];
         s_h1[j] = xa_elu(h1);
         __syncthreads();
         if (j < 64) {
@@ -346,7 +370,11 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     g.cols = g.ow + 2;
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
     static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
-    if (2 * N > nC1 || nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
+    const int64_t Np = (int64_t)(D + 2) * (H + 2) * (W + 2);
+    if (2 * Np + N <= nC1) g.pad_in_b = 0;
+    else if (Np <= nB && Np + N <= nC1) g.pad_in_b = 1;
+    else return XR_ERR_RANGE;
+    if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
     const size_t lds = (size_t)(nB + nC1) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
     const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
