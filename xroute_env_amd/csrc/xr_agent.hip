@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
                 if (k + 1 < nl && l1 > best) { best = l1; besta = id1; }
             }
         }
-    } else
+    } else {
     for (int k = 0; k < nl; k++) {
         const int id = (int)ids[k];
         float h1 = hs;
@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
                 if (lg > best) { best = lg; besta = id; }
             }
         }
+    }
     }
     if (logits) for (int k = nl + j; k < kcap; k += 128) logits[(int64_t)e * kcap + k] = -INFINITY;
     if (j == 0) action[e] = besta;
