@@ -198,15 +198,33 @@ def cpu_baseline(regions, seconds, with_obs=True):
                       f"nets-left distribution) in {dt_a:.1f}s, oracle/xr_oracle.c, host cpu '{model}' ({os.cpu_count()} logical)"}
 
 
-def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256):
+def obs_sample_sha(obs, nlegal, slot_regions, n_check=256, n_sample=32):
+    """sha256 of the fp32 observation rows (reference layout, (2+7K)*N floats) of `n_sample` env slots among the first `n_check`,
+    spread over the nets-left distribution (sorted by K, evenly spaced).  Called right after the timed region, BEFORE any leg
+    touches the buffer again: these are bytes the timed launches wrote.  {env: (K, sha)}"""
+    import numpy as np
+    n = min(n_check, int(obs.shape[0]), len(slot_regions))
+    nl = nlegal[:n].cpu().numpy()
+    order = np.argsort(nl, kind="stable")
+    pick = sorted({int(order[int(round(j))]) for j in np.linspace(0, n - 1, min(n_sample, n))})
+    out = {}
+    for e in pick:
+        size = (2 + 7 * int(nl[e])) * slot_regions[e].n_nodes
+        out[e] = (int(nl[e]), hashlib.sha256(obs[e, :size].cpu().numpy().tobytes()).hexdigest())
+    return out
+
+
+def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256, obs_sha=None, v2=None, actions_log=None):
     """Checker leg (oracle as the CHECKER, never the thing measured): replays the bench's own action sequence — the
-    device policy is a counter-based hash of (seed, env, step count), bit-identical in the oracle — on the first
-    `n_check` envs (stagger pre-roll, warm-up and timed steps) and compares every env's hash chain (all path nodes, metrics
-    and actions of every step) and cumulative metrics with what the GPU produced."""
+    device policy is a counter-based hash of (seed, env, step count), bit-identical in the oracle; `actions_log` (learner flow:
+    the actions rank 0 broadcast) replaces it — on the first `n_check` envs (stagger pre-roll, warm-up and timed steps) and
+    compares every env's hash chain (all path nodes, metrics and actions of every step) and cumulative metrics with what the GPU
+    produced; `obs_sha` ({env: (K, sha256)} of observation rows fetched right after the timed region, `obs_sample_sha`): the
+    oracle's build_3Dgrid restatement of the same envs must give the same bytes.  `v2`: XR-Maze v2 knobs of the batch."""
     import numpy as np
     from oracle import xr_oracle as orc
     n = min(len(regions), n_check)
-    ob = orc.OracleBatch(regions[:n])
+    ob = orc.OracleBatch(regions[:n], **(v2 or {}))
     threads = ob.max_threads()
     steps = 0
     if stagger is not None:
@@ -215,13 +233,31 @@ def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256):
             a = ob.random_actions(sd)
             a[off[:n] <= i] = 0
             steps += ob.step(a, threads=threads, auto_reset=True)["real_steps"]
-    for sd in seeds:
-        steps += ob.step(ob.random_actions(sd), threads=threads, auto_reset=True)["real_steps"]
+    for i, sd in enumerate(seeds):
+        a = ob.random_actions(sd) if actions_log is None else np.ascontiguousarray(actions_log[i][:n], np.int32)
+        steps += ob.step(a, threads=threads, auto_reset=True)["real_steps"]
     ref_hash = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
     ref_cum = np.stack([e.cum() for e in ob.envs])
-    return {"envs": n, "env_steps": int(steps), "hash_chains_equal": bool(np.array_equal(ref_hash, gpu_hash[:n])),
-            "cumulative_metrics_equal": bool(np.array_equal(ref_cum, gpu_cum[:n])),
-            "what": "CPU oracle replay of the same actions on the first envs of rank 0: stagger pre-roll + warm-up + timed steps"}
+    res = {"envs": n, "env_steps": int(steps), "hash_chains_equal": bool(np.array_equal(ref_hash, gpu_hash[:n])),
+           "cumulative_metrics_equal": bool(np.array_equal(ref_cum, gpu_cum[:n])),
+           "what": "CPU oracle replay of the same actions on the first envs of the rank: stagger pre-roll + warm-up + timed steps"}
+    if obs_sha is not None:
+        bad = []
+        for e, (k, sha) in obs_sha.items():
+            if e >= n:
+                continue
+            o = ob.envs[e].observation()
+            if ob.envs[e].nlegal() != k or hashlib.sha256(np.ascontiguousarray(o).tobytes()).hexdigest() != sha:
+                bad.append(int(e))
+        checked = [e for e in obs_sha if e < n]
+        res["observations_checked"] = len(checked)
+        res["observations_equal"] = len(checked) > 0 and not bad
+        res["observation_nets_left_range"] = [min(k for k, _ in obs_sha.values()), max(k for k, _ in obs_sha.values())] if obs_sha else None
+        if bad:
+            res["observation_mismatch_envs"] = bad[:8]
+        res["what"] += "; observations: sha256 of the fp32 rows the last timed launch wrote for envs spread over K vs the oracle's build_3Dgrid restatement"
+    res["ok"] = bool(res["hash_chains_equal"] and res["cumulative_metrics_equal"] and res.get("observations_equal", True))
+    return res
 
 
 def kernel_entry(name, ms, nbytes, env_steps, bound, note):
@@ -353,6 +389,9 @@ def main():
             if args.global_envs % world == 0 else None
     nsteps_total = args.warmup + args.steps
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
+    n_par = min(B, 256 if world == 1 else 32)          # envs of this rank the oracle replays after the run (`parity`)
+    acts_log = torch.zeros((max(nsteps_total, 1), n_par), dtype=torch.int32, device=dev)
+    last_gather = [None]
     n_nodes = torch.tensor([regions[e % len(regions)].n_nodes for e in range(B)], dtype=torch.float64, device=dev)
 
     # ---- stagger: every env to a uniform phase of its episode cycle (untimed, route-only steps) ----------------------
@@ -391,6 +430,8 @@ def main():
             acts.copy_(acts_all[first_env:first_env + B] if strong else acts_all[rank * B:(rank + 1) * B])
         else:
             batch.random_actions(args.seed + rank * 7919 + i, acts)
+        if learner:
+            acts_log[i].copy_(acts[:n_par])
         if ev:
             ev[0].record()
         if fused:
@@ -412,10 +453,10 @@ def main():
                 batch.fetch("legal", legal_local)
                 dist.all_gather_into_tensor(legal_all, legal_local)
             if rec_all is not None:
-                gather_records_fixed(rec_local, rec_all)         # RCCL over xGMI: the batched-env gather
+                last_gather[0] = gather_records_fixed(rec_local, rec_all)         # RCCL over xGMI: the batched-env gather
             else:
                 from xroute_env_amd.dist import gather_records
-                gather_records(rec_local)
+                last_gather[0] = gather_records(rec_local)
 
     for i in range(args.warmup):
         one_step(i)
@@ -435,6 +476,22 @@ def main():
     real_steps = batch.total_steps() - steps0
     gpu_hash = batch.fetch("hash").cpu().numpy().view("uint64")          # state right after the timed region
     gpu_cum = batch.fetch("cum").cpu().numpy()
+    # bytes of the observation the LAST timed launch wrote, for envs spread over K (compared with the oracle in `parity`)
+    obs_sha = None
+    if obs is not None and nsteps_total > 0:
+        obs_sha = obs_sample_sha(obs, nlegal_log[nsteps_total - 1], [regions[e % len(regions)] for e in range(n_par)], n_check=n_par)
+
+    # ---- N > 1: the run certifies itself — the gather delivered every rank's records, and every rank's envs replay on the oracle
+    certify = None
+    if world > 1:
+        from xroute_env_amd.dist import verify_gather
+        gathered = last_gather[0]
+        if gathered is None:
+            certify = {"ranks_seen": 0, "gather_verified": False, "rows": 0}
+        else:
+            if os.environ.get("XR_BENCH_TEST_CORRUPT_GATHER") == "1" and rank == 0:       # test hook: a slice that is NOT what its owner sent
+                gathered[-1, 0] ^= 0xFF
+            certify = verify_gather(rec_local, gathered, first_env)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([float(real_steps)], dtype=torch.float64, device=dev)
@@ -564,6 +621,10 @@ def main():
                     kernels.append(v2_leg(args, None, dev, 0, pack=pack_regions))
                 except Exception as ex:
                     kernels.append({"kernel": "xr_route_kernel (XR-Maze v2 + the design's guide rectangles, ispd18_test1 region pack)", "error": str(ex)})
+                try:        # the reference's own configuration as a FULL step: v2 knobs + the design's guides + observation, oracle replay incl. observation bytes
+                    kernels.append(pack_leg(args, pack_regions, dev, v2=dict(V2_KNOBS, guide_margin=1)))
+                except Exception as ex:
+                    kernels.append({"kernel": "xr_step_queue_kernel (design-derived ispd18_test1 region pack, XR-Maze v2)", "error": str(ex)})
 
     traffic = None
     traffic_scaled = False
@@ -594,6 +655,20 @@ def main():
                                   "(profiles/pmc_traffic.json)") if traffic is not None else
                                  "null: no PMC pass recorded for this build + command (profiles/pmc_traffic.json carries the last one with its source hash)"),
                 "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes"])}
+
+    parity = None
+    can_replay = not args.region_pack and len(regions) >= B          # regions == env slots: rotation keeps every slot on its region, the oracle subset can follow
+    if can_replay and (world > 1 or not args.no_cpu_baseline):
+        try:
+            seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
+            parity = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
+                                  actions_log=acts_log.cpu().numpy() if learner else None)
+        except Exception as ex:
+            parity = {"error": str(ex), "ok": False}
+    if world > 1:
+        flag = torch.tensor([1 if (parity or {}).get("ok") else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity = dict(parity or {}, all_ranks_ok=bool(flag.item() == 1), envs_per_rank=n_par)
 
     out = None
     if rank == 0:
@@ -631,12 +706,12 @@ def main():
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
-        if world == 1 and not args.no_cpu_baseline and not args.region_pack and len(regions) >= B:
-            try:        # regions == env slots: rotation keeps every slot on its region, the oracle subset can follow
-                seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
-                out["parity"] = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum)
-            except Exception as ex:
-                out["parity"] = {"error": str(ex)}
+        if parity is not None:
+            out["parity"] = parity
+        if certify is not None:
+            out["gather_verified"] = certify["gather_verified"]
+            out["ranks_seen"] = certify["ranks_seen"]
+            out["gathered_rows"] = certify["rows"]
         if do_legs and not args.no_extras:
             out["extras"] = extras_leg(args, regions, dev, batch, obs)
             if sustained is not None:
@@ -647,10 +722,18 @@ def main():
             except Exception as ex:          # the oracle is optional for the GPU number itself
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}
+        failed = world > 1 and not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
+        if failed:          # an N-GPU label is only printed for a run that proved it was one
+            out["n_gpus"] = None
+            out["error"] = (f"N > 1 self-certification failed: ranks_seen {certify['ranks_seen']} of {args.gpus}, gather_verified "
+                            f"{certify['gather_verified']}, parity on every rank {parity.get('all_ranks_ok')}")
+            print(out["error"], file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok")):
+            sys.exit(3)
 
 
 def bench_args_key(args, world):
@@ -798,39 +881,47 @@ def _head_of(batch, head):
     return head
 
 
+V2_KNOBS = dict(guide_cost=800, maze_end_iter=3)      # + guide_margin: 2 with the default guides (bounding box of the access points), 1 with the design's rectangles
+
+
 def v2_leg(args, regions, dev, first_env, pack=None):
     """The simulator knobs the reference actually runs (ispd/ispd18_test1/run-net-ordering-training.tcl:3: `-maze_end_iter 3 -drc_cost 8
     -follow_guide 1 -ripup_mode 1`) on the driver-visible line: the same envs, route-only, with XR-Maze v2's rip-up-and-reroute
-    (maze_end_iter 3) and guide cost switched on.  Build-defined semantics, parity unpinned like all of a11."""
+    (maze_end_iter 3) and guide cost switched on, with an oracle replay of the leg's own actions (`parity`).  Build-defined semantics
+    (DESIGN.md §3.1), parity unpinned against TritonRoute like all of a11."""
     import torch
     from xroute_env_amd.batch import RegionBatch
     if pack is not None:      # the design-derived regions with the guide rectangles of ispd18_test1.input.guide (Region.guide_box)
         B = args.pack_envs
+        v2 = dict(V2_KNOBS, guide_margin=1)
         b = RegionBatch(pack, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
-                        launch_order=args.launch_order, guide_cost=800, guide_margin=1, maze_end_iter=3, max_route_count=1 << 30)
+                        launch_order=args.launch_order, max_route_count=1 << 30, **v2)
         regions = [pack[e % len(pack)] for e in range(B)]
     else:
         B = len(regions)
+        v2 = dict(V2_KNOBS, guide_margin=2)
         b = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
-                        launch_order=args.launch_order, guide_cost=800, guide_margin=2, maze_end_iter=3)
+                        launch_order=args.launch_order, **v2)
     b.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     off = stagger_offsets(b.fetch("nlegal").cpu().numpy(), first_env)
     off_d = torch.from_numpy(off).to(dev)
     zero = torch.zeros_like(acts)
-    for i in range(int(off.max()) if B else 0):
-        b.random_actions(args.seed ^ 0x7C1 ^ i, acts)
+    pre_seeds = [args.seed ^ 0x7C1 ^ i for i in range(int(off.max()) if B else 0)]
+    for i, sd in enumerate(pre_seeds):
+        b.random_actions(sd, acts)
         torch.where(off_d > i, acts, zero, out=acts)
         b.step(acts)
-    n_t = max(args.steps, 5)
+    n_w, n_t = 3, max(args.steps, 5)
+    seeds = [args.seed + 400000 + i for i in range(n_w)] + [args.seed + 400100 + i for i in range(n_t)]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
-    for i in range(3):
-        b.random_actions(args.seed + 400000 + i, acts)
+    for i in range(n_w):
+        b.random_actions(seeds[i], acts)
         b.step(acts)
     s0 = b.total_steps()
     vio = 0.0
     for i, (e0, e1) in enumerate(evs):
-        b.random_actions(args.seed + 400100 + i, acts)
+        b.random_actions(seeds[n_w + i], acts)
         e0.record()
         b.step(acts)
         e1.record()
@@ -839,38 +930,44 @@ def v2_leg(args, regions, dev, first_env, pack=None):
     ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
     real = (b.total_steps() - s0) / n_t
     nbytes = float(sum(4.0 * r.n_nodes for r in regions))
+    gpu_hash = b.fetch("hash").cpu().numpy().view("uint64")
+    gpu_cum = b.fetch("cum").cpu().numpy()
+    b.close()
     if pack is not None:
         ent = kernel_entry("xr_route_kernel (XR-Maze v2 + the design's guide rectangles, ispd18_test1 region pack)", ms, nbytes, real, "lds-latency",
                            f"route-only step on {B} env slots over the {len(pack)} design-derived regions with maze_end_iter 3 and guide cost 800 / "
                            "margin 1 where a net's guide = the rectangles ispd18_test1.input.guide lists for it, clipped to the region (1-8 boxes "
                            "per net, xr_batch_load_guides) — the closest this build gets to `-follow_guide 1 -maze_end_iter 3`; build-defined "
-                           "semantics, parity unpinned; env_steps_per_s is the figure of merit")
+                           "semantics, parity unpinned against TritonRoute; env_steps_per_s is the figure of merit")
         ent["data"] = "ispd18_test1 (design-derived regions + guides)"
-        ent["violations_per_env_step"] = vio / max(real * n_t, 1.0)
-        b.close()
-        return ent
-    ent = kernel_entry("xr_route_kernel (XR-Maze v2: the reference's TCL knobs)", ms, nbytes, real, "lds-latency",
-                       f"route-only step on the same {B} envs with maze_end_iter 3 (rip-up and reroute, penalty doubled per attempt) and guide "
-                       "cost 800 / margin 2 — the knobs of ispd/ispd18_test1/run-net-ordering-training.tcl:3 that XR-Maze v1 leaves out; "
-                       "build-defined semantics, parity unpinned; env_steps_per_s is the figure of merit")
+    else:
+        ent = kernel_entry("xr_route_kernel (XR-Maze v2: the reference's TCL knobs)", ms, nbytes, real, "lds-latency",
+                           f"route-only step on the same {B} envs with maze_end_iter 3 (rip-up and reroute, penalty doubled per attempt) and guide "
+                           "cost 800 / margin 2 — the knobs of ispd/ispd18_test1/run-net-ordering-training.tcl:3 that XR-Maze v1 leaves out; "
+                           "build-defined semantics, parity unpinned against TritonRoute; env_steps_per_s is the figure of merit")
     ent["violations_per_env_step"] = vio / max(real * n_t, 1.0)
-    b.close()
+    try:
+        ent["parity"] = parity_check(regions, seeds, (off, pre_seeds), gpu_hash, gpu_cum, v2=v2)
+    except Exception as ex:
+        ent["parity"] = {"error": str(ex), "ok": False}
     return ent
 
 
-def pack_leg(args, pack, dev):
+def pack_leg(args, pack, dev, v2=None):
     """The REAL ispd18_test1 regions on the record: 4096 env slots over the 253 regions `xroute_env_amd.lefdef` extracts from the
     reference's own ispd/ispd18_test1/ispd18_test1.input.{lef,def,guide} (per-GCell windows: 20-26 x 27-45 x 9 tracks, K up to 77),
-    full step in the default queue form, with its own oracle replay.  Their N is rarely a multiple of 4, so channel planes are not
-    16-byte aligned: the unit writer is xr_unit_stream.  Slots keep their region (max_route_count = 2^30: the replay needs no
-    rotation bookkeeping; rotation itself is covered by the tests)."""
+    full step in the default queue form, with its own oracle replay (hash chains, cumulative metrics and the observation bytes of
+    32 slots spread over K).  Their N is rarely a multiple of 4, so channel planes are not 16-byte aligned: the unit writer is
+    xr_unit_stream.  Slots keep their region (max_route_count = 2^30: the replay needs no rotation bookkeeping; rotation itself is
+    covered by the tests).  `v2`: the same full step with the reference's own simulator configuration (run-net-ordering-training.tcl:3:
+    maze_end_iter 3, follow_guide with the design's guide rectangles) — the step a user of the reference actually takes."""
     import numpy as np
     import torch
     from xroute_env_amd.batch import RegionBatch
     Bp = args.pack_envs
     slot_regions = [pack[e % len(pack)] for e in range(Bp)]
     b = RegionBatch(pack, n_envs=Bp, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
-                    launch_order=args.launch_order, max_route_count=1 << 30)
+                    launch_order=args.launch_order, max_route_count=1 << 30, **(v2 or {}))
     b.reset(rotate=True)
     acts = torch.empty(Bp, dtype=torch.int32, device=dev)
     obs = b.alloc_observation()
@@ -892,36 +989,46 @@ def pack_leg(args, pack, dev):
         b.random_actions(seeds[i], acts)
         b.step(acts, obs)
     s0 = b.total_steps()
+    vio = 0.0
     for i, (e0, e1) in enumerate(evs):
         b.random_actions(seeds[n_w + i], acts)
         e0.record()
         b.step(acts, obs)
         e1.record()
         b.fetch("nlegal", klog[i])
+        if v2:
+            vio += float(b.fetch("delta")[:, 0].double().sum().item())
     torch.cuda.synchronize(dev)
     ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
     real = (b.total_steps() - s0) / n_t
     info = b.observe_info()
     k_after = klog.to(torch.float64)
     nbytes = float((4.0 * n_nodes).sum().item()) + float((4.0 * (2.0 + 7.0 * k_after) * n_nodes[None, :]).sum().item()) / n_t
-    ent = kernel_entry("xr_step_queue_kernel (design-derived ispd18_test1 region pack)", ms, nbytes, real,
+    name = ("xr_step_queue_kernel (design-derived ispd18_test1 region pack, XR-Maze v2 + the design's guide rectangles: the reference's configuration)"
+            if v2 else "xr_step_queue_kernel (design-derived ispd18_test1 region pack)")
+    ent = kernel_entry(name, ms, nbytes, real,
                        "hbm-write (routing phase: lds-latency)",
                        f"{Bp} env slots over the {len(pack)} regions extracted from the reference's ispd18_test1.input.lef/def/guide "
                        "(tests/golden/ispd18_test1_regions.npz, xroute_env_amd/lefdef.py): full step (random net-order action + route + "
                        "fp32 observation of every env), queue form, stationary nets-left distribution; planes are not 16-byte aligned "
-                       "(N % 4 != 0 for 98 % of the regions): unit writer xr_unit_stream; bytes = state load + 4·N·(2+7K) per slot")
-    ent["data"] = "ispd18_test1 (design-derived regions)"
+                       "(N % 4 != 0 for 98 % of the regions): unit writer xr_unit_stream; bytes = state load + 4·N·(2+7K) per slot"
+                       + ("; router = XR-Maze v2 with the knobs of ispd/ispd18_test1/run-net-ordering-training.tcl:3 (maze_end_iter 3, guide cost 800 "
+                          "over the rectangles ispd18_test1.input.guide lists per net, margin 1)" if v2 else ""))
+    ent["data"] = "ispd18_test1 (design-derived regions" + (" + guides)" if v2 else ")")
     ent["form"] = info
     ent["mean_nets_left"] = float(k_after.mean().item())
     ent["mean_nodes"] = float(n_nodes.mean().item())
+    if v2:
+        ent["violations_per_env_step"] = vio / max(real * n_t, 1.0)
     gpu_hash = b.fetch("hash").cpu().numpy().view("uint64")
     gpu_cum = b.fetch("cum").cpu().numpy()
+    obs_sha = obs_sample_sha(obs, klog[n_t - 1], slot_regions)
     b.close()
     del obs
     try:
-        ent["parity"] = parity_check(slot_regions, seeds, (off, pre_seeds), gpu_hash, gpu_cum)
+        ent["parity"] = parity_check(slot_regions, seeds, (off, pre_seeds), gpu_hash, gpu_cum, obs_sha=obs_sha, v2=v2)
     except Exception as ex:
-        ent["parity"] = {"error": str(ex)}
+        ent["parity"] = {"error": str(ex), "ok": False}
     return ent
 
 
@@ -939,6 +1046,7 @@ def config5_leg(args, c5_regions, dev):
         b5.random_actions(555 + i, a5)
         b5.step(a5)
     n_t = 5
+    c5_seeds = [555, 556] + [600 + i for i in range(n_t)]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
     s0 = b5.total_steps()
     sweeps = 0.0
@@ -986,7 +1094,14 @@ def config5_leg(args, c5_regions, dev):
     ent["mean_path_nodes"] = plen / (n_t * Bc)
     ent["mean_touched_nodes"] = touched / (n_t * Bc)
     ent["envs"] = Bc
+    gpu_hash = b5.fetch("hash").cpu().numpy().view("uint64")
+    gpu_cum = b5.fetch("cum").cpu().numpy()
     b5.close()
+    try:        # oracle replay of the leg's own actions on its first slots (a Dijkstra over 786 k nodes per search: 16 slots x 7 steps)
+        n_chk = min(16, len(c5_regions), Bc)
+        ent["parity"] = parity_check([c5_regions[e % len(c5_regions)] for e in range(n_chk)], c5_seeds, None, gpu_hash, gpu_cum, n_check=n_chk)
+    except Exception as ex:
+        ent["parity"] = {"error": str(ex), "ok": False}
     return ent
 
 

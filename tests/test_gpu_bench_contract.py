@@ -45,6 +45,14 @@ def test_bench_json_contract(extra):
         pk = [k for k in d["kernels"] if "design-derived" in k["kernel"]][0]
         assert any("guide rectangles" in n for n in names)          # ... and XR-Maze v2 on them with the design's own guides
         assert pk["parity"]["hash_chains_equal"] is True and pk["parity"]["cumulative_metrics_equal"] is True and pk["form"]["form"] == 3
+        assert pk["parity"]["observations_equal"] is True and pk["parity"]["observations_checked"] >= 16
+        # the reference's own configuration (maze_end_iter 3, follow_guide over the design's rectangles) as a FULL step, and every
+        # XR-Maze v2 / config 5 leg: each with its own oracle replay
+        v2full = [k for k in d["kernels"] if "the reference's configuration" in k["kernel"]]
+        assert len(v2full) == 1 and v2full[0]["parity"]["ok"] is True and v2full[0]["parity"]["observations_equal"] is True
+        for k in d["kernels"]:
+            if "XR-Maze v2" in k["kernel"] or "config 5" in k["kernel"]:
+                assert k["parity"]["ok"] is True, (k["kernel"], k["parity"])
         assert "queue form" in d["config"]["workload"]
         for k in d["kernels"]:
             assert k["ms"] > 0 and k["bytes"] > 0 and abs(k["frac"] - k["achieved"] / 8000.0) < 1e-3 and k["env_steps_per_s"] > 0
@@ -56,6 +64,8 @@ def test_bench_json_contract(extra):
         assert su["steps"] == 500 and su["value"] > 0 and len(su["ms_per_step_by_100"]) == 5 and min(su["ms_per_step_by_100"]) > 0
     p = d["parity"]                                  # the checker leg: oracle replay of the run's own actions
     assert p["hash_chains_equal"] is True and p["cumulative_metrics_equal"] is True and p["env_steps"] > 0 and p["envs"] == 256
+    # ... and the bytes of the observation the last timed launch wrote, for 32 envs spread over K (fused and two-launch form alike)
+    assert p["observations_equal"] is True and p["observations_checked"] == 32 and p["ok"] is True
     # value is consistent with the reported step time: real env-steps <= slots
     assert d["value"] <= 256 * 1 / (d["ms_per_step"] * 1e-3) * 1.001
 
@@ -95,6 +105,11 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_envs"] == 256 and "cpu_baseline" not in d and "RCCL all_gather" in d["config"]["workload"]
+    # the run certifies itself: every rank's records arrived in the gather, two distinct ranks answered, and every rank's first
+    # 32 envs replay on the oracle (hash chains, metrics, observation bytes), AND-reduced over the ranks
+    assert d["gather_verified"] is True and d["ranks_seen"] == 2 and d["gathered_rows"] == 256
+    assert d["parity"]["all_ranks_ok"] is True and d["parity"]["ok"] is True and d["parity"]["envs_per_rank"] == 32
+    assert d["parity"]["observations_equal"] is True
     # strong scaling (BASELINE config 4 shape): the same global batch split over the ranks
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
@@ -103,6 +118,7 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["global_envs"] == 256 and d["config"]["envs_per_gpu"] == 128
+    assert d["gather_verified"] is True and d["ranks_seen"] == 2 and d["parity"]["all_ranks_ok"] is True
     # BASELINE config 4's learner flow: gather records + legal sets, policy on rank 0, i32 action broadcast
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
@@ -111,6 +127,15 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert "learner flow" in d["config"]["workload"] and d["value"] > 0 and d["config"]["slots_stepped_per_batch_step"] > 0.5
+    assert d["gather_verified"] is True and d["ranks_seen"] == 2 and d["parity"]["all_ranks_ok"] is True      # (replay of the BROADCAST actions)
+    # a slice of the gathered records that is not what its owner sent fails the run: rc != 0, no N-GPU label
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "64"],
+                         capture_output=True, text=True, timeout=900, env=dict(env, XR_BENCH_TEST_CORRUPT_GATHER="1"))
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines and json.loads(lines[0])["gather_verified"] is False and json.loads(lines[0])["n_gpus"] is None
 
 
 def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():

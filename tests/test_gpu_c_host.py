@@ -34,7 +34,15 @@ def test_c_host_matches_oracle(tmp_path):
     rows = [[int(v) for v in line.split()] for line in out.stdout.strip().splitlines()]
     env = orc.OracleEnv(reg)
     assert len(rows) == reg.n_nets
-    for a, dv, dw, dvia, done, plen, h in rows:
+    def fnv(buf: bytes) -> int:            # position-weighted sum of the fp32 words, mod 2^64 (step_demo.c)
+        w = np.frombuffer(buf, np.uint32).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            return int((w * (np.arange(w.size, dtype=np.uint64) + np.uint64(1))).sum(dtype=np.uint64))
+
+    for a, dv, dw, dvia, done, plen, h, nleg, obs_fnv in rows:
         ref = env.step(a)
         assert [dv, dw, dvia] == ref["delta"].tolist() and bool(done) == ref["done"] and plen == ref["path_len"]
         assert h == env.hash()
+        # the observation crossed the plain-C boundary too: xr_batch_observation (odd actions) / xr_batch_step_observe (even ones)
+        assert nleg == env.nlegal()
+        assert obs_fnv == fnv(np.ascontiguousarray(env.observation()).tobytes()), a

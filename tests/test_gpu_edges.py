@@ -173,3 +173,49 @@ def test_env_state_dump_and_restore_continues_bit_identically():
         assert torch.equal(oa[e, :n], ob[e, :n])
     with pytest.raises(Exception):
         RegionBatch(regions[:3], n_envs=16, device="cuda:0").load_state_dict(dump)
+
+
+@pytest.mark.gpu
+def test_env_state_restore_is_validated():
+    """xr_batch_store range-checks the arrays the kernels index with (region index, legal bits, nets-left count: XR_ERR_RANGE
+    instead of a device fault in the next step), the dump carries a fingerprint of the regions + step-relevant config it belongs to, and
+    the batch's env-step counter is part of the state."""
+    import torch
+    from xroute_env_amd import _lib
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import generate_region
+    regions = [generate_region(6200 + i, dims=(10, 9, 4), k_range=(2, 5), net_span=5) for i in range(6)]
+    kw = dict(n_envs=8, device="cuda:0", auto_reset=True)
+    a = RegionBatch(regions, **kw)
+    a.reset()
+    acts = torch.empty(8, dtype=torch.int32, device="cuda:0")
+    for i in range(3):
+        a.random_actions(5 + i, acts)
+        a.step(acts)
+    dump = a.state_dict()
+    assert int(dump["steps"][0]) == a.total_steps() > 0
+    b = RegionBatch(regions, **kw)
+    b.load_state_dict(dump)
+    assert b.total_steps() == a.total_steps()
+    # a region index outside the loaded regions
+    bad = dict(dump); bad["region"] = dump["region"].clone(); bad["region"][3] = len(regions)
+    with pytest.raises(_lib.XRouteError) as ei:
+        RegionBatch(regions, **kw).load_state_dict(bad)
+    assert "region" in str(ei.value)
+    # legal bits above the region's nets
+    bad = dict(dump); bad["legal"] = dump["legal"].clone(); bad["legal"][2, 0] |= (1 << 40)
+    with pytest.raises(_lib.XRouteError):
+        RegionBatch(regions, **kw).load_state_dict(bad)
+    bad = dict(dump); bad["nlegal"] = dump["nlegal"].clone(); bad["nlegal"][1] = 1000
+    with pytest.raises(_lib.XRouteError):
+        RegionBatch(regions, **kw).load_state_dict(bad)
+    # same sizes, other content / other step-relevant config: refused by the fingerprint
+    other = [generate_region(6300 + i, dims=(10, 9, 4), k_range=(2, 5), net_span=5) for i in range(6)]
+    if max(r.n_nets for r in other) == max(r.n_nets for r in regions):
+        with pytest.raises(ValueError):
+            RegionBatch(other, **kw).load_state_dict(dump)
+    with pytest.raises(ValueError):
+        RegionBatch(regions, via_cost=900, **kw).load_state_dict(dump)
+    # the batch that refused is still usable
+    b.random_actions(9, acts); a.step(acts); b.step(acts)
+    assert torch.equal(a.fetch("record"), b.fetch("record"))

@@ -200,3 +200,59 @@ def test_auto_router_selection_is_invisible_in_the_results():
     small.random_actions(1, acts[:2048])
     small.step(acts[:2048].contiguous(), o)
     assert small.observe_info() == {"form": 3, "inplace": False, "sweeps": False, "writer_ms": 0.0}
+
+
+def test_exact_headline_launch_observation_bytes_vs_oracle(regions):
+    """The launch bench.py times, exactly: 4096 slots of config 3 (K ~ U[4,36]), `router = 0` (the line-segment sweeps INSIDE the
+    queue kernel, chosen for full rewrites of >= 4096 slots), full-rewrite steps at a staggered (stationary-like) nets-left
+    distribution — against the ORACLE's bytes, not against another HIP form: 64 observations spread over K after each of two
+    steps, every env's deltas / done after each step, and the hash chains of the replayed envs at the end."""
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.batch import RegionBatch
+    dev = "cuda:0"
+    NCHK = 256
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True)          # bench.py's construction (router 0, obs_mode 0)
+    batch.reset(rotate=True)
+    ob = orc.OracleBatch(regions[:NCHK])
+    threads = ob.max_threads()
+    acts = torch.empty(B, dtype=torch.int32, device=dev)
+    # stagger like bench.py: env e advanced by (e * 7) % (K0 + 1) untimed route-only steps -> K spread over 0..36 in one batch
+    nl0 = batch.fetch("nlegal").cpu().numpy()
+    off = (np.arange(B) * 7) % (nl0 + 1)
+    off_d = torch.from_numpy(off).to(dev)
+    zero = torch.zeros_like(acts)
+    for i in range(int(off.max())):
+        batch.random_actions(9000 + i, acts)
+        torch.where(off_d > i, acts, zero, out=acts)
+        batch.step(acts)
+        a = ob.random_actions(9000 + i)
+        a[off[:NCHK] <= i] = 0
+        ob.step(a, threads=threads, auto_reset=True)
+    obs = batch.alloc_observation()
+    N = regions[0].n_nodes
+    checked = 0
+    ks = set()
+    for it in range(2):
+        batch.random_actions(9500 + it, acts)
+        batch.step(acts, obs)
+        info = batch.observe_info()
+        assert info["form"] == 3 and info["sweeps"] and not info["inplace"]        # XR_OBS_QUEUE, sweeps in the queue kernel, full rewrite
+        a = ob.random_actions(9500 + it)
+        assert np.array_equal(acts[:NCHK].cpu().numpy(), a)
+        r = ob.step(a, threads=threads, auto_reset=True)
+        rec = batch.records()
+        assert np.array_equal(np.asarray(rec["delta"])[:NCHK], r["delta"])
+        assert np.array_equal(np.asarray(rec["done"])[:NCHK].astype(bool), r["done"].astype(bool))
+        nl = np.asarray(rec["nlegal"])[:NCHK]
+        order = np.argsort(nl, kind="stable")
+        pick = sorted({int(order[int(round(j))]) for j in np.linspace(0, NCHK - 1, 64)})
+        for e in pick:
+            ro = ob.envs[e].observation().ravel()
+            assert ob.envs[e].nlegal() == nl[e]
+            assert ro.size == (2 + 7 * int(nl[e])) * N
+            assert np.array_equal(obs[e, : ro.size].cpu().numpy(), ro), (it, e, int(nl[e]))
+            ks.add(int(nl[e]))
+            checked += 1
+    assert checked >= 100 and max(ks) >= 30 and min(ks) <= 2              # the whole K range, K up to ~36
+    hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)[:NCHK]
+    assert np.array_equal(hashes, np.array([e.hash() for e in ob.envs], dtype=np.uint64))

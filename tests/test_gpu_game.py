@@ -170,3 +170,23 @@ def test_fixed_shape_dict_spaces_on_the_device():
     for e, s in enumerate(venv.batch.legal_sets()):
         assert sorted(np.nonzero(m[e])[0] + 1) == sorted(s)
     assert venv.observation_space["grid"].shape[0] == 4 and venv.single_observation_space["grid"].shape == (2 + 7 * kmax, 3, 7, 8)
+
+
+def test_vector_env_observations_lie_in_the_advertised_space():
+    """the batched Box is built from the buffer's own env stride (a multiple of 32 floats, >= (2+7*Kmax)*N), so the env's own
+    observations are members of `observation_space`; `dict_observation=True` makes reset() / step() return that Dict."""
+    from xroute_env_amd.envs import XRouteVectorEnv
+    regions = [generate_region(7500 + i, dims=(8, 7, 3), k_range=(2, 5)) for i in range(4)]      # 8*7*3 = 168 nodes: (2+7*5)*168 = 6216 -> stride 6240
+    venv = XRouteVectorEnv(regions)
+    obs, info = venv.reset()
+    assert tuple(obs.shape) == venv.observation_space["grid"].shape == (4, int(venv.batch.obs_env_stride))
+    assert venv.batch.obs_env_stride % 32 == 0 and venv.batch.obs_env_stride >= (2 + 7 * venv.kmax) * 168
+    assert venv.observation_dict() in venv.observation_space
+    denv = XRouteVectorEnv(regions, dict_observation=True)
+    dobs, dinfo = denv.reset()
+    for it in range(4):
+        assert dobs in denv.observation_space
+        assert torch.equal(dobs["grid"], obs)
+        a = denv.random_actions(5 + it)
+        dobs, rew, done, dinfo = denv.step(a)
+        obs, *_ = venv.step(a)

@@ -134,3 +134,22 @@ def test_request_records_access_without_net_follows_handle_messange():
     bad = f.copy(); bad[0, 8] = -3
     with pytest.raises(ValueError):
         proto.request_records(proto.decode_message(proto.encode_request((4, 1, 1), bad, (0, 0, 0), False, [4])))
+
+
+def test_duplicate_vertex_lists_longer_than_the_region_and_two_pins():
+    """a Request may list a vertex several times (the reference looks at every entry on its own), so the list may be longer
+    than X*Y*Z; a vertex under two pins of one net keeps the lowest pin whatever the list order."""
+    import numpy as np
+    from xroute_env_amd.regions import records_from_entries, unpack_records
+    n = 8
+    flat = np.array([0, 1, 2, 3, 4, 5, 6, 7, 3, 3, 5])          # 11 entries for 8 vertices
+    Net = np.array([0, 0, 0, 2, 0, 2, 0, -1, 2, 2, 2])
+    used = np.array([0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0])
+    for perm in (np.arange(11), np.arange(11)[::-1]):
+        Pin = np.array([-1, -1, -1, 3, -1, 2, -1, -1, 1, 3, 4])
+        rec = records_from_entries(n, flat[perm], Net[perm], used[perm], Pin[perm])
+        t, u, net, pin = unpack_records(rec)
+        assert net[3] == 1 and pin[3] == 0 and u[3] == 1           # pins {3,1,3} -> lowest (1-based 1 -> 0-based 0); used if ANY entry says so
+        assert net[5] == 1 and pin[5] == 1 and u[5] == 0           # pins {2,4} -> 2 (0-based 1)
+    with np.testing.assert_raises(ValueError):
+        records_from_entries(n, [3, 3], [2, 3], [0, 0], [1, 1])   # two different NETS on one vertex: not representable

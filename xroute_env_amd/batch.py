@@ -304,8 +304,9 @@ class RegionBatch:
         "env_steps": (_lib.XR_FETCH_ENV_STEPS, torch.int64, lambda s: (s.n_envs,)),
     }
     # the arrays that ARE the env state (xr_batch_store accepts exactly these)
-    _STATE = ("owner", "legal", "nlegal", "cum", "delta", "reward", "done", "status", "path_len", "hash", "region", "replay",
-              "env_steps", "record")
+    # (restore order: `region` first — xr_batch_store checks legal bits and nets-left counts against the region each slot plays)
+    _STATE = ("region", "owner", "legal", "nlegal", "cum", "delta", "reward", "done", "status", "path_len", "hash", "replay",
+              "env_steps", "record", "steps")
 
     def fetch(self, what: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Copy one result array into a device tensor (async on the current stream)."""
@@ -334,13 +335,33 @@ class RegionBatch:
         (baseline/DQN/DQN.py:236-242)."""
         d = {k: self.fetch(k).cpu() for k in self._STATE}
         d["_meta"] = torch.tensor([self.n_envs, self.n_regions, self.n_max, self.legal_words], dtype=torch.int64)
+        d["_fingerprint"] = torch.from_numpy(np.frombuffer(self.fingerprint(), np.uint8).copy())
         return d
+
+    def fingerprint(self) -> bytes:
+        """sha256 over what the env state is a state OF: every region's content (dims, tracks, layer directions, node records, initial
+        metrics, guide boxes) and the config fields that change what a step computes (costs, rotation period, XR-Maze v2 knobs)."""
+        import hashlib
+        h = hashlib.sha256()
+        c = self.cfg
+        h.update(np.array([c.via_cost, c.drc_cost, c.drc_unit, c.max_route_count, c.guide_cost, c.guide_margin, c.maze_end_iter,
+                           len(self.regions)], np.int64).tobytes())
+        for r in self.regions:
+            h.update(np.array([*r.dims, r.n_nets, *[int(v) for v in r.metrics0]], np.int64).tobytes())
+            for a, dt in ((r.xs, np.int32), (r.ys, np.int32), (r.layer_dir, np.uint8), (r.nodes, np.uint32)):
+                h.update(np.ascontiguousarray(a, dt).tobytes())
+            if getattr(r, "guide_off", None) is not None:
+                h.update(np.ascontiguousarray(r.guide_off, np.int32).tobytes())
+                h.update(np.ascontiguousarray(r.guide_box, np.int16).tobytes())
+        return h.digest()
 
     def load_state_dict(self, d: dict):
         """Restore a state_dict() into a batch created with the same regions and config: it continues bit-identically."""
         meta = [int(v) for v in d["_meta"]]
         if meta != [self.n_envs, self.n_regions, self.n_max, self.legal_words]:
             raise ValueError(f"state of a different batch: (n_envs, n_regions, n_max, legal_words) = {meta}")
+        if "_fingerprint" in d and bytes(d["_fingerprint"].numpy().tobytes()) != self.fingerprint():
+            raise ValueError("state of a different batch: the regions or the step-relevant config (costs, rotation, XR-Maze v2 knobs) differ")
         with torch.cuda.device(self.device):
             for k in self._STATE:
                 sel, dtype, shape = self._FETCH[k]

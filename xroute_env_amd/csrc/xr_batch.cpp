@@ -1194,13 +1194,48 @@ int32_t xr_batch_store(xr_batch* b, int32_t what, const void* src_dev, size_t sr
     case XR_FETCH_REPLAY: dst = b->env_replay.p; bytes = B * sizeof(int32_t); break;
     case XR_FETCH_ENV_STEPS: dst = b->env_steps.p; bytes = B * sizeof(int64_t); break;
     case XR_FETCH_RECORD: dst = b->records.p; bytes = B * sizeof(XrStepRecord); break;
+    case XR_FETCH_STEPS: dst = b->total_steps.p; bytes = sizeof(int64_t); break;
     default: return fail(XR_ERR_INVALID, "xr_batch_store: selector %d is not part of the env state", what);
     }
     if (src_bytes != bytes)
         return fail(XR_ERR_RANGE, "xr_batch_store(%d): source holds %zu bytes, the array has %zu", what, src_bytes, bytes);
     XR_HIP(hipSetDevice(b->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // The arrays the kernels INDEX with are validated on the host before they reach the device (a restore is not a hot path: one small
+    // staging copy + a stream sync): a region index outside the loaded regions, or legal bits / a nets-left count beyond the region's
+    // nets, would make the next plan / route kernel read regions[], net_csr[] and net_work[] out of bounds — a device fault, not XR_ERR_RANGE.
+    // Restore order for a consistent check: XR_FETCH_REGION before XR_FETCH_LEGAL / XR_FETCH_NLEGAL (RegionBatch.load_state_dict does).
+    if (what == XR_FETCH_REGION || what == XR_FETCH_LEGAL || what == XR_FETCH_NLEGAL) {
+        std::vector<unsigned char> host(bytes);
+        std::vector<int32_t> reg(B);
+        XR_HIP(hipMemcpyAsync(host.data(), src_dev, bytes, hipMemcpyDefault, st));
+        if (what != XR_FETCH_REGION) XR_HIP(hipMemcpyAsync(reg.data(), b->env_region.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        XR_HIP(hipStreamSynchronize(st));
+        if (what == XR_FETCH_REGION) {
+            const int32_t* r = reinterpret_cast<const int32_t*>(host.data());
+            for (size_t e = 0; e < B; e++)
+                if (r[e] < 0 || r[e] >= b->n_regions)
+                    return fail(XR_ERR_RANGE, "xr_batch_store(region): env %zu -> region %d outside 0..%d", e, r[e], b->n_regions - 1);
+        } else if (what == XR_FETCH_NLEGAL) {
+            const int32_t* nl = reinterpret_cast<const int32_t*>(host.data());
+            for (size_t e = 0; e < B; e++)
+                if (nl[e] < 0 || nl[e] > b->h_n_nets[reg[e]])
+                    return fail(XR_ERR_RANGE, "xr_batch_store(nlegal): env %zu: %d nets left, its region %d has %d", e, nl[e], reg[e], b->h_n_nets[reg[e]]);
+        } else {
+            const uint64_t* lg = reinterpret_cast<const uint64_t*>(host.data());
+            for (size_t e = 0; e < B; e++) {
+                const int K = b->h_n_nets[reg[e]];
+                for (int w = 0; w < b->legal_words; w++) {
+                    const int lo = w * 64;
+                    const uint64_t allowed = K >= lo + 64 ? ~0ULL : (K > lo ? ((1ULL << (K - lo)) - 1ULL) : 0ULL);
+                    if (lg[e * b->legal_words + w] & ~allowed)
+                        return fail(XR_ERR_RANGE, "xr_batch_store(legal): env %zu: net bits beyond the %d nets of its region %d", e, K, reg[e]);
+                }
+            }
+        }
+    }
     b->obs_valid_ptr = nullptr;                       // whatever observation a caller holds no longer describes the batch
-    XR_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
+    XR_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, st));
     return XR_OK;
 }
 

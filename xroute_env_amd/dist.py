@@ -106,6 +106,39 @@ def gather_records_fixed(local: torch.Tensor, out: torch.Tensor, group=None) -> 
     return out
 
 
+def rows_checksum(rows: torch.Tensor) -> torch.Tensor:
+    """Position-weighted int64 checksum of a [n, w] uint8 tensor (a swap of two rows or two bytes changes it); device-only."""
+    flat = rows.reshape(-1).to(torch.int64)
+    w = (torch.arange(flat.numel(), device=rows.device, dtype=torch.int64) % 65521) + 1
+    return (flat * w).sum().reshape(1)
+
+
+def verify_gather(local: torch.Tensor, gathered: torch.Tensor, lo: int, group=None) -> dict:
+    """Self-certification of the batched-env gather: every rank sends (rank, lo, rows, checksum of its LOCAL records); every rank
+    then recomputes the checksum of the matching slice of what the collective delivered to IT.  Returns
+    {"ranks_seen": distinct ranks that answered, "gather_verified": every slice on every rank equals its owner's local rows,
+     "rows": total rows}.  One tiny all_gather + one all_reduce; call it outside the timed region."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = local.device
+    mine = torch.cat([torch.tensor([rank, lo, local.shape[0]], dtype=torch.int64, device=dev), rows_checksum(local)])
+    if world == 1:
+        ok = bool(torch.equal(local, gathered[lo:lo + local.shape[0]]))
+        return {"ranks_seen": 1, "gather_verified": ok, "rows": int(local.shape[0])}
+    table = torch.empty((world, 4), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(table, mine.reshape(1, 4), group=group)
+    t = table.cpu().tolist()
+    ok = True
+    for r_, lo_, n_, sum_ in t:
+        if lo_ < 0 or lo_ + n_ > gathered.shape[0] or int(rows_checksum(gathered[lo_:lo_ + n_]).item()) != sum_:
+            ok = False
+    covered = sorted((lo_, lo_ + n_) for _, lo_, n_, _ in t)
+    ok = ok and covered[0][0] == 0 and covered[-1][1] == gathered.shape[0] and all(a[1] == b_[0] for a, b_ in zip(covered, covered[1:]))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return {"ranks_seen": len({r_ for r_, *_ in t}), "gather_verified": bool(flag.item() == 1), "rows": int(sum(n_ for _, _, n_, _ in t))}
+
+
 def first_legal_policy(records: dict, legal: torch.Tensor) -> torch.Tensor:
     """A deterministic stand-in learner policy: the lowest legal net of every env (0 when none).  legal: int64[n, words],
     bit n-1 of the row <=> net n in netSet."""

@@ -82,15 +82,18 @@ def backend():
         return sys.modules[__name__]
 
 
-def fixed_spaces(dims, kmax: int, batch: int = 0, sp=None):
+def fixed_spaces(dims, kmax: int, batch: int = 0, sp=None, row: int = 0):
     """(observation_space, action_space) of the fixed-shape form for regions of `dims` = (X, Y, Z) with at most `kmax` nets.
-    batch > 0: the vector env's batched spaces (grid rows are flat: [batch, Cmax * N], the layout of the device buffer)."""
+    batch > 0: the vector env's batched spaces (grid rows are flat: [batch, row], the layout of the device buffer: row =
+    the buffer's env stride >= Cmax * N — xr_batch_sizes rounds it up to whole 128-byte lines; 0: exactly Cmax * N)."""
     sp = sp or backend()
     X, Y, Z = (int(v) for v in dims)
     kmax = max(int(kmax), 1)
     cmax = 2 + 7 * kmax
     if batch:
-        grid = sp.Box(low=0.0, high=float(kmax), shape=(batch, cmax * X * Y * Z), dtype=np.float32)
+        if row and row < cmax * X * Y * Z:
+            raise ValueError("row stride shorter than the observation")
+        grid = sp.Box(low=0.0, high=float(kmax), shape=(batch, int(row) if row else cmax * X * Y * Z), dtype=np.float32)
         mask = sp.MultiBinary((batch, kmax))
     else:
         grid = sp.Box(low=0.0, high=float(kmax), shape=(cmax, Z, Y, X), dtype=np.float32)

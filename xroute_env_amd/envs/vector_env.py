@@ -17,12 +17,18 @@ from ..dist import RECORD_BYTES, unpack_records
 
 class XRouteVectorEnv:
     def __init__(self, regions: Sequence, n_envs: Optional[int] = None, device="cuda:0", with_observation: bool = True,
-                 **batch_kw):
+                 dict_observation: bool = False, **batch_kw):
+        """dict_observation: reset() / step() return the observation as the advertised Dict space's member
+        {"grid": [B, stride] fp32, "legal_mask": [B, Kmax] u8} instead of the bare grid tensor (the default: the hot loop's
+        consumers — agents.dqn_actions / ppo_actions — take the grid buffer and the legal bitmasks of `info` as they are)."""
         self.batch = RegionBatch(regions, n_envs=n_envs, device=device, auto_reset=True, **batch_kw)
         self.n_envs = self.batch.n_envs
         self.device = self.batch.device
         self.with_observation = with_observation
-        self.obs = self.batch.alloc_observation() if with_observation else None
+        self.dict_observation = bool(dict_observation)
+        # (zeros, not empty: a row beyond its env's (2+7K)*N floats then only ever holds zeros or stale 0/1 planes of earlier steps —
+        #  inside the Box's bounds; consumers go by nlegal / legal_mask)
+        self.obs = self.batch.alloc_observation().zero_() if with_observation else None
         # the 48-byte xr_step_record of every env, written by the step / reset kernels themselves: ONE copy per step;
         # reward / done / delta / nlegal below are views into it
         self.record = torch.empty((self.n_envs, RECORD_BYTES), dtype=torch.uint8, device=self.device)
@@ -39,8 +45,12 @@ class XRouteVectorEnv:
         if len(dims) == 1:
             d = dims.pop()
             self.single_observation_space, self.single_action_space = xr_spaces.fixed_spaces(d, self.kmax)
-            self.observation_space, _ = xr_spaces.fixed_spaces(d, self.kmax, batch=self.n_envs)
+            self.observation_space, _ = xr_spaces.fixed_spaces(d, self.kmax, batch=self.n_envs, row=int(self.batch.obs_env_stride))
             self.action_space = self.single_action_space
+
+    def observation_dict(self) -> dict:
+        """The current observation as a member of `observation_space`: the grid buffer itself (no copy) + the legal mask."""
+        return {"grid": self.obs, "legal_mask": self.legal_mask()}
 
     def legal_mask(self) -> torch.Tensor:
         """uint8 [B, Kmax] (the `legal_mask` of the Dict space): bit n-1 of an env's row <=> net n is in its netSet; a device op on
@@ -57,7 +67,7 @@ class XRouteVectorEnv:
         b.fetch("done", self.done)
         b.fetch("legal", self.legal)
         b.fetch("region", self.region)          # the region every slot is playing (key of agents.NetVectorCache)
-        return self.obs, self.reward, self.done, {"delta": self.delta, "nlegal": self.nlegal, "legal": self.legal,
+        return (self.observation_dict() if self.dict_observation and self.with_observation else self.obs), self.reward, self.done, {"delta": self.delta, "nlegal": self.nlegal, "legal": self.legal,
                                                   "region": self.region, "record": self.record, "cum": self.cum}
 
     def reset(self):

@@ -137,8 +137,8 @@ def request_records(msg: DecodedMessage):
     net = np.full(n, -1, np.int64)
     pin = np.full(n, -1, np.int64)
     if len(f):
-        if len(f) > n:
-            raise ValueError(f"Request lists {len(f)} nodes for a {X}x{Y}x{Z} region")
+        # (a list may name a vertex several times — per-entry meaning, records_from_entries — so its length is not bounded by n;
+        #  only the indices are checked)
         m = f[:, 0:3]
         if (m < 0).any() or (m[:, 0] >= X).any() or (m[:, 1] >= Y).any() or (m[:, 2] >= Z).any():
             raise ValueError("maze index outside the region dimensions")

@@ -52,7 +52,10 @@ def records_from_entries(n: int, flat, Net, used, Pin) -> np.ndarray:
     (Net == -1, or occupied), and an access point of net n if ANY of its entries says so.  `Net` follows handle_messange:
     -1 blockage, 0 plain node, >= 1 the 1-based net of an access point; `Pin` 1-based or -1.  In dense form an obstacle that is also
     an access point is a used ACCESS node — the same observation.  Not representable (ValueError): one vertex as an access point
-    of two different nets.  Vertices the list does not mention are unused NORMAL nodes."""
+    of two different nets.  One vertex listed under two different PINS of the same net (the reference appends it to both pins' lists,
+    :37-43; its observation only asks "access point of this net, any pin", :126-138, so the tensor is the same) keeps the LOWEST pin
+    in the one-pin-per-node record — deterministic whatever the list order; only the build-defined router sees pins.
+    Vertices the list does not mention are unused NORMAL nodes."""
     flat = np.asarray(flat, np.int64)
     Net = np.asarray(Net, np.int64)
     used = np.asarray(used, np.int64) == 1
@@ -76,7 +79,9 @@ def records_from_entries(n: int, flat, Net, used, Pin) -> np.ndarray:
         ntype[any_acc] = ACCESS
         u[any_used | (any_blk & any_acc)] = 1
         net[flat[acc]] = Net[acc] - 1
-        pin[flat[acc]] = np.maximum(Pin[acc] - 1, -1)
+        plo = np.full(n, np.iinfo(np.int64).max, np.int64)
+        np.minimum.at(plo, flat[acc], np.maximum(Pin[acc] - 1, -1))
+        pin[any_acc] = plo[any_acc]
     return pack_records(ntype, u, net, pin)
 
 
