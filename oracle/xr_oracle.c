@@ -24,7 +24,7 @@
 #define T_ACCESS 2u
 #define OWNER_FOREIGN 0x7FFF
 #define INF32 0xFFFFFFFFu
-#define DIST_CAP 0x30000000u   /* XR-Maze v1: distances >= DIST_CAP do not exist (such a node is unreachable) */
+#define DIST_CAP 0x07F00000u   /* XR-Maze v1: distances >= DIST_CAP do not exist (such a node is unreachable) */
 
 #define ENV_BAD_ACTION 1
 #define ENV_UNREACHABLE 2

@@ -100,7 +100,17 @@ def _worker(rank, world, port, q):
     eq_lo, eq_hi = shard_range(10, world, rank)
     eq = torch.full((eq_hi - eq_lo, RECORD_BYTES), rank, dtype=torch.uint8)
     eq_all = gather_records(eq)
-    q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy()))
+    # self-certification of the gather (bench.py's N > 1 line): equal shards, ragged shards, and a slice corrupted on ONE rank only
+    from xroute_env_amd.dist import verify_gather
+    local = torch.arange((eq_hi - eq_lo) * RECORD_BYTES, dtype=torch.int64).reshape(-1, RECORD_BYTES).add(37 * rank).to(torch.uint8)
+    cert = [verify_gather(local, gather_records(local), eq_lo)]
+    rl = plain[-1][lo:hi].clone()                                  # ragged: this rank's rows of the last plain gather
+    cert.append(verify_gather(rl, gather_records(rl), lo))
+    bad = gather_records(local).clone()
+    if rank == 1:
+        bad[0, 3] ^= 0x40                                          # rank 1 received a wrong byte in rank 0's slice
+    cert.append(verify_gather(local, bad, eq_lo))
+    q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy(), cert))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -163,8 +173,11 @@ def test_two_rank_learner_flow_equals_single_process():
         assert p.exitcode == 0
     single_recs, single_sent, _ = _run_learner(N_TOTAL, STEPS)
     for rank in (0, 1):
-        recs, sent, (lo, hi), plain, eq_all = got[rank]
+        recs, sent, (lo, hi), plain, eq_all, cert = got[rank]
         assert len(recs) == STEPS
+        assert cert[0] == {"ranks_seen": 2, "gather_verified": True, "rows": 10}
+        assert cert[1] == {"ranks_seen": 2, "gather_verified": True, "rows": N_TOTAL}
+        assert cert[2]["gather_verified"] is False and cert[2]["ranks_seen"] == 2       # BOTH ranks learn that one of them saw a bad slice
         for g, s in zip(recs, single_recs):                     # every rank holds every env's record
             assert g.shape == (N_TOTAL, RECORD_BYTES) and np.array_equal(g, s.numpy())
         for a, s in zip(sent, single_sent):                     # the broadcast actions are the rank's slice of the learner's

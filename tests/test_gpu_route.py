@@ -15,7 +15,8 @@ def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
     from oracle import xr_oracle as orc
     from xroute_env_amd.batch import RegionBatch
     batch = RegionBatch(regions, device="cuda:0", **kw)
-    envs = [orc.OracleEnv(r, kw.get("via_cost", 800), kw.get("drc_cost", 8), kw.get("drc_unit", 400)) for r in regions]
+    v2 = {k: kw[k] for k in ("guide_cost", "guide_margin", "maze_end_iter") if k in kw}
+    envs = [orc.OracleEnv(r, kw.get("via_cost", 800), kw.get("drc_cost", 8), kw.get("drc_unit", 400), **v2) for r in regions]
     batch.reset()
     rng = np.random.default_rng(5)
     total = 0
@@ -478,3 +479,20 @@ def test_round_cap_aborts_the_net_not_the_device(kw):
     ok.reset()
     ok.step(torch.tensor([1] * 16, dtype=torch.int32, device="cuda:0"))
     assert not np.any(ok.fetch("status").cpu().numpy() & _lib.XR_ENV_ROUTER_ABORT)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(router=3), dict(router=1), dict(force_scratch_field=True),
+                                dict(maze_end_iter=2), dict(maze_end_iter=2, force_scratch_field=True)],
+                         ids=["lds", "lds-round2", "sweeps", "scratch", "lds-v2", "scratch-v2"])
+def test_distance_cap_rule_in_every_router_form(kw):
+    """Spec: a distance >= XR_DIST_CAP = 0x07F00000 does not exist.  A track of nodes held by a pre-routed
+    wire, 1 040 000 per node: the pin 128 columns away is reached at 132.1 M, the one 129 away is not (unreachable: one violation,
+    flagged), and a third pin 140 columns beyond the grown component is not either — identically in the oracle and in every router
+    form.  (Round 3's LDS form is selected by `step < 2^20`, no longer by N x step < 2^27: the cap is what keeps its word wrap-free.)"""
+    from tests.test_oracle_router import cap_region
+    pen = dict(via_cost=800, drc_cost=1040, drc_unit=1000)
+    if kw.get("maze_end_iter", 1) > 1:              # attempt 0 reaches every pin over held nodes -> ripped up; attempt 1 doubles the penalty to 1 040 000
+        pen = dict(via_cost=800, drc_cost=520, drc_unit=1000)
+    regions = [cap_region(targets=(t,)) for t in (127, 128, 129, 130)] + [cap_region(targets=(120, 260))]
+    n = _run_episode_parity(regions, **pen, **kw)
+    assert n == len(regions)

@@ -98,3 +98,39 @@ def test_single_pin_net_and_bad_actions():
     r = env.step(1)
     assert r["status"] == 0 and r["delta"].tolist() == [0, 0, 0] and r["done"] and r["path_len"] == 0
     assert env.step(1)["status"] == 1 and env.step(0)["status"] == 1 and env.step(7)["status"] == 1
+
+
+def cap_region(n_cols=300, targets=(120, 140), pitch=400):
+    """One horizontal track of `n_cols` nodes (Y = 2, Z = 1; row 1 is blocked) whose every node between the pins is a used NORMAL node
+    (a pre-routed foreign wire: passable at the drc penalty).  Net 1 has pin 1 at x = 0 and one pin at every column of `targets`."""
+    from xroute_env_amd.regions import ACCESS, BLOCKAGE, NORMAL, Region, pack_records
+    X, Y, Z = n_cols, 2, 1
+    n = X * Y * Z
+    ntype = np.full(n, NORMAL, np.int64); used = np.ones(n, np.int64); net = np.full(n, -1, np.int64); pin = np.full(n, -1, np.int64)
+    f = lambda x, y: (x * Y + y) * Z
+    for x in range(X):
+        ntype[f(x, 1)] = BLOCKAGE
+    for p, x in enumerate((0,) + tuple(targets)):
+        ntype[f(x, 0)] = ACCESS; used[f(x, 0)] = 0; net[f(x, 0)] = 0; pin[f(x, 0)] = p
+    return Region(dims=(X, Y, Z), xs=np.arange(X, dtype=np.int32) * pitch, ys=np.arange(Y, dtype=np.int32) * pitch,
+                  layer_dir=np.zeros(Z, np.uint8), nodes=pack_records(ntype, used, net, pin), n_nets=1)
+
+
+def test_distance_cap_rule():
+    """Spec: a distance >= XR_DIST_CAP = 0x07F00000 does not exist — such a node is unreachable.  With a penalty of
+    1 040 000 per held node the pin 120 columns from the component costs 119 x 1 040 400 + 400 = 123.8 M (reached; the target itself is
+    this net's access point: no penalty); the next pin, 140 columns beyond the grown component, would cost 144.6 M >= 133.2 M:
+    unreachable, one violation, flagged."""
+    reg = cap_region(targets=(120, 260))
+    env = orc.OracleEnv(reg, via_cost=800, drc_cost=1040, drc_unit=1000)
+    d = env.distance_field(1)[::2]
+    assert d[120] == 119 * 1040400 + 400 and d[128] < 0x07F00000 <= d[128] + 1040400 and d[129] == 0xFFFFFFFF      # the field stops at the cap
+    r = env.step(1)
+    assert r["status"] & 2                                         # XR_ENV_UNREACHABLE
+    assert r["path_len"] == 121 and r["delta"].tolist() == [119 + 1, 120 * 400, 0]
+    # the edge of the cap: 127 held nodes + the target = 127 x 1 040 400 + 400 = 132.13 M < 133.17 M; one more column is over it
+    for col, ok in ((128, True), (129, False)):
+        e2 = orc.OracleEnv(cap_region(targets=(col,)), via_cost=800, drc_cost=1040, drc_unit=1000)
+        r2 = e2.step(1)
+        assert bool(r2["status"] & 2) == (not ok), (col, r2)
+        assert r2["path_len"] == (col + 1 if ok else 0)

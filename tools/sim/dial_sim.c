@@ -7,7 +7,7 @@
 #include <string.h>
 #include <stdio.h>
 
-#define CAP 0x30000000u
+#define CAP 0x07F00000u
 #define UNREACHED 0xFFFFFFFDu
 
 int g_astar = 0;      /* 1: buckets keyed on f = d + h(v), h = distance to the bounding box of the unconnected targets */

@@ -266,7 +266,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     std::vector<float> hwork;            // per (region, net): predicted route work (launch order of route-only launches)
     std::vector<int32_t> hinfo;          // per (region, net): static facts for xr_dial3.h (XrBatchDev::net_info)
     std::vector<uint8_t> hap_flags;      // per access point: bit 0 = its pin sits in a closed pocket
-    int64_t edge_max = b->cfg.via_cost;  // longest edge of any region graph (distance range check of xr_dial3.h)
+    int64_t edge_max = b->cfg.via_cost;  // longest edge of any region graph (range checks of xr_dial3.h)
+    int64_t ext_max = 0;                 // widest span of a region's tracks in x or y, DBU
     std::map<uint64_t, uint64_t> magic_cache;   // (divisor, limit) -> multiplier << 8 | shift (0xFF: none)
     bool div24_all = true;               // every region has its exact 24-bit division constants
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
@@ -398,6 +399,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             const int Xd = d.dim_x, Yd = d.dim_y, Zd = d.dim_z, YZd = Yd * Zd;
             for (int i = 1; i < Xd; i++) edge_max = std::max<int64_t>(edge_max, d.xs_host[i] - d.xs_host[i - 1]);
             for (int i = 1; i < Yd; i++) edge_max = std::max<int64_t>(edge_max, d.ys_host[i] - d.ys_host[i - 1]);
+            ext_max = std::max<int64_t>(ext_max, std::max<int64_t>((int64_t)d.xs_host[Xd - 1] - d.xs_host[0], (int64_t)d.ys_host[Yd - 1] - d.ys_host[0]));
             auto blocked = [&](int f) { return XR_REC_TYPE(d.nodes_host[f]) == XR_TYPE_BLOCKAGE; };
             std::vector<int> seen_pins, pocket;
             for (int n = 1; n <= d.n_nets; n++) {
@@ -565,12 +567,15 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             }
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : big_threads;
         }
-        // round 3's LDS form (xr_dial3.h) where it applies: the field fits with its queues, node ids fit 16 bits, and no distance
-        // can exceed the 27 bits its field word holds — (N + 1) x (longest edge + largest penalty) bounds every simple path
+        // round 3's LDS form (xr_dial3.h) where it applies: the field fits with its queues, node ids fit 16 bits, and its 27-bit distance
+        // arithmetic cannot wrap: every distance that exists is below XR_DIST_CAP = 0x07F00000 (spec; a candidate at or above the cap is
+        // never written), so a reached word + one edge with every penalty stays inside 32 bits while that step is < 2^20 (the x32
+        // fixed point of the word); the x32 coordinate tables and the heuristic need a region that spans < 2^25 DBU
         {
             const size_t d3_lds = XR3_LDS_BYTES(b->n_max, x_max, y_max);
             const int64_t pen_max = ((int64_t)b->cfg.drc_cost * b->cfg.drc_unit) << (b->cfg.maze_end_iter - 1);
-            const bool range_ok = ((int64_t)b->n_max + 1) * (edge_max + pen_max + b->cfg.guide_cost) < XR3_DIST_LIMIT;
+            const bool range_ok = edge_max + pen_max + b->cfg.guide_cost < XR3_STEP_LIMIT && ext_max < XR3_EXTENT_LIMIT &&
+                                  (int64_t)b->cfg.via_cost * 32 < XR3_EXTENT_LIMIT;
             if (b->kzch == -1 && b->lds_dist && b->cfg.router != XR_ROUTER_DIAL_R2 && range_ok && b->n_max < 65536 && div24_all &&
                 d3_lds + kLdsStatic <= kLdsLimit) {
                 b->kzch = -3;

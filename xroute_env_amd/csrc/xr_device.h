@@ -25,7 +25,8 @@
 #endif
 #define XR3_LDS_BYTES(n_max, x_max, y_max) ((size_t)(n_max) * 4 + 3 * ((size_t)(n_max) / 32 + 1) * 4 + \
                                             ((size_t)(x_max) + (size_t)(y_max) + 4) * 4 + (size_t)XR3_TMP * 2 + 16)
-#define XR3_DIST_LIMIT ((1ll << 27) - 64)     // the form's field word holds 27 distance bits
+#define XR3_STEP_LIMIT (1ll << 20)     // one edge + every penalty it can carry (the word's x32 fixed point: cap x 32 + step x 32 < 2^32)
+#define XR3_EXTENT_LIMIT (1ll << 25)   // widest track span of a region (x32 coordinate tables; heuristic sums of two spans + 31 via costs in 31 bits)
 
 // One region (static after xr_batch_load_regions). Node arrays are in the reference observation's
 // flat order f = (x*Y + y)*Z + z.

@@ -12,10 +12,19 @@
 //    its first tight predecessor (every tight predecessor u of such a node has d(u) + h(u) <= best too, so it was expanded with
 //    its final distance and its candidate word took part in the min).  A node is re-opened only when its DISTANCE went down.
 //    The back-trace is a pointer chase: one LDS read per node, by one wave, while the others wait at the barrier.
-//    27 distance bits: the host only selects this form when (N + 1) * (longest edge + penalty) < 2^27 (else: xr_dial.h).
+//    27 distance bits: every distance the spec knows is below XR_DIST_CAP = 0x07F00000 ("a distance >= the cap does
+//    not exist"), a candidate at or above the cap is never written, and the host only selects this form when one edge plus every
+//    penalty stays below 2^20 and the region spans less than 2^25 DBU — so no sum can wrap the word (else: xr_dial.h).
 //  * Isolated pins (closed pockets) and the per-net constants (first pin, number of pins) are static: decided at load
 //    (xr_batch_load_regions), one word per net — no flood, no pin census per route.
 //  * Path nodes are listed while the chase runs and become sources / get claimed in parallel afterwards (no claim mask).
+//
+//  * XR-Maze v2 (round 4): bit 0 of the word is "outside the net's guide" instead of "valid" (a v2 source word carries bit 3, so only
+//    blockages are 0) — the guide test of a hop and of a trace step is a bit of a word that is loaded anyway, decided once per route
+//    by one LDS pass over the nodes.  Claims are DEFERRED: an attempt writes nothing to global memory but its path list; whether a
+//    node can be claimed is in its word (not held <=> owner 0 or this net), a ripped-up attempt is undone by an LDS-only pass that
+//    returns every word to "unreached" (the static bits stay), and the attempt that stands is accepted by one scan of the words
+//    (source + owner bit + not held -> owner = net).  No owner reads, no N-wide global passes, no field rebuild per attempt.
 //
 // Two other search organisations were built on this word format and measured this round (git history of this file): ONE searching
 // wave with explicit bucket queues and wave-uniform counters (mean route -30 %, but a route with a wide frontier — 60 rounds — took
@@ -26,7 +35,9 @@
 
 // XR3_TMP and XR3_LDS_BYTES: xr_device.h (the host sizes the launch from them)
 #define XR3_UNREACHED 0xFFFFFFFDu      // | held << 1   (dist bits all ones, pdir 7)
+#define XR3_UNREACHED_V2 0xFFFFFFFCu   // | held << 1 | outside the guide   (XR-Maze v2: bit 0 is the guide bit)
 #define XR3_DMAX 0x07FFFFFFu           // distance of an unreached word
+#define XR3_CAP5 ((uint32_t)(XR_W_USABLE_END >> 2) << 5)     // XR_DIST_CAP x 32: candidates at or above it do not exist (spec)
 #define XR3_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -71,7 +82,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ unsigned short s_qn[XR_QUAD_POOL];
     __shared__ int s_remaining, s_abort;
     __shared__ int s_gb[4], s_retry, s_ngb;                     // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
-    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                  // ... and its guide (xr_guide_load, xr_dial.h)
+    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                  // ... and its guide (xr_guide_load, xr_dial.h): only read by the marking pass
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -143,7 +154,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                 for (int j = 0; j < 8; j++) {
                     const int nn = (int)(short)((j & 1) ? (pn[j >> 1] >> 16) : (pn[j >> 1] & 0xFFFF));
                     const int ow = (int)(short)((j & 1) ? (po[j >> 1] >> 16) : (po[j >> 1] & 0xFFFF));
-                    const uint32_t ww = XR3_UNREACHED | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
+                    const uint32_t ww = (V2 ? XR3_UNREACHED_V2 : XR3_UNREACHED) | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
                     w[j] = (nn == -1 || f0 + j >= N) ? 0u : ww;
                 }
                 uint4* dst = reinterpret_cast<uint4*>(field + f0);
@@ -196,21 +207,48 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     uint32_t pen5 = (uint32_t)b.pen_cost << 5;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
     const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;  // bucket width (keys f = d + h, DBU)
     const uint32_t guide5 = V2 ? (uint32_t)b.guide_cost << 5 : 0u;
+    const uint32_t sh_yz = R.s24 & 31u, sh_z = (R.s24 >> 8) & 31u, sh_mw = (R.s24 >> 16) & 31u;
+    auto node_xyz = [&](uint32_t f, int& x, int& y, int& z) __attribute__((always_inline)) {
+        uint32_t ux, ur, uy, uz;
+        xr3_divmod(f, uYZ, R.m24_yz, sh_yz, ux, ur);
+        xr3_divmod(ur, uZ, R.m24_z, sh_z, uy, uz);
+        x = (int)ux; y = (int)uy; z = (int)uz;
+    };
     if (V2 && b.guide_cost) {
+        // ---- guide membership as data (round 4): ONE pass over the nodes sets bit 0 of every word outside the net's guide (<= 8 box
+        // tests per node, boxes unpacked once per 8-node chunk); a hop and a trace step then test a bit of a word they load anyway.
         xr_guide_load(b, R, a, s_gb, Z, s_gbx, &s_ngb, tid);
         __syncthreads();
+        const int ngb = s_ngb;
+        const int nchunk = (N + 7) >> 3;
+        for (int ci = tid; ci < nchunk; ci += nthr) {
+            const int f0 = ci << 3;
+            int x, y, z;
+            node_xyz((uint32_t)f0, x, y, z);
+            uint32_t in = 0u;                                  // bit j: node f0 + j lies inside some box
+            for (int g = 0; g < ngb; g++) {
+                const int4 bx = s_gbx[g];
+                const int x0 = bx.x & 0xFFFF, x1 = (int)((uint32_t)bx.x >> 16), y0 = bx.y & 0xFFFF, y1 = (int)((uint32_t)bx.y >> 16);
+                const int z0 = bx.z & 0xFFFF, z1 = (int)((uint32_t)bx.z >> 16);
+                int xx = x, yy = y, zz = z;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    in |= (uint32_t)(xx >= x0 && xx <= x1 && yy >= y0 && yy <= y1 && zz >= z0 && zz <= z1) << j;
+                    if (++zz == Z) { zz = 0; if (++yy == Y) { yy = 0; xx++; } }
+                }
+            }
+            if ((in & 0xFFu) != 0xFFu) {
+                uint4* dst = reinterpret_cast<uint4*>(field + f0);
+                uint4 lo = dst[0], hi = dst[1];
+                lo.x |= (lo.x != 0u && !(in & 1u)) ? 1u : 0u;   lo.y |= (lo.y != 0u && !(in & 2u)) ? 1u : 0u;
+                lo.z |= (lo.z != 0u && !(in & 4u)) ? 1u : 0u;   lo.w |= (lo.w != 0u && !(in & 8u)) ? 1u : 0u;
+                hi.x |= (hi.x != 0u && !(in & 16u)) ? 1u : 0u;  hi.y |= (hi.y != 0u && !(in & 32u)) ? 1u : 0u;
+                hi.z |= (hi.z != 0u && !(in & 64u)) ? 1u : 0u;  hi.w |= (hi.w != 0u && !(in & 128u)) ? 1u : 0u;
+                dst[0] = lo; dst[1] = hi;
+            }
+        }
+        __syncthreads();
     }
-    const int ngb = (V2 && b.guide_cost) ? s_ngb : 0;
-    int4 gb0 = make_int4(0, 0, 0, 0);
-    if (V2 && b.guide_cost) {
-        const int4 t = s_gbx[0];
-        gb0 = make_int4(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y), __builtin_amdgcn_readfirstlane(t.z), 0);
-    }
-    auto guide_of = [&](int x, int y, int z) __attribute__((always_inline)) -> uint32_t {
-        if (!V2) return 0u;
-        return (guide5 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide5 : 0u;
-    };
-    const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);   // rip-up: claims are tentative (-a) until the attempt stands
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
     int attempt = 0;
 
@@ -223,13 +261,6 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     // predecessor direction stored in the NEIGHBOUR's word (pointing back at the quad's node), E,S,W,N,U,D = 0..5
     const uint32_t pdH = (planar ? (sgn > 0 ? 2u : 0u) : (sgn > 0 ? 5u : 4u)) << 2, pdV = (planar ? (sgn > 0 ? 1u : 3u) : (sgn > 0 ? 5u : 4u)) << 2;
 
-    const uint32_t sh_yz = R.s24 & 31u, sh_z = (R.s24 >> 8) & 31u, sh_mw = (R.s24 >> 16) & 31u;
-    auto node_xyz = [&](uint32_t f, int& x, int& y, int& z) __attribute__((always_inline)) {
-        uint32_t ux, ur, uy, uz;
-        xr3_divmod(f, uYZ, R.m24_yz, sh_yz, ux, ur);
-        xr3_divmod(ur, uZ, R.m24_z, sh_z, uy, uz);
-        x = (int)ux; y = (int)uy; z = (int)uz;
-    };
     // node f <-> (word f % mw, bit f / mw) of the node bitmasks
     auto mask_pos = [&](uint32_t f, uint32_t& q, uint32_t& r) __attribute__((always_inline)) { xr3_divmod(f, umw, R.m24_mw, sh_mw, q, r); };
     // a node becomes a source: distance 0, open
@@ -240,11 +271,12 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         uint32_t q, r;
         mask_pos(f, q, r);
         const uint32_t w0 = field[f];
-        field[f] = (w0 & ((w0 >> 5) == 0u ? 7u : 3u)) | (owned ? 4u : 0u);
+        field[f] = (w0 & ((w0 >> 5) == 0u ? 7u : 3u)) | (owned ? 4u : 0u) | (V2 ? 8u : 0u);    // (v2: bit 0 is the guide bit, so bit 3 keeps a source != 0)
         atomicOr(&s_open[r], 1u << q);
         s_wmin[r] = 0u;                       // (racing plain stores of the same value)
     };
 
+    const uint64_t h0 = wv == sw ? b.hash[e] : 0ULL;        // (a ripped-up attempt rewinds the chain to here)
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     // component = all access points of the lowest pin id
     for (int i = tid; i < nap; i += nthr)
@@ -252,7 +284,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     if (tid == 0) { s_remaining = npins - 1 - n_isolated; s_abort = 0; }
     // the tracing wave's bookkeeping (uniform over that wave; meaningless in the others)
     int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0, nrounds = 0;
-    uint64_t h = wv == sw ? b.hash[e] : 0ULL;
+    uint64_t h = h0;
 
     for (;;) {
         // ---- new search: sources are open with distance 0; deferred nodes are looked at again ------------
@@ -408,12 +440,12 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const uint32_t ca = vert ? yq : xq;
                         const uint32_t dlt = cb - ca, adl = (int)dlt < 0 ? 0u - dlt : dlt;
                         const uint32_t len5 = planar ? adl : via5;
-                        const int nx = gx + ((planar && !vert) ? sgn : 0), ny = gy + ((planar && vert) ? sgn : 0), nz = gz + (planar ? 0 : sgn);
-                        const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + guide_of(nx, ny, nz);
+                        const int nz = gz + (planar ? 0 : sgn);
+                        const uint32_t cand5 = (gw & ~31u) + len5 + ((wn & 2u) ? pen5 : 0u) + ((V2 && (wn & 1u)) ? guide5 : 0u);
                         const uint32_t cw = cand5 | (vert ? pdV : pdH) | (wn & 3u);
                         const uint32_t key = (cand5 >> 5) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
                         // blockage, or no improvement of the WORD (distance, then predecessor direction): nothing to do
-                        const bool go = inb && wn != 0u && gw < 0xFFFFFFE0u && cand5 < 0xFFFFFFC0u && cw < wn;
+                        const bool go = inb && wn != 0u && gw < 0xFFFFFFE0u && cand5 < XR3_CAP5 && cw < wn;     // (gw reached => below the cap: the sum cannot wrap)
                         const bool refused = go && key > best;                                 // bound pruning (on f)
                         bool improved = false;
                         if (go && !refused) {
@@ -448,9 +480,6 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             lmin = xr3_wave_min(lmin);
             if (lane == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
             if (wv == sw) nrounds++;
-#ifdef XR_PHASE_TIMING
-            if (tid == XR_TIMING_TID) _ph[7] += 1;
-#endif
             xr_lds_barrier();
             XR_LAP(6);
             cur = nx1;
@@ -485,8 +514,6 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     // in parallel afterwards.
                     int v = tf, np = 0;
                     uint32_t vw = field[v];
-                    int x = 0, y = 0, z = 0;
-                    if (V2) node_xyz((uint32_t)v, x, y, z);
                     auto flush = [&]() __attribute__((always_inline)) {        // the listed path nodes: sources of the next search, claimed if nobody holds them
                         XR3_WSYNC();
                         const int pl0 = plen - np;              // (the listed nodes are path[pl0 .. plen): one coalesced store per 64 nodes —
@@ -497,10 +524,9 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                             if (pl0 + i < b.path_cap) path[pl0 + i] = (int)f;
                             make_source(f, true);               // (whatever it was before: it has an owner from here on)
                             // claimed if nobody holds it.  Not held (bit 1 clear) = owner 0 or this net itself (a used access point of
-                            // it): the store of `a` is right in both cases and needs no load.  XR-Maze v2's claims are tentative (-a,
-                            // undone by a rip-up), so there the owner is read.
-                            if (!V2 && !(w0 & 2u)) owner[f] = claim_val;
-                            else if (owner[f] == 0) owner[f] = claim_val;
+                            // it): the store of `a` is right in both cases and needs no load.  XR-Maze v2 defers the store to the
+                            // attempt that stands (the acceptance scan below finds these words: source + owner bit + not held).
+                            if (!V2 && !(w0 & 2u)) owner[f] = (int16_t)a;
                         }
                         XR3_WSYNC();
                         np = 0;
@@ -511,13 +537,12 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         const int off = pd == 0u ? YZ : pd == 1u ? -Z : pd == 2u ? -YZ : pd == 3u ? Z : pd == 4u ? 1 : -1;
                         const int u = v + off;
                         const uint32_t uw = field[u];
-                        const uint32_t step5 = (vw & ~31u) - (uw & ~31u) - ((vw & 2u) ? pen5 : 0u) - guide_of(x, y, z);   // the edge itself, x32
+                        const uint32_t step5 = (vw & ~31u) - (uw & ~31u) - ((vw & 2u) ? pen5 : 0u) - ((V2 && (vw & 1u)) ? guide5 : 0u);   // the edge itself, x32
                         if (vw & 2u) { d_vio += 1; d_held += 1; }
                         if (pd >= 4u) d_via += 1; else d_wl += (int)(step5 >> 5);
                         if (lane == 0) s_tmp[np] = (unsigned short)v;
                         plen++; np++;
                         fnv_mix(h, (uint32_t)v);
-                        if (V2) { x += (pd == 0u) - (pd == 2u); y += (pd == 3u) - (pd == 1u); z += (pd == 4u) - (pd == 5u); }
                         v = u; vw = uw;
                         if (np == XR3_TMP) flush();
                     }
@@ -525,9 +550,9 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     if (status & 0x100) remaining = 0;
                     else {
                         // terminal node of the component: claimed (and recorded) only if nobody holds it yet
-                        // (a source: not held and no owner bit <=> owner[v] == 0, see make_source; XR-Maze v2 reads the owner)
-                        if (V2 ? owner[v] == 0 : (vw & 6u) == 0u) {
-                            if (lane == 0) { owner[v] = claim_val; if (plen < b.path_cap) path[plen] = v; field[v] = vw | 4u; }
+                        // (a source: not held and no owner bit <=> owner[v] == 0, see make_source; XR-Maze v2: the owner it will have)
+                        if ((vw & 6u) == 0u) {
+                            if (lane == 0) { if (!V2) owner[v] = (int16_t)a; if (plen < b.path_cap) path[plen] = v; field[v] = vw | 4u; }
                             plen++;
                             fnv_mix(h, (uint32_t)v);
                         }
@@ -553,18 +578,41 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         }
     }
     XR_LAP(5);
-    if (!V2 || b.maze_end_iter <= 1) break;
-    __syncthreads();                                          // the attempt's owner writes and s_retry are visible
+    if (!V2) break;
+    xr_lds_barrier();                                         // s_retry and the last sources are visible
     const bool retry = s_retry != 0;
-    for (int f = tid; f < N; f += nthr)                       // tentative claims: accepted (-a -> a) or undone (-a -> 0)
-        if (owner[f] == (int16_t)-a) owner[f] = retry ? (int16_t)0 : (int16_t)a;
-    if (!retry) break;
+    if (!retry) {
+        // ---- the attempt stands: its deferred claims.  A word that is a source with the owner bit and not held belongs to this net
+        // from here on: a path node nobody held, the terminal node, or a used access point that already was this net's (same value).
+        const int nq = (N + 3) >> 2;
+        for (int c = tid; c < nq; c += nthr) {
+            const uint4 w = *reinterpret_cast<const uint4*>(field + (c << 2));
+            const int f = c << 2;
+            if ((w.x >> 5) == 0u && (w.x & 6u) == 4u) owner[f] = (int16_t)a;
+            if ((w.y >> 5) == 0u && (w.y & 6u) == 4u) owner[f + 1] = (int16_t)a;
+            if ((w.z >> 5) == 0u && (w.z & 6u) == 4u) owner[f + 2] = (int16_t)a;
+            if ((w.w >> 5) == 0u && (w.w & 6u) == 4u) owner[f + 3] = (int16_t)a;
+        }
+        break;
+    }
+    // ---- rip-up: nothing reached global memory but the path list (overwritten by the next attempt) — every word goes back to
+    // "unreached" with its static bits (held, outside the guide), the masks are emptied, the component starts over.  LDS only.
     attempt++;
     pen5 = ((uint32_t)b.pen_cost << 5) << attempt;
-    __syncthreads();                                          // the owner grid is clean again before the field is rebuilt
-    build_field();
-    for (int i = tid; i < nap; i += nthr) s_ap_conn[i] = (unsigned char)(s_ap_conn[i] == 2 ? 2 : (s_ap_pin[i] == (short)first_pin ? 1 : 0));
-    __syncthreads();
+    {
+        const int nq = (N + 3) >> 2;
+        for (int c = tid; c < nq; c += nthr) {
+            uint4* p4 = reinterpret_cast<uint4*>(field + (c << 2));
+            uint4 w = *p4;
+            w.x = w.x ? (XR3_UNREACHED_V2 | (w.x & 3u)) : 0u;  w.y = w.y ? (XR3_UNREACHED_V2 | (w.y & 3u)) : 0u;
+            w.z = w.z ? (XR3_UNREACHED_V2 | (w.z & 3u)) : 0u;  w.w = w.w ? (XR3_UNREACHED_V2 | (w.w & 3u)) : 0u;
+            *p4 = w;
+        }
+        for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_wmin[i] = XR_DIAL_INF; }
+        for (int i = tid; i < nap; i += nthr) s_ap_conn[i] = (unsigned char)(s_ap_conn[i] == 2 ? 2 : (s_ap_pin[i] == (short)first_pin ? 1 : 0));
+    }
+    xr_lds_barrier();
+    XR_LAP(7);
     }
     XR_TDUMP();
 }

@@ -155,7 +155,7 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 // Field word (one u32 per node, nothing else per node):
 //     w = (distance << 2) | (held << 1) | 1          for every real node; a blockage is w = 0
 //     held = node is held by another net (drc penalty + violation)
-//     0xFFFFFFFD | (held << 1) = unreached.  Distances >= XR_DIST_CAP (0x30000000) do not exist (spec,
+//     0xFFFFFFFD | (held << 1) = unreached.  Distances >= XR_DIST_CAP (0x07F00000) do not exist (spec,
 //     mirrored by the oracle): candidates are capped there, which makes u32 wrap-around impossible.
 //
 // Two placements of the same code (template LDS_DIST): field + worklists (aliased by the claim bitmask) in LDS
@@ -175,7 +175,7 @@ __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, 
 #define XR_TDUMP() do {} while (0)
 #endif
 #define XR_CH 8                       // generic line chunk held in registers
-#define XR_W_USABLE_END 0xC0000000u   // (XR_DIST_CAP << 2): predecessors must be below this
+#define XR_W_USABLE_END 0x1FC00000u   // (XR_DIST_CAP << 2, XR_DIST_CAP = 0x07F00000): predecessors must be below this
 #define XR_W_UNREACHED 0xFFFFFFFDu    // | held << 1
 #define XR_W_BLOCK 0u                 // blockage (and padded register slots)
 
