@@ -523,10 +523,11 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                             const uint32_t w0 = field[f];
                             if (pl0 + i < b.path_cap) path[pl0 + i] = (int)f;
                             make_source(f, true);               // (whatever it was before: it has an owner from here on)
-                            // claimed if nobody holds it.  Not held (bit 1 clear) = owner 0 or this net itself (a used access point of
-                            // it): the store of `a` is right in both cases and needs no load.  XR-Maze v2 defers the store to the
-                            // attempt that stands (the acceptance scan below finds these words: source + owner bit + not held).
-                            if (!V2 && !(w0 & 2u)) owner[f] = (int16_t)a;
+                            // claimed if nobody OWNS it.  Not held (bit 1 clear) = owner 0 or this net itself (a used access point of
+                            // it): the store of `a` is right in both cases and needs no load.  Held = owned by another net OR another
+                            // net's still unowned access point: only then the owner is read.  XR-Maze v2 defers all of this to the attempt
+                            // that stands (the acceptance scan below finds these words: source + owner bit).
+                            if (!V2) { if (!(w0 & 2u)) owner[f] = (int16_t)a; else if (owner[f] == 0) owner[f] = (int16_t)a; }
                         }
                         XR3_WSYNC();
                         np = 0;
@@ -582,16 +583,17 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     xr_lds_barrier();                                         // s_retry and the last sources are visible
     const bool retry = s_retry != 0;
     if (!retry) {
-        // ---- the attempt stands: its deferred claims.  A word that is a source with the owner bit and not held belongs to this net
-        // from here on: a path node nobody held, the terminal node, or a used access point that already was this net's (same value).
+        // ---- the attempt stands: its deferred claims.  A source word with the owner bit is a path node, the terminal node, or an
+        // access point that had an owner when the route began.  Not held: owner 0 or this net -> this net (no load).  Held: another
+        // net's wire (stays) or another net's unowned access point on the path (claimed, as XR-Maze v1 does): the owner is read.
         const int nq = (N + 3) >> 2;
+        auto accept = [&](uint32_t w, int f) __attribute__((always_inline)) {
+            if ((w >> 5) == 0u && (w & 4u)) { if (!(w & 2u)) owner[f] = (int16_t)a; else if (owner[f] == 0) owner[f] = (int16_t)a; }
+        };
         for (int c = tid; c < nq; c += nthr) {
             const uint4 w = *reinterpret_cast<const uint4*>(field + (c << 2));
             const int f = c << 2;
-            if ((w.x >> 5) == 0u && (w.x & 6u) == 4u) owner[f] = (int16_t)a;
-            if ((w.y >> 5) == 0u && (w.y & 6u) == 4u) owner[f + 1] = (int16_t)a;
-            if ((w.z >> 5) == 0u && (w.z & 6u) == 4u) owner[f + 2] = (int16_t)a;
-            if ((w.w >> 5) == 0u && (w.w & 6u) == 4u) owner[f + 3] = (int16_t)a;
+            accept(w.x, f); accept(w.y, f + 1); accept(w.z, f + 2); accept(w.w, f + 3);
         }
         break;
     }

@@ -303,9 +303,27 @@ class RegionExtractor:
         # guide rectangles as arrays per net index
         self.net_index = {nm: i for i, (nm, _) in enumerate(design.nets)}
 
-    def extract(self, box: Rect, name: str = "") -> Region:
+    def extract(self, box: Rect, name: str = "", route_box: Optional[Rect] = None, drc_halo: int = 500) -> Region:
+        """The region of `box` (the worker's extBox: every track inside it is routing resource).  `route_box` (the worker's routeBox,
+        inside `box`) restricts which nets are ROUTED here, the way the reference describes its one static region (xroute_env/__init__.py:
+        13-23: a 1x1-GCell routeBox of ispd18_test1 with 36 nets): a net is routed when its global-route guide overlaps the routeBox or
+        one of its cell pins lies in routeBox + drcBox (`drc_halo`, 500 DBU in the shipped worker dumps); every other net
+        met in the halo is an obstacle (its pin shapes are blocked), the halo's free tracks stay routing resource.  None: every net
+        with two pins inside `box` (round 2-3 behaviour)."""
         d = self.d
         bx0, by0, bx1, by1 = box
+        selected = None
+        if route_box is not None:
+            rx0, ry0, rx1, ry1 = route_box
+            selected = set()
+            for nm, rects in d.guides.items():
+                ni = self.net_index.get(nm)
+                if ni is None:
+                    continue
+                for (gx0, gy0, gx1, gy1, z) in rects:
+                    if max(gx0, rx0) < min(gx1, rx1) and max(gy0, ry0) < min(gy1, ry1):
+                        selected.add(ni)
+                        break
         xs = _track_coords(d, "X", bx0, bx1)
         ys = _track_coords(d, "Y", by0, by1)
         Z = len(d.layers)
@@ -345,6 +363,9 @@ class RegionExtractor:
                     a, b = span(xs, x0, x1); c, e = span(ys, y0, y1)
                     z = rect[0]
                     if routed:
+                        if selected is not None and (rx0 - drc_halo <= (x0 + x1) // 2 <= rx1 + drc_halo and
+                                                     ry0 - drc_halo <= (y0 + y1) // 2 <= ry1 + drc_halo):
+                            selected.add(ni)
                         if key not in pin_rect_center and bx0 <= (x0 + x1) // 2 <= bx1 and by0 <= (y0 + y1) // 2 <= by1:
                             pin_rect_center[key] = ((x0 + x1) // 2, (y0 + y1) // 2, z)
                         for xi in range(a, b):
@@ -411,8 +432,8 @@ class RegionExtractor:
                     claimed[nd] = (ni, pi)
                 if got:
                     placed.setdefault(ni, []).append(got)
-        # a net is routed here when at least two of its pins got nodes; everything else is an obstacle
-        routed_nets = sorted(ni for ni, pins in placed.items() if len(pins) >= 2)
+        # a net is routed here when at least two of its pins got nodes (and the routeBox rule selects it); everything else is an obstacle
+        routed_nets = sorted(ni for ni, pins in placed.items() if len(pins) >= 2 and (selected is None or ni in selected))
         local_id = {ni: k for k, ni in enumerate(routed_nets)}
         net = np.full((X, Y, Z), -1, np.int64)
         pin = np.full((X, Y, Z), -1, np.int64)
@@ -447,15 +468,18 @@ class RegionExtractor:
             reg.guide_box = np.asarray(guide_box, np.int16).reshape(-1, 6)
         return reg
 
-    def gcell_regions(self, gcell=(6000, 5700), halo: int = 2000, limit: Optional[int] = None, min_nets: int = 1):
-        """Regions of 1x1 GCell + halo over the die, row-major, skipping boxes with fewer than `min_nets` routed nets."""
+    def gcell_regions(self, gcell=(6000, 5700), halo: int = 2000, limit: Optional[int] = None, min_nets: int = 1,
+                      route_box_rule: bool = True):
+        """Regions of 1x1 GCell + halo over the die, row-major, skipping boxes with fewer than `min_nets` routed nets.  The GCell is the
+        routeBox, the halo the extBox ring (routeBox 5700^2 + 2000 DBU in the reference's worker dumps): with `route_box_rule` only nets
+        the routeBox rule of `extract` selects are routed; the halo is routing resource."""
         x0, y0, x1, y1 = self.d.die
         out = []
         for gy in range(0, (y1 - y0 + gcell[1] - 1) // gcell[1]):
             for gx in range(0, (x1 - x0 + gcell[0] - 1) // gcell[0]):
-                box = (max(x0, x0 + gx * gcell[0] - halo), max(y0, y0 + gy * gcell[1] - halo),
-                       min(x1, x0 + (gx + 1) * gcell[0] + halo), min(y1, y0 + (gy + 1) * gcell[1] + halo))
-                reg = self.extract(box, name=f"gcell_x{gx}_y{gy}")
+                rb = (x0 + gx * gcell[0], y0 + gy * gcell[1], min(x1, x0 + (gx + 1) * gcell[0]), min(y1, y0 + (gy + 1) * gcell[1]))
+                box = (max(x0, rb[0] - halo), max(y0, rb[1] - halo), min(x1, rb[2] + halo), min(y1, rb[3] + halo))
+                reg = self.extract(box, name=f"gcell_x{gx}_y{gy}", route_box=rb if route_box_rule else None)
                 if reg.n_nets >= min_nets:
                     out.append(reg)
                     if limit is not None and len(out) >= limit:
