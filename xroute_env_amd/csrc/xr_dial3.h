@@ -514,6 +514,11 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     // in parallel afterwards.
                     int v = tf, np = 0;
                     uint32_t vw = field[v];
+                    // XR-Maze v2: an attempt whose path uses a held node is ripped up unless it is the last one — nothing of it is kept,
+                    // so it may as well end at the first held node its trace meets (same results, the doomed attempt's remaining
+                    // trace and searches are skipped)
+                    const bool doomable = V2 && attempt + 1 < b.maze_end_iter;
+                    bool doomed = false;
                     auto flush = [&]() __attribute__((always_inline)) {        // the listed path nodes: sources of the next search, claimed if nobody holds them
                         XR3_WSYNC();
                         const int pl0 = plen - np;              // (the listed nodes are path[pl0 .. plen): one coalesced store per 64 nodes —
@@ -535,6 +540,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     for (int nt = 0; (vw >> 5) != 0u; nt++) {
                         const uint32_t pd = (vw >> 2) & 7u;
                         if (nt > N || pd > 5u) { status |= 0x100; break; }          // (distances strictly decrease: cannot happen)
+                        if (doomable && (vw & 2u)) { doomed = true; d_held += 1; break; }
                         const int off = pd == 0u ? YZ : pd == 1u ? -Z : pd == 2u ? -YZ : pd == 3u ? Z : pd == 4u ? 1 : -1;
                         const int u = v + off;
                         const uint32_t uw = field[u];
@@ -547,8 +553,8 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         v = u; vw = uw;
                         if (np == XR3_TMP) flush();
                     }
-                    flush();
-                    if (status & 0x100) remaining = 0;
+                    if (!doomed) flush();
+                    if ((status & 0x100) || doomed) remaining = 0;
                     else {
                         // terminal node of the component: claimed (and recorded) only if nobody holds it yet
                         // (a source: not held and no owner bit <=> owner[v] == 0, see make_source; XR-Maze v2: the owner it will have)

@@ -308,13 +308,18 @@ class RegionExtractor:
         inside `box`) restricts which nets are ROUTED here, the way the reference describes its one static region (xroute_env/__init__.py:
         13-23: a 1x1-GCell routeBox of ispd18_test1 with 36 nets): a net is routed when its global-route guide overlaps the routeBox or
         one of its cell pins lies in routeBox + drcBox (`drc_halo`, 500 DBU in the shipped worker dumps); every other net
-        met in the halo is an obstacle (its pin shapes are blocked), the halo's free tracks stay routing resource.  None: every net
-        with two pins inside `box` (round 2-3 behaviour)."""
+        met in the halo is an obstacle (its pin shapes are blocked), the halo's free tracks stay routing resource.  With a routeBox the
+        worker only routes what lies inside it: a cell pin outside routeBox + drcBox is not a pin of the region (its net's wiring out
+        there exists already: the shape is an obstacle), and a net that leaves the routeBox gets its boundary pin where its guide crosses
+        the ROUTEBOX edge, not the extBox edge.  None: every net with two pins inside `box`, boundary pins on the edge of `box`
+        (round 2-3 behaviour)."""
         d = self.d
         bx0, by0, bx1, by1 = box
         selected = None
+        pbx0, pby0, pbx1, pby1 = box                       # the box pins live in / boundary pins sit on the edge of
         if route_box is not None:
             rx0, ry0, rx1, ry1 = route_box
+            pbx0, pby0, pbx1, pby1 = route_box
             selected = set()
             for nm, rects in d.guides.items():
                 ni = self.net_index.get(nm)
@@ -354,6 +359,13 @@ class RegionExtractor:
             for pname, pin in m.pins.items():
                 ni = self.comp_net.get((cname, pname), -1)
                 routed = pin["use"] == "SIGNAL" and ni >= 0
+                if routed and route_box is not None:       # a pin is the region's when (the centre of) one of its shapes lies in routeBox + drcBox
+                    routed = False
+                    for rect in pin["rects"]:
+                        x0, y0, x1, y1 = _place(rect, m, px, py, orient)
+                        if (rx0 - drc_halo <= (x0 + x1) // 2 <= rx1 + drc_halo and ry0 - drc_halo <= (y0 + y1) // 2 <= ry1 + drc_halo):
+                            routed = True
+                            break
                 key = None
                 if routed:
                     conns = d.nets[ni][1]
@@ -383,29 +395,32 @@ class RegionExtractor:
             xi = int(np.argmin(np.abs(xs - cx))); yj = int(np.argmin(np.abs(ys - cy)))
             if abs(int(xs[xi]) - cx) <= self.snap and abs(int(ys[yj]) - cy) <= self.snap:
                 pin_nodes[key] = [(xi, yj, z)]
-        # boundary pins from the global-route guides
+        # boundary pins from the global-route guides, on the edge of the pin box (the routeBox when there is one)
+        xi_lo, xi_hi = int(np.searchsorted(xs, pbx0, "left")), int(np.searchsorted(xs, pbx1, "right")) - 1
+        yj_lo, yj_hi = int(np.searchsorted(ys, pby0, "left")), int(np.searchsorted(ys, pby1, "right")) - 1
+        xi_lo, xi_hi, yj_lo, yj_hi = max(0, min(xi_lo, X - 1)), max(0, min(xi_hi, X - 1)), max(0, min(yj_lo, Y - 1)), max(0, min(yj_hi, Y - 1))
         boundary: Dict[int, List[Tuple[int, int, int]]] = {}
         for nm, rects in d.guides.items():
             ni = self.net_index.get(nm)
             if ni is None:
                 continue
             for (gx0, gy0, gx1, gy1, z) in rects:
-                cx0, cy0, cx1, cy1 = max(gx0, bx0), max(gy0, by0), min(gx1, bx1), min(gy1, by1)
+                cx0, cy0, cx1, cy1 = max(gx0, pbx0), max(gy0, pby0), min(gx1, pbx1), min(gy1, pby1)
                 if cx0 >= cx1 or cy0 >= cy1:
                     continue
                 vert = d.layer_dir[z] == 1
                 if not vert:       # horizontal wires leave through the left / right edge
                     yj = int(np.argmin(np.abs(ys - (cy0 + cy1) // 2)))
-                    if gx0 < bx0:
-                        boundary.setdefault(ni, []).append((0, yj, z))
-                    if gx1 > bx1:
-                        boundary.setdefault(ni, []).append((X - 1, yj, z))
+                    if gx0 < pbx0:
+                        boundary.setdefault(ni, []).append((xi_lo, yj, z))
+                    if gx1 > pbx1:
+                        boundary.setdefault(ni, []).append((xi_hi, yj, z))
                 else:
                     xi = int(np.argmin(np.abs(xs - (cx0 + cx1) // 2)))
-                    if gy0 < by0:
-                        boundary.setdefault(ni, []).append((xi, 0, z))
-                    if gy1 > by1:
-                        boundary.setdefault(ni, []).append((xi, Y - 1, z))
+                    if gy0 < pby0:
+                        boundary.setdefault(ni, []).append((xi, yj_lo, z))
+                    if gy1 > pby1:
+                        boundary.setdefault(ni, []).append((xi, yj_hi, z))
         # candidate pins per net: local pins first (DEF connection order), then boundary pins
         pins_of: Dict[int, List[List[Tuple[int, int, int]]]] = {}
         for (ni, _), nodes in sorted(pin_nodes.items()):
@@ -422,7 +437,7 @@ class RegionExtractor:
                 got = [nd for nd in nodes if nd not in claimed]
                 if not got and len(nodes) == 1:
                     xi, yj, z = nodes[0]
-                    on_x_edge = xi in (0, X - 1)
+                    on_x_edge = xi in (xi_lo, xi_hi)
                     for dlt in (1, -1, 2, -2, 3, -3):
                         cand = (xi, yj + dlt, z) if on_x_edge else (xi + dlt, yj, z)
                         if 0 <= cand[0] < X and 0 <= cand[1] < Y and cand not in claimed:
