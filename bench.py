@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 253 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
+PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 256 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 STAGGER_SEED = 0x5EED5EED
 
@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--c5-envs", type=int, default=1024, help="env slots of the BASELINE config 5 leg (256x256x12 regions)")
     ap.add_argument("--c5-regions", type=int, default=128, help="distinct config 5 regions generated (cycled over the env slots)")
     ap.add_argument("--pack-envs", type=int, default=4096,
-                    help="env slots of the design-derived leg: the 253 regions extracted from the reference's ispd18_test1.input.{lef,def,guide} "
+                    help="env slots of the design-derived leg: the 256 regions extracted from the reference's ispd18_test1.input.{lef,def,guide} "
                          "(tests/golden/ispd18_test1_regions.npz) cycled over this many slots, full step in the queue form (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=2024)
@@ -954,8 +954,8 @@ def v2_leg(args, regions, dev, first_env, pack=None):
 
 
 def pack_leg(args, pack, dev, v2=None):
-    """The REAL ispd18_test1 regions on the record: 4096 env slots over the 253 regions `xroute_env_amd.lefdef` extracts from the
-    reference's own ispd/ispd18_test1/ispd18_test1.input.{lef,def,guide} (per-GCell windows: 20-26 x 27-45 x 9 tracks, K up to 77),
+    """The REAL ispd18_test1 regions on the record: 4096 env slots over the 256 regions `xroute_env_amd.lefdef` extracts from the
+    reference's own ispd/ispd18_test1/ispd18_test1.input.{lef,def,guide} (per-GCell routeBox + 2000 DBU ring: 22-25 x 27-34 x 9 tracks, K up to 28),
     full step in the default queue form, with its own oracle replay (hash chains, cumulative metrics and the observation bytes of
     32 slots spread over K).  Their N is rarely a multiple of 4, so channel planes are not 16-byte aligned: the unit writer is
     xr_unit_stream.  Slots keep their region (max_route_count = 2^30: the replay needs no rotation bookkeeping; rotation itself is
