@@ -438,6 +438,13 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                     if (pn == first) src_iso = 1; else n_iso++;
                 }
                 hinfo[R.net_off + n] = (first & 0x3FFF) | ((int)seen_pins.size() << 14) | (n_iso << 22) | (src_iso << 30);
+                // heuristic slot of every access point (bits 1..2 of ap_flags): pins in ascending id order, the lowest one (the first
+                // component: never a target) aside, are dealt round-robin over the three pin boxes of xr_dial3.h's heuristic
+                std::sort(seen_pins.begin(), seen_pins.end());
+                for (int i = lo; i < hi; i++) {
+                    const int rank = (int)(std::find(seen_pins.begin(), seen_pins.end(), (int)hap_pin[base + i]) - seen_pins.begin());
+                    hap_flags[base + i] |= (uint8_t)(((rank + 2) % 3) << 1);         // rank 1 -> slot 0, 2 -> 1, 3 -> 2, 4 -> 0 ...
+                }
             }
         }
         // predicted work of routing net n: extent of its access points (DBU; a layer of span counted as half a via) times

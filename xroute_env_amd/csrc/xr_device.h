@@ -93,7 +93,8 @@ struct XrBatchDev {
     const uint8_t* net_work; // [like net_csr] predicted route work class of net n of a region (1..255; 0 = no access points), static
     const int32_t* net_info; // [like net_csr] static facts of net n: lowest pin id (pin + 1, 14 bits) | distinct pins << 14 | pins in closed
                              // pockets (never reachable) << 22 | the lowest pin itself is in one << 30   (xr_dial3.h)
-    const uint8_t* ap_flags; // [like ap_node] bit 0: the access point's pin sits in a closed pocket (isolated)
+    const uint8_t* ap_flags; // [like ap_node] bit 0: the access point's pin sits in a closed pocket (isolated); bits 1..2: which of the three
+                             // pin boxes of the search heuristic the access point's pin belongs to (xr_dial3.h)
     const int32_t* guide_csr; // [like net_csr] XR-Maze v2, optional (null: none): boxes of net n are [guide_csr[n], guide_csr[n + 1]) of guide_box
     const int16_t* guide_box; // [boxes][6] x0, y0, x1, y1, z0, z1 (track / layer indices, inclusive)
     int32_t n_regions;

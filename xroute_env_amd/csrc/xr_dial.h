@@ -62,6 +62,7 @@
 #ifndef XR_SCAN_UNROLL
 #define XR_SCAN_UNROLL 2      // open nodes of a mask word classified per loop iteration
 #endif
+#define XR_HB_MAX 6          // pin boxes of the search heuristic (HBM-scratch form; xr_dial3.h)
 #define XR_QUAD_POOL 128       // nodes of a bucket queued per workgroup for the quads (split evenly over the waves); no room: next round
 #ifndef XR_DIAL_CHAIN
 #define XR_DIAL_CHAIN 1
@@ -1137,7 +1138,9 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];
     __shared__ uint32_t s_min[3], s_bst[3];
     __shared__ unsigned long long s_tkey;
-    __shared__ int s_hb[6];
+    __shared__ int s_hbk[XR_HB_MAX][6];                         // heuristic: one box per unconnected pin (x, y: coordinates x4; z), see the search start
+    __shared__ short s_hbpin[XR_HB_MAX];
+    __shared__ int s_nhb;
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
     __shared__ int s_nG, s_nA, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
@@ -1282,7 +1285,6 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
             s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
             s_tkey = ~0ULL;
-            s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1;
         }
         // deferred nodes are looked at again (the list overflowed: every reached node is — re-expanding one is harmless)
         {
@@ -1300,22 +1302,49 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         if (tid == 0) s_ndefer = 0;
         __syncthreads();
         if (s_remaining <= 0) break;          // uniform
-        // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
-        for (int i = tid; i < nap; i += nthr)
-            if (!s_ap_conn[i]) {
+        // heuristic of this search (round 4): h(v) = min over the unconnected (and not isolated) PINS of the distance from v to the box of
+        // that pin's access points (coordinate differences + one via cost per layer).  A minimum of consistent lower bounds is one, and
+        // it is 0 on every target, so the results are the oracle's as before — but where ONE box around all unconnected pins is 0
+        // everywhere between them (a 3-4 pin net spread over 70 x 70 tracks flooded its whole box: 40-50 k touched nodes, the routes
+        // that decide a launch, profiles/r04_b_config5_route_distribution.txt), this one leads the search to the nearest pin.
+        // The first XR_HB_MAX - 1 pins get a box each, any further pins share the last one (still a lower bound).
+        if (tid == 0) {
+            int nh = 0;
+            for (int i = 0; i < nap; i++) {
+                if (s_ap_conn[i]) continue;
                 uint32_t ax, ar, ay, az;
                 xr_divmod((uint32_t)s_ap_f[i], uYZ, R.magic_yz, ax, ar);
                 xr_divmod(ar, uZ, R.magic_z, ay, az);
-                atomicMin(&s_hb[0], (int)s_xc[ax + 1]); atomicMax(&s_hb[1], (int)s_xc[ax + 1]);
-                atomicMin(&s_hb[2], (int)s_yc[ay + 1]); atomicMax(&s_hb[3], (int)s_yc[ay + 1]);
-                atomicMin(&s_hb[4], (int)az); atomicMax(&s_hb[5], (int)az);
+                const int cx = (int)s_xc[ax + 1], cy = (int)s_yc[ay + 1], cz = (int)az;
+                const short pin = s_ap_pin[i];
+                int k = 0;
+                while (k < nh && s_hbpin[k] != pin) k++;
+                if (k == nh) {
+                    if (nh < XR_HB_MAX) {
+                        s_hbpin[nh] = pin;
+                        s_hbk[nh][0] = cx; s_hbk[nh][1] = cx; s_hbk[nh][2] = cy; s_hbk[nh][3] = cy; s_hbk[nh][4] = cz; s_hbk[nh][5] = cz;
+                        nh++;
+                        continue;
+                    }
+                    k = XR_HB_MAX - 1;
+                }
+                s_hbk[k][0] = min(s_hbk[k][0], cx); s_hbk[k][1] = max(s_hbk[k][1], cx);
+                s_hbk[k][2] = min(s_hbk[k][2], cy); s_hbk[k][3] = max(s_hbk[k][3], cy);
+                s_hbk[k][4] = min(s_hbk[k][4], cz); s_hbk[k][5] = max(s_hbk[k][5], cz);
             }
+            s_nhb = nh;
+        }
         __syncthreads();
-        const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
+        const int nhb = s_nhb;
         auto heur_c = [&](int xc, int yc, int z) -> uint32_t {                 // (from coordinates x4)
-            const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
-            const int hz = max(0, max(hb4 - z, z - hb5));
-            return ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
+            uint32_t hmin = 0xFFFFFFFFu;
+            for (int k = 0; k < nhb; k++) {
+                const int hx = max(0, max(s_hbk[k][0] - xc, xc - s_hbk[k][1])), hy = max(0, max(s_hbk[k][2] - yc, yc - s_hbk[k][3]));
+                const int hz = max(0, max(s_hbk[k][4] - z, z - s_hbk[k][5]));
+                const uint32_t hv = ((uint32_t)(hx + hy) >> 2) + (uint32_t)hz * (uint32_t)b.via_cost;
+                hmin = hv < hmin ? hv : hmin;
+            }
+            return hmin;
         };
         auto heur = [&](int x, int y, int z) -> uint32_t { return heur_c((int)s_xc[x + 1], (int)s_yc[y + 1], z); };
         int cur = 0;

@@ -76,8 +76,9 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];      // 0 target, 1 connected, 2 isolated (static, from the load)
     __shared__ unsigned char s_ap_own[XR_MAX_AP_PER_NET];       // the access point's node had an owner when the route began (a used access point of this net)
+    __shared__ unsigned char s_ap_slot[XR_MAX_AP_PER_NET];      // which heuristic box the access point's pin is dealt to (static, from the load)
     __shared__ uint32_t s_min[3], s_bst[3];                     // rotating per round: smallest open key, smallest target distance
-    __shared__ int s_hb[6];                                     // bounding box of the unconnected targets: x, y (coordinates x32), z
+    __shared__ int s_hb[3][6];                                  // heuristic: three boxes over the unconnected pins (x, y: coordinates x32; z), see the search start
     __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
     __shared__ unsigned short s_qn[XR_QUAD_POOL];
     __shared__ int s_remaining, s_abort;
@@ -184,6 +185,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         s_ap_f[i] = (unsigned short)apf;
         s_ap_pin[i] = (short)pin;
         s_ap_conn[i] = (unsigned char)((iso & 1) ? 2 : (pin == first_pin ? 1 : 0));
+        s_ap_slot[i] = (unsigned char)((iso >> 1) & 3);
         s_ap_own[i] = (unsigned char)((i < nthr ? my_ap_own : (int)owner[apf]) != 0);
         if (V2 && b.guide_cost) {                // XR-Maze v2: the net's guide = bounding box of all its access points (+ margin)
             const int gy = (apf / Z) % Y, gx = apf / YZ;
@@ -291,31 +293,45 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         if (tid == 0) {
             s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
             s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
-            s_hb[0] = 0x7FFFFFFF; s_hb[1] = -0x7FFFFFFF; s_hb[2] = 0x7FFFFFFF; s_hb[3] = -0x7FFFFFFF; s_hb[4] = 0x7FFFFFFF; s_hb[5] = -1;
         }
+        if (tid < 18) { const int k = tid % 6; s_hb[tid / 6][k] = (k & 1) ? -0x3FFFFFFF : 0x3FFFFFFF; }      // (empty: min > max)
         for (int i = tid; i < mw; i += nthr) {
             const uint32_t m = s_defer[i];
             if (m) { atomicOr(&s_open[i], m); s_defer[i] = 0; s_wmin[i] = 0u; }   // (0: a lower bound; the first scan fixes it)
         }
         xr_lds_barrier();
         if (s_remaining <= 0) break;          // uniform: written before the barrier above
-        // heuristic of this search: bounding box of the access points of the unconnected (and not isolated) pins
+        // heuristic of this search (round 4): the unconnected (and not isolated) pins are dealt over THREE boxes (statically, by pin
+        // rank: ap_flags) and h(v) = the smallest distance to a box — coordinate differences + one via cost per layer, from coordinates
+        // x32.  A minimum of consistent lower bounds is one, and it is 0 on every target: same results as with one box around all of
+        // them — but one box is 0 everywhere between the pins of a spread multi-pin net, which then floods its whole box.
         for (int i = tid; i < nap; i += nthr)
             if (!s_ap_conn[i]) {
                 int ax, ay, az;
                 node_xyz((uint32_t)s_ap_f[i], ax, ay, az);
                 const int cx = (int)s_tab[ax + 1], cy = (int)s_tab[XO + ay + 1];
-                atomicMin(&s_hb[0], cx); atomicMax(&s_hb[1], cx); atomicMin(&s_hb[2], cy); atomicMax(&s_hb[3], cy);
-                atomicMin(&s_hb[4], az); atomicMax(&s_hb[5], az);
+                int* hb = s_hb[s_ap_slot[i] < 3 ? s_ap_slot[i] : 0];
+                atomicMin(&hb[0], cx); atomicMax(&hb[1], cx); atomicMin(&hb[2], cy); atomicMax(&hb[3], cy);
+                atomicMin(&hb[4], az); atomicMax(&hb[5], az);
             }
         xr_lds_barrier();
-        const int hb0 = s_hb[0], hb1 = s_hb[1], hb2 = s_hb[2], hb3 = s_hb[3], hb4 = s_hb[4], hb5 = s_hb[5];
-        // h(v): distance to that box — coordinate differences + one via cost per layer (a consistent lower bound), from
-        // coordinates x32
+        int hbv[3][6];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) hbv[k][j] = __builtin_amdgcn_readfirstlane(s_hb[k][j]);       // (uniform: scalar registers)
+        const bool hb0on = hbv[0][0] <= hbv[0][1], hb1on = hbv[1][0] <= hbv[1][1], hb2on = hbv[2][0] <= hbv[2][1];      // (an empty box is skipped)
+        auto heur_1 = [&](const int* hb, int xc, int yc, int z) __attribute__((always_inline)) -> uint32_t {
+            const int hx = max(0, max(hb[0] - xc, xc - hb[1])), hy = max(0, max(hb[2] - yc, yc - hb[3]));
+            const int hz = max(0, max(hb[4] - z, z - hb[5]));
+            return (((uint32_t)hx + (uint32_t)hy) >> 5) + __umul24((uint32_t)hz, (uint32_t)b.via_cost);
+        };
         auto heur_c = [&](int xc, int yc, int z) __attribute__((always_inline)) -> uint32_t {
-            const int hx = max(0, max(hb0 - xc, xc - hb1)), hy = max(0, max(hb2 - yc, yc - hb3));
-            const int hz = max(0, max(hb4 - z, z - hb5));
-            return ((uint32_t)(hx + hy) >> 5) + __umul24((uint32_t)hz, (uint32_t)b.via_cost);
+            uint32_t hv = 0xFFFFFFFFu;
+            if (hb0on) hv = heur_1(hbv[0], xc, yc, z);
+            if (hb1on) { const uint32_t t = heur_1(hbv[1], xc, yc, z); hv = t < hv ? t : hv; }
+            if (hb2on) { const uint32_t t = heur_1(hbv[2], xc, yc, z); hv = t < hv ? t : hv; }
+            return hv;
         };
         XR_LAP(4);
         int cur = 0;
