@@ -7,8 +7,9 @@ res = {}
 for rep in range(3):
     for lib in libs:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", B, "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-                              "--c5-envs", "0"], capture_output=True, text=True, env=dict(os.environ, XR_LIB=lib))
+                              "--c5-envs", "0", "--no-extras"], capture_output=True, text=True, env=dict(os.environ, XR_LIB=lib))
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         res.setdefault(lib, []).append(tuple(round(k["ms"], 4) for k in d["kernels"]))
+print("kernels:", [k["kernel"][:60] for k in d["kernels"]])
 for k, v in res.items():
     print(f"{k:28s} {v}")

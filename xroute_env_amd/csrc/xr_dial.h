@@ -1498,10 +1498,14 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                             if (!chained) { open_insert((uint32_t)nf, key); lmin = key < lmin ? key : lmin; }
                         }
                     }
-                    __syncthreads();
+                    // (LDS-only barrier, round 4: the next pass is handed the E list, nothing else.  __syncthreads() would also wait for the
+                    //  acknowledgement of this pass's fire-and-forget traffic — touched / deferred list stores, open-mask atomics: one more
+                    //  L2 round trip per pass on the critical chain.  A later pass that reads a word an unacknowledged atomic is about to
+                    //  lower sees the older, HIGHER value: it may issue an atomicMin that loses, never skip one that would win.)
+                    xr_lds_barrier();
                     if (tid == 0) s_nE[eb] = 0;
                     eb ^= 1;
-                    __syncthreads();
+                    xr_lds_barrier();
                 }
             }
             lmin = xr_wave_min_u32(lmin);

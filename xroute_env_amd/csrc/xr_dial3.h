@@ -279,14 +279,21 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     };
 
     const uint64_t h0 = wv == sw ? b.hash[e] : 0ULL;        // (a ripped-up attempt rewinds the chain to here)
-    for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
-    // component = all access points of the lowest pin id
-    for (int i = tid; i < nap; i += nthr)
-        if (s_ap_conn[i] == 1) make_source((uint32_t)s_ap_f[i], s_ap_own[i] != 0);
-    if (tid == 0) { s_remaining = npins - 1 - n_isolated; s_abort = 0; }
-    // the tracing wave's bookkeeping (uniform over that wave; meaningless in the others)
+    // the tracing wave's bookkeeping (uniform over that wave; meaningless in the others), and its state at the start of the search that
+    // is running (XR-Maze v2: where a ripped-up attempt resumes, see the rip-up below)
     int d_vio = 0, d_wl = 0, d_via = 0, plen = 0, status = XR_ENV_OK, d_held = 0, nrounds = 0;
     uint64_t h = h0;
+    int sv_vio = 0, sv_wl = 0, sv_via = 0, sv_plen = 0, sv_status = XR_ENV_OK, sv_rem = 0;
+    uint64_t sv_h = h0;
+    bool resume = false;
+    for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
+    // component = all access points of the lowest pin id (a resumed attempt: of every pin connected so far; its path nodes are sources still)
+    for (int i = tid; i < nap; i += nthr)
+        if (s_ap_conn[i] == 1) make_source((uint32_t)s_ap_f[i], s_ap_own[i] != 0);
+    if (tid == 0) { s_remaining = resume ? sv_rem : npins - 1 - n_isolated; s_abort = 0; }
+    if (resume) { d_vio = sv_vio; d_wl = sv_wl; d_via = sv_via; plen = sv_plen; status = sv_status; h = sv_h; }
+    else { d_vio = 0; d_wl = 0; d_via = 0; plen = 0; status = XR_ENV_OK; h = h0; }
+    d_held = 0; nrounds = 0;
 
     for (;;) {
         // ---- new search: sources are open with distance 0; deferred nodes are looked at again ------------
@@ -301,6 +308,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         }
         xr_lds_barrier();
         if (s_remaining <= 0) break;          // uniform: written before the barrier above
+        if (V2) { sv_vio = d_vio; sv_wl = d_wl; sv_via = d_via; sv_plen = plen; sv_status = status; sv_h = h; sv_rem = s_remaining; }
         // heuristic of this search (round 4): the unconnected (and not isolated) pins are dealt over THREE boxes (statically, by pin
         // rank: ap_flags) and h(v) = the smallest distance to a box — coordinate differences + one via cost per layer, from coordinates
         // x32.  A minimum of consistent lower bounds is one, and it is 0 on every target: same results as with one box around all of
@@ -310,7 +318,11 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                 int ax, ay, az;
                 node_xyz((uint32_t)s_ap_f[i], ax, ay, az);
                 const int cx = (int)s_tab[ax + 1], cy = (int)s_tab[XO + ay + 1];
+#ifdef XR3_HB_ONE       // A/B: one box around all unconnected pins (rounds 2-3)
+                int* hb = s_hb[0];
+#else
                 int* hb = s_hb[s_ap_slot[i] < 3 ? s_ap_slot[i] : 0];
+#endif
                 atomicMin(&hb[0], cx); atomicMax(&hb[1], cx); atomicMin(&hb[2], cy); atomicMax(&hb[3], cy);
                 atomicMin(&hb[4], az); atomicMax(&hb[5], az);
             }
@@ -534,7 +546,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     // so it may as well end at the first held node its trace meets (same results, the doomed attempt's remaining
                     // trace and searches are skipped)
                     const bool doomable = V2 && attempt + 1 < b.maze_end_iter;
-                    bool doomed = false;
+                    bool doomed = false, dirty = false;        // dirty: part of the doomed trace was already flushed (its nodes are sources)
                     auto flush = [&]() __attribute__((always_inline)) {        // the listed path nodes: sources of the next search, claimed if nobody holds them
                         XR3_WSYNC();
                         const int pl0 = plen - np;              // (the listed nodes are path[pl0 .. plen): one coalesced store per 64 nodes —
@@ -567,9 +579,10 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         plen++; np++;
                         fnv_mix(h, (uint32_t)v);
                         v = u; vw = uw;
-                        if (np == XR3_TMP) flush();
+                        if (np == XR3_TMP) { flush(); dirty = true; }
                     }
                     if (!doomed) flush();
+                    if (doomed && lane == 0) s_retry = dirty ? 1 : 2;       // 2: the next attempt resumes at THIS search, 1: it starts over
                     if ((status & 0x100) || doomed) remaining = 0;
                     else {
                         // terminal node of the component: claimed (and recorded) only if nobody holds it yet
@@ -594,16 +607,21 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     // ---- does the attempt stand (XR-Maze v2)?  Its path uses a node held by another net and attempts are left: rip it up ----
     if (wv == sw) {
         const bool retry = V2 && b.maze_end_iter > 1 && d_held > 0 && attempt + 1 < b.maze_end_iter;
-        if (V2 && lane == 0) s_retry = retry ? 1 : 0;
+        if (V2 && lane == 0 && !retry) s_retry = 0;             // (a doomed trace wrote 1 or 2: a held node is only ever met by one)
         if (!retry && lane == 0) {
             if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
+#ifdef XR_PHASE_TIMING
+            xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h, attempt + 1);       // (probe builds: XR_FETCH_TOUCHED = attempts)
+#else
             xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h);
+#endif
         }
     }
     XR_LAP(5);
     if (!V2) break;
     xr_lds_barrier();                                         // s_retry and the last sources are visible
-    const bool retry = s_retry != 0;
+    const int retry_kind = s_retry;
+    const bool retry = retry_kind != 0;
     if (!retry) {
         // ---- the attempt stands: its deferred claims.  A source word with the owner bit is a path node, the terminal node, or an
         // access point that had an owner when the route began.  Not held: owner 0 or this net -> this net (no load).  Held: another
@@ -619,21 +637,40 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         }
         break;
     }
-    // ---- rip-up: nothing reached global memory but the path list (overwritten by the next attempt) — every word goes back to
-    // "unreached" with its static bits (held, outside the guide), the masks are emptied, the component starts over.  LDS only.
+    // ---- rip-up: nothing reached global memory but the path list (overwritten by the next attempt).  The searches of this attempt
+    // BEFORE the one whose path met a held node would repeat themselves exactly under the doubled penalty: their paths use no held
+    // node, so they cost what they cost before while every alternative through a held node only got dearer — same distances along
+    // them, same first tight predecessors, same targets.  The next attempt therefore RESUMES at the failed search:
+    // the component (source words: access points of the connected pins, path nodes, their owner bits) and the tracing wave's sums
+    // as they were when that search began; every other word goes back to "unreached" with its static bits.  LDS only.
+    // (kind 1 — a trace so long that part of it was flushed before the held node showed: start over from the first pin.)
     attempt++;
     pen5 = ((uint32_t)b.pen_cost << 5) << attempt;
+    resume = retry_kind == 2;
+    for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_wmin[i] = XR_DIAL_INF; }
+    if (!resume)
+        for (int i = tid; i < nap; i += nthr) s_ap_conn[i] = (unsigned char)(s_ap_conn[i] == 2 ? 2 : (s_ap_pin[i] == (short)first_pin ? 1 : 0));
+    xr_lds_barrier();
     {
         const int nq = (N + 3) >> 2;
+        auto undo = [&](uint32_t w, int f) __attribute__((always_inline)) -> uint32_t {
+            if (w == 0u) return 0u;
+            if (resume && (w >> 5) == 0u) {                   // a source of the kept component: stays, and is open again
+                uint32_t q, r;
+                mask_pos((uint32_t)f, q, r);
+                atomicOr(&s_open[r], 1u << q);
+                s_wmin[r] = 0u;
+                return w;
+            }
+            return XR3_UNREACHED_V2 | (w & 3u);
+        };
         for (int c = tid; c < nq; c += nthr) {
             uint4* p4 = reinterpret_cast<uint4*>(field + (c << 2));
             uint4 w = *p4;
-            w.x = w.x ? (XR3_UNREACHED_V2 | (w.x & 3u)) : 0u;  w.y = w.y ? (XR3_UNREACHED_V2 | (w.y & 3u)) : 0u;
-            w.z = w.z ? (XR3_UNREACHED_V2 | (w.z & 3u)) : 0u;  w.w = w.w ? (XR3_UNREACHED_V2 | (w.w & 3u)) : 0u;
+            const int f = c << 2;
+            w.x = undo(w.x, f); w.y = undo(w.y, f + 1); w.z = undo(w.z, f + 2); w.w = undo(w.w, f + 3);
             *p4 = w;
         }
-        for (int i = tid; i < mw; i += nthr) { s_open[i] = 0; s_defer[i] = 0; s_wmin[i] = XR_DIAL_INF; }
-        for (int i = tid; i < nap; i += nthr) s_ap_conn[i] = (unsigned char)(s_ap_conn[i] == 2 ? 2 : (s_ap_pin[i] == (short)first_pin ? 1 : 0));
     }
     xr_lds_barrier();
     XR_LAP(7);
