@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--region-pack", default=None,
                     help="npz of design-derived regions (tools/extract_regions.py), cycled over the env slots, instead of the "
                          "synthetic generator; NOT the headline workload")
+    ap.add_argument("--maze-v2", action="store_true",
+                    help="the main batch routes with XR-Maze v2 (the reference's TCL knobs: maze_end_iter 3, guide cost 800, margin 1 with a "
+                         "region pack's own guide rectangles / 2 with the default guides) — NOT the headline; used with --region-pack")
     ap.add_argument("--no-observation", action="store_true", help="skip the observation (NOT the headline)")
     ap.add_argument("--no-stagger", action="store_true", help="start every episode at step 0 (round-1 behaviour: NOT stationary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -374,10 +377,11 @@ def main():
             dist.destroy_process_group()
         return
 
+    main_v2 = dict(V2_KNOBS, guide_margin=1 if args.region_pack else 2) if args.maze_v2 else {}
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
                         obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
                         dial_mult=args.dial_mult, obs_helper_blocks=args.helper_blocks, obs_split_permille=args.quota,
-                        launch_order=args.launch_order)
+                        launch_order=args.launch_order, **main_v2)
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()
@@ -662,7 +666,7 @@ def main():
         try:
             seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
             parity = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
-                                  actions_log=acts_log.cpu().numpy() if learner else None)
+                                  actions_log=acts_log.cpu().numpy() if learner else None, v2=main_v2 or None)
         except Exception as ex:
             parity = {"error": str(ex), "ok": False}
     if world > 1:
@@ -692,7 +696,7 @@ def main():
                                     f"north_star target: a {Bg}-env batch of ispd18_test1-sized regions (24x40x9, K~U[4,36]; generator of "
                                     f"BASELINE configs 2-4), {B} per GPU, ")
                                    +
-                                   "full step = random net-order action + XR-Maze v1 route + metrics/reward"
+                                   f"full step = random net-order action + XR-Maze {'v2 (maze_end_iter 3, guide cost 800)' if args.maze_v2 else 'v1'} route + metrics/reward"
                                    + ("" if obs is None else " + reference-layout fp32 observation of every env")
                                    + (" (queue form: one persistent launch after a planning kernel)" if headline_form == 3 else
                                       " (split form: route kernel + concurrent net-plane writer)" if headline_form == 2 else

@@ -2,7 +2,11 @@
 CPU oracle stepped with the same actions; compares deltas, done flags and rewards every step and every env's hash
 chain (every path node of every step) at the end.
 
-    python tools/soak.py [B=4096] [STEPS=300] [config=3] [obs|inplace]
+    python tools/soak.py [B=4096] [STEPS=300] [config=3] [obs|inplace|route] [pack-v2|pack]
+
+`pack-v2`: the env slots play the design-derived ispd18_test1 regions (tests/golden/ispd18_test1_regions.npz) with the reference's
+simulator configuration — XR-Maze v2: maze_end_iter 3, guide cost 800 over the design's guide rectangles, margin 1 — on both sides
+(`pack`: the same regions with XR-Maze v1).
 
 With `obs` the GPU steps with its observation (xr_batch_step_observe, default form) and the observations of 32 envs
 (a different set every step) are compared byte for byte with the oracle's; `inplace` does the same through the in-place
@@ -20,9 +24,18 @@ cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 with_obs = len(sys.argv) > 4 and sys.argv[4] in ("obs", "inplace")
 inplace = len(sys.argv) > 4 and sys.argv[4] == "inplace"
 n_inplace = 0
-regions = config_regions(cfg, B)
-batch = RegionBatch(regions, n_envs=B, auto_reset=True)
-ob = orc.OracleBatch(regions)
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+if mode in ("pack", "pack-v2"):
+    from xroute_env_amd.lefdef import load_region_pack
+    pack = load_region_pack(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ispd18_test1_regions.npz"))
+    v2 = dict(guide_cost=800, guide_margin=1, maze_end_iter=3) if mode == "pack-v2" else {}
+    regions = [pack[e % len(pack)] for e in range(B)]
+    batch = RegionBatch(pack, n_envs=B, auto_reset=True, max_route_count=1 << 30, **v2)
+    ob = orc.OracleBatch(regions, **v2)
+else:
+    regions = config_regions(cfg, B)
+    batch = RegionBatch(regions, n_envs=B, auto_reset=True)
+    ob = orc.OracleBatch(regions)
 threads = ob.max_threads()
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
@@ -52,7 +65,7 @@ for it in range(STEPS):
 hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
 ref = np.array([e.hash() for e in ob.envs], dtype=np.uint64)
 ok = np.array_equal(hashes, ref) and batch.total_steps() == real
-print(f"soak config {cfg}: {B} envs x {STEPS} steps = {real} env-steps in {time.time()-t0:.0f}s, {threads} oracle threads: "
+print(f"soak {mode or 'config ' + str(cfg)}: {B} envs x {STEPS} steps = {real} env-steps in {time.time()-t0:.0f}s, {threads} oracle threads: "
       f"deltas/done/reward equal every step, hash chains equal: {ok}"
       + (f", {obs_checked} observations byte-equal (form {batch.observe_timing()[0] & 15}" + (f", in-place path in {n_inplace} of {STEPS} steps" if inplace else "") + ")" if with_obs else ""))
 sys.exit(0 if ok else 1)

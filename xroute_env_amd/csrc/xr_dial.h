@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __shared__ int s_nhb;
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
-    __shared__ int s_nG, s_nA, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
+    __shared__ int s_nG, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
     __shared__ int s_gb[4], s_retry, s_ngb;                   // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
     __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                // ... and its guide (xr_guide_load)
 
@@ -1370,41 +1370,55 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             const int nG = s_nG;
             // chunks of the active groups: 8 groups (= 256 words = one A list) at a time
             for (int g0 = 0; g0 < nG; g0 += XR_BIG_CA / 32) {
-                if (tid == 0) { s_nA = 0; s_nN = 0; s_nE[0] = 0; s_nE[1] = 0; }
+                if (tid == 0) { s_nN = 0; s_nE[0] = 0; s_nE[1] = 0; }
                 __syncthreads();
-                // ---- A2: active words of these groups --------------------------------------------------
-                for (int i = tid; i < XR_BIG_CA; i += nthr) {
-                    const int gi = g0 + (i >> 5);
-                    if (gi < nG) {
-                        const int g = s_G[gi];
-                        const int wd = (g << 5) + (i & 31);
-                        if (wd < mw) {
-                            const uint32_t wm = xr_ld(&wming[wd]);
-                            // active: the cached minimum is reset HERE — the barrier below orders the reset before any lane takes
-                            // the bits (stage B), so a concurrent insertion is either seen by stage C or keeps its own minimum
-                            if (wm < hi) { s_A[atomicAdd(&s_nA, 1)] = (uint32_t)wd; xr_st(&wming[wd], XR_DIAL_INF); }
-                            else if (wm != XR_DIAL_INF) { atomicMin(&s_gmin[g], wm); lmin = wm < lmin ? wm : lmin; }
+                // ---- A2 + B (fused, round 4): active words of these groups, and their open bits -> node list.  The cached minimum is
+                // read AND reset by ONE atomic exchange (a word that turns out inactive gets its bound back by an atomicMin — nobody reads
+                // it in between: insertions only happen in stages C / D, behind barriers); the exchange has returned, i.e. the reset is
+                // done at L2, before the same lane takes the bits — "reset, THEN take the bits, THEN read distances" holds without the
+                // barrier and the A list that used to sit between the two stages: two dependent round trips instead of three.
+                {
+                    constexpr int XR_A2_MAXW = 8;                      // words a thread looks at per chunk (XR_BIG_CA / blockDim.x)
+                    uint32_t wds[XR_A2_MAXW], wms[XR_A2_MAXW];
+                    int gs[XR_A2_MAXW];
+                    for (int base = 0; base < XR_BIG_CA; base += XR_A2_MAXW * nthr) {
+#pragma unroll
+                        for (int u = 0; u < XR_A2_MAXW; u++) {          // all exchanges of this thread in flight together
+                            const int i = base + u * nthr + tid;
+                            const int gi = g0 + (i >> 5);
+                            wds[u] = 0xFFFFFFFFu; wms[u] = XR_DIAL_INF; gs[u] = 0;
+                            if (i < XR_BIG_CA && gi < nG) {
+                                const int g = s_G[gi];
+                                const int wd = (g << 5) + (i & 31);
+                                if (wd < mw) { wds[u] = (uint32_t)wd; gs[u] = g; wms[u] = atomicExch(&wming[wd], XR_DIAL_INF); }
+                            }
                         }
-                    }
-                }
-                __syncthreads();
-                // ---- B: take the open bits of the active words -> node list --------------------------------
-                const int nA = s_nA;
-                for (int i = tid; i < nA; i += nthr) {
-                    const uint32_t wd = s_A[i];
-                    uint32_t bits = atomicExch(&openg[wd], 0u);
-                    const int cnt = __popc(bits);
-                    if (cnt) {
-                        const int pos = atomicAdd(&s_nN, cnt);
-                        if (pos + cnt <= XR_BIG_CN) {
-                            int k = pos;
-                            while (bits) { s_N[k++] = (wd << 5) + (uint32_t)(__ffs((int)bits) - 1); bits &= bits - 1; }
-                        } else {                                        // no room in this chunk: back into the mask, seen again next round
-                            atomicAdd(&s_nN, -cnt);
-                            atomicOr(&openg[wd], bits);
-                            atomicMin(&wming[wd], m);
-                            atomicMin(&s_gmin[wd >> 5], m);
-                            lmin = m < lmin ? m : lmin;
+                        uint32_t bitsv[XR_A2_MAXW];
+#pragma unroll
+                        for (int u = 0; u < XR_A2_MAXW; u++) {
+                            bitsv[u] = 0u;
+                            if (wds[u] == 0xFFFFFFFFu) continue;
+                            const uint32_t wm = wms[u];
+                            if (wm < hi) bitsv[u] = atomicExch(&openg[wds[u]], 0u);
+                            else if (wm != XR_DIAL_INF) { atomicMin(&wming[wds[u]], wm); atomicMin(&s_gmin[gs[u]], wm); lmin = wm < lmin ? wm : lmin; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < XR_A2_MAXW; u++) {
+                            uint32_t bits = bitsv[u];
+                            const int cnt = __popc(bits);
+                            if (!cnt) continue;
+                            const uint32_t wd = wds[u];
+                            const int pos = atomicAdd(&s_nN, cnt);
+                            if (pos + cnt <= XR_BIG_CN) {
+                                int k = pos;
+                                while (bits) { s_N[k++] = (wd << 5) + (uint32_t)(__ffs((int)bits) - 1); bits &= bits - 1; }
+                            } else {                                        // no room in this chunk: back into the mask, seen again next round
+                                atomicAdd(&s_nN, -cnt);
+                                atomicOr(&openg[wd], bits);
+                                atomicMin(&wming[wd], m);
+                                atomicMin(&s_gmin[wd >> 5], m);
+                                lmin = m < lmin ? m : lmin;
+                            }
                         }
                     }
                 }
