@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 5
+#define XR_ABI_VERSION 6
 
 /* status codes */
 #define XR_OK            0
@@ -143,7 +143,11 @@ typedef struct xr_config {
                                  struct's former tail padding: sizeof(xr_config) is unchanged.) */
     int32_t debug_round_cap;  /* 0 = default.  > 0: relaxation rounds one search of the router may take before it aborts with
                                  XR_ENV_ROUTER_ABORT (tests force the abort path with 1) */
-    int32_t reserved0;        /* keep 0 */
+    int32_t window;           /* regions whose distance field does not fit LDS (BASELINE config 5): the router first runs inside an LDS window of
+                                 the region centred on the net and accepts the result only with an exactness certificate (no shortest path to
+                                 anything the step looks at leaves the window), else the HBM-scratch form routes the net.  0 = default: the
+                                 largest square window that fits LDS (52 tracks at 12 layers); > 0: that many tracks (tests force fallbacks
+                                 with small ones); < 0: off.  Results never depend on it.  (ABI 6; was reserved0 = 0.) */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */

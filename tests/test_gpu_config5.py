@@ -65,10 +65,11 @@ def test_config5_fullsize_route_order_matches_oracle(regions):
         assert np.array_equal(owner[e, : r.n_nodes], env.owner())
 
 
-# 0: bucketed frontier, HBM-scratch form (default: 1024-thread workgroups for a batch this small; 512 is what a large batch gets);
-# 1: line-segment sweeps in scratch
-@pytest.mark.parametrize("router,block_threads", [(0, 0), (0, 512), (1, 0)])
-def test_config5_32_envs_10_steps_match_oracle(router, block_threads):
+# 0: bucketed frontier — LDS-window form first, HBM-scratch form for what does not fit or certify (default: 1024-thread workgroups and a
+#    52-track window for a batch this small; 512 threads / a 36-track window is what a large batch gets; window 20: most nets fall back;
+#    -1: the HBM-scratch form alone);  1: line-segment sweeps in scratch
+@pytest.mark.parametrize("router,block_threads,window", [(0, 0, 0), (0, 512, 0), (0, 0, 20), (0, 512, 36), (0, 0, -1), (1, 0, 0)])
+def test_config5_32_envs_10_steps_match_oracle(router, block_threads, window):
     """32 full-size config 5 envs x 10 batched steps (random net order, K = 32) against the oracle stepped with OpenMP over
     envs: deltas, done, path length, reward of every env at every step; owner grids, cumulative metrics and the hash chains
     (every path node of every step) at the end.  The scratch of the frontier router must be left CLEAN by every route —
@@ -76,8 +77,10 @@ def test_config5_32_envs_10_steps_match_oracle(router, block_threads):
     from xroute_env_amd.batch import RegionBatch
     B, STEPS = 32, 10
     regs = config_regions(5, B)
-    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router, launch_order=2 if router == 0 else 0, block_threads=block_threads)
+    batch = RegionBatch(regs, device="cuda:0", auto_reset=True, router=router, launch_order=2 if router == 0 else 0, block_threads=block_threads,
+                        window=window)
     batch.reset()
+    forms = set()
     ob = orc.OracleBatch(regs)
     threads = ob.max_threads()
     acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
@@ -89,6 +92,9 @@ def test_config5_32_envs_10_steps_match_oracle(router, block_threads):
         rec = batch.records()
         assert np.array_equal(rec["delta"], ref["delta"]), it
         assert np.array_equal(rec["done"], ref["done"]) and np.array_equal(rec["reward"], ref["reward"])
+        forms |= set((batch.fetch("touched").cpu().numpy()[a > 0] > 0).tolist())
+    if router == 0:       # XR_FETCH_TOUCHED > 0 <=> the HBM-scratch form routed the net; both forms must have run (window on) / only that one (off)
+        assert forms == ({True} if window < 0 else {False, True}), forms
     owner = batch.fetch("owner").cpu().numpy()
     hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
     for e, env in enumerate(ob.envs):
@@ -117,7 +123,7 @@ from oracle import xr_oracle as orc
 from xroute_env_amd.batch import RegionBatch
 from xroute_env_amd.regions import generate_region
 regs = [generate_region(7700 + i, dims=(40, 48, 6), k_range=(6, 10), net_span=30, blockage=(0.25, 0.35)) for i in range(12)]
-batch = RegionBatch(regs, device="cuda:0", auto_reset=True, force_scratch_field=True)
+batch = RegionBatch(regs, device="cuda:0", auto_reset=True, force_scratch_field=True, window=-1)
 batch.reset()
 ob = orc.OracleBatch(regs)
 acts = torch.empty(len(regs), dtype=torch.int32, device="cuda:0")

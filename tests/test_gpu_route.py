@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
     from oracle import xr_oracle as orc
     from xroute_env_amd.batch import RegionBatch
-    batch = RegionBatch(regions, device="cuda:0", **kw)
+    batch = RegionBatch(regions, device="cuda:0", **{k: v for k, v in kw.items() if k != "expect_forms"})
     v2 = {k: kw[k] for k in ("guide_cost", "guide_margin", "maze_end_iter") if k in kw}
     envs = [orc.OracleEnv(r, kw.get("via_cost", 800), kw.get("drc_cost", 8), kw.get("drc_unit", 400), **v2) for r in regions]
+    paths_taken = set()
     batch.reset()
     rng = np.random.default_rng(5)
     total = 0
@@ -41,10 +42,12 @@ def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
         path = batch.fetch("path").cpu().numpy()
         owner = batch.fetch("owner").cpu().numpy()
         reward = batch.fetch("reward").cpu().numpy()
+        touched = batch.fetch("touched").cpu().numpy()
         for i, env in enumerate(envs):
             if not acts[i]:
                 assert status[i] & 1        # XR_ENV_BAD_ACTION on a finished env without auto_reset
                 continue
+            paths_taken.add(bool(touched[i]))
             ref = env.step(acts[i])
             assert status[i] == ref["status"], (i, status[i], ref["status"])
             assert delta[i].tolist() == ref["delta"].tolist(), (i, acts[i], delta[i], ref["delta"])
@@ -57,6 +60,8 @@ def _run_episode_parity(regions, policy="min", max_steps=200, **kw):
             total += 1
     hashes = batch.fetch("hash").cpu().numpy().view(np.uint64)
     assert [int(h) for h in hashes] == [e.hash() for e in envs]
+    if kw.get("expect_forms") is not None:        # XR_FETCH_TOUCHED > 0 <=> the HBM-scratch form routed the net (0: an LDS form, incl. the window form)
+        assert kw["expect_forms"] <= paths_taken and (len(kw["expect_forms"]) > 1 or paths_taken == kw["expect_forms"] or False in kw["expect_forms"]), paths_taken
     return total
 
 
@@ -91,7 +96,7 @@ def test_route_parity_chunk_boundaries(dims, scratch):
     n = dims[0] * dims[1] * dims[2]
     regions = [generate_region(4200 + 13 * i + n, dims=dims, k_range=(3, 9), net_span=8, blockage=(0.2, 0.35))
                for i in range(5)]
-    assert _run_episode_parity(regions, policy="random", force_scratch_field=scratch) >= 15
+    assert _run_episode_parity(regions, policy="random", force_scratch_field=scratch, window=-1) >= 15
 
 
 def test_route_parity_policies_and_costs():
@@ -216,7 +221,7 @@ def test_equal_distance_targets_tie_goes_to_lowest_flat_index(scratch):
     ref = orc.OracleEnv(reg).step(1)
     first_target = int(ref["path"][0])
     assert first_target == (4 * 17 + 9) * 2          # (x=4, y=9, z=0): lower flat index than (6, 7, 0)
-    batch = RegionBatch([reg], device="cuda:0", force_scratch_field=scratch)
+    batch = RegionBatch([reg], device="cuda:0", force_scratch_field=scratch, window=-1)
     batch.reset()
     batch.step(torch.tensor([1], dtype=torch.int32, device="cuda:0"))
     plen = int(batch.fetch("path_len").cpu()[0])
@@ -228,7 +233,7 @@ def test_scratch_field_variant_full_parity_on_ispd_sized_regions():
     """The large-region code path (field in HBM scratch, layer-major layout) forced on ispd18-sized regions:
     same bit-exact parity as the LDS-resident path."""
     regions = [generate_region(5100 + i) for i in range(12)]
-    _run_episode_parity(regions, policy="random", force_scratch_field=True)
+    _run_episode_parity(regions, policy="random", force_scratch_field=True, window=-1)
 
 
 @pytest.mark.parametrize("form", ["lds", "scratch", "large"])
@@ -246,7 +251,7 @@ def test_xr_maze_v2_matches_the_oracle(v2, form):
                    for i in range(6)]
     else:
         regions = [generate_region(3300 + i) for i in range(16)]
-    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), **v2)
+    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), window=-1, **v2)
     envs = [orc.OracleEnv(r, **v2) for r in regions]
     v1 = [orc.OracleEnv(r) for r in regions]
     batch.reset()
@@ -318,7 +323,7 @@ def test_xr_maze_v2_guide_boxes_match_the_oracle(form):
     plain = [copy.copy(r) for r in regions]
     for r in plain:
         r.guide_off = r.guide_box = None
-    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), router=3 if form == "lds-round2" else 0, **v2)
+    batch = RegionBatch(regions, device="cuda:0", force_scratch_field=(form == "scratch"), window=-1, router=3 if form == "lds-round2" else 0, **v2)
     envs = [orc.OracleEnv(r, **v2) for r in regions]
     base = [orc.OracleEnv(r, **v2) for r in plain]
     batch.reset()
@@ -448,7 +453,7 @@ def test_longest_first_order_on_a_multi_round_batch():
     assert twins[1].fetch("route_order").abs().sum().item() == 0
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(force_scratch_field=True), dict(router=1), dict(router=3)],
+@pytest.mark.parametrize("kw", [dict(), dict(force_scratch_field=True, window=-1), dict(router=1), dict(router=3)],
                          ids=["frontier-lds", "frontier-hbm-scratch", "sweeps", "frontier-lds-round2"])
 def test_round_cap_aborts_the_net_not_the_device(kw):
     """No router loop is unbounded: a search that exceeds its round cap (default 1024 + N, forced to 1 here) gives up on the
@@ -481,9 +486,10 @@ def test_round_cap_aborts_the_net_not_the_device(kw):
     assert not np.any(ok.fetch("status").cpu().numpy() & _lib.XR_ENV_ROUTER_ABORT)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(router=3), dict(router=1), dict(force_scratch_field=True),
-                                dict(maze_end_iter=2), dict(maze_end_iter=2, force_scratch_field=True)],
-                         ids=["lds", "lds-round2", "sweeps", "scratch", "lds-v2", "scratch-v2"])
+@pytest.mark.parametrize("kw", [dict(), dict(router=3), dict(router=1), dict(force_scratch_field=True, window=-1),
+                                dict(maze_end_iter=2), dict(maze_end_iter=2, force_scratch_field=True), dict(force_scratch_field=True, window=0),
+                                dict(force_scratch_field=True, window=160)],
+                         ids=["lds", "lds-round2", "sweeps", "scratch", "lds-v2", "scratch-v2", "window", "window-160"])
 def test_distance_cap_rule_in_every_router_form(kw):
     """Spec: a distance >= XR_DIST_CAP = 0x07F00000 does not exist.  A track of nodes held by a pre-routed
     wire, 1 040 000 per node: the pin 128 columns away is reached at 132.1 M, the one 129 away is not (unreachable: one violation,
@@ -496,3 +502,17 @@ def test_distance_cap_rule_in_every_router_form(kw):
     regions = [cap_region(targets=(t,)) for t in (127, 128, 129, 130)] + [cap_region(targets=(120, 260))]
     n = _run_episode_parity(regions, **pen, **kw)
     assert n == len(regions)
+
+
+@pytest.mark.parametrize("window,forms", [(0, {False}), (16, {False, True}), (4, {True}), (-1, {True})])
+def test_window_form_of_the_lds_router_matches_the_oracle(window, forms):
+    """Round 4 (BASELINE config 5's path): regions whose field is kept out of LDS are routed by the LDS router inside a WINDOW of the
+    region around the net, accepted only with the exactness certificate (no shortest path to anything the step looks at leaves the
+    window), else by the HBM-scratch form.  Whole episodes on ispd18_test1-sized regions forced onto that path (`force_scratch_field`)
+    equal the oracle whatever the window: the default (24 tracks: the region's width), 16 tracks (some nets fit, some do not, some
+    certificates fail: both forms must have run), 4 tracks (below the smallest window: the form is off), off."""
+    regions = [generate_region(3900 + i) for i in range(16)]
+    n = _run_episode_parity(regions, policy="random", force_scratch_field=True, window=window, expect_forms=forms)
+    assert n > 150
+    n = _run_episode_parity(regions[:6], policy="max", force_scratch_field=True, window=window, via_cost=5000, drc_cost=0, drc_unit=400)
+    assert n > 50

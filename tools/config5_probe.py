@@ -13,7 +13,7 @@ regions = config_regions(5, R)
 print(f"generated {R} regions in {time.time()-t0:.1f}s, nets {[r.n_nets for r in regions][:8]}")
 thr = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 mult = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-batch = RegionBatch(regions, n_envs=B, auto_reset=True, block_threads=thr, dial_mult=mult)
+batch = RegionBatch(regions, n_envs=B, auto_reset=True, block_threads=thr, dial_mult=mult, window=int(os.environ.get('XR_WINDOW', '0')))
 print('block_threads', thr or 'default', 'dial_mult', mult or 'default', 'occupancy', batch.route_occupancy())
 batch.reset()
 acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
@@ -25,4 +25,4 @@ for it in range(3):
     sw = batch.fetch("sweeps").float().mean().item()
     d = batch.fetch("delta").float().mean(0).tolist()
     st = batch.fetch("status").cpu()
-    print(f"step {it}: {dt*1e3:.1f} ms for {B} envs -> {B/dt:.0f} env-steps/s, mean iterations {sw:.1f}, mean delta {d}, unreachable {(st & 2).ne(0).sum().item()}")
+    print(f"step {it}: {dt*1e3:.1f} ms for {B} envs -> {B/dt:.0f} env-steps/s, mean iterations {sw:.1f}, mean delta {d}, unreachable {(st & 2).ne(0).sum().item()}, routed by the HBM-scratch form {(batch.fetch('touched') > 0).sum().item()}")

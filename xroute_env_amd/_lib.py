@@ -41,7 +41,7 @@ class XrConfig(C.Structure):
                 ("obs_writer_blocks", C.c_int32), ("router", C.c_int32), ("dial_mult", C.c_int32),
                 ("guide_cost", C.c_int32), ("guide_margin", C.c_int32), ("maze_end_iter", C.c_int32),
                 ("stream_per_region", C.c_int32), ("obs_helper_blocks", C.c_int32), ("obs_split_permille", C.c_int32),
-                ("launch_order", C.c_int32), ("debug_round_cap", C.c_int32), ("reserved0", C.c_int32)]
+                ("launch_order", C.c_int32), ("debug_round_cap", C.c_int32), ("window", C.c_int32)]
 
 
 class XrStepRecord(C.Structure):          # include/xroute_hip.h xr_step_record (48 bytes)
@@ -117,7 +117,7 @@ def lib():
         fn = getattr(L, name)
         if name not in ("xr_last_error", "xr_config_default"):
             fn.restype = C.c_int32
-    if L.xr_abi_version() != 5:
+    if L.xr_abi_version() != 6:
         raise RuntimeError("libxroute_hip.so ABI version mismatch")
     _LIB = L
     return L

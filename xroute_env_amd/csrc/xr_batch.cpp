@@ -126,6 +126,7 @@ struct xr_batch {
     DevBuf<unsigned long long> total_steps;
     DevBuf<uint32_t> dist_scratch, dg_field, dg_masks, dg_touch, dg_path;
     bool dial_big = false;
+    struct { int x = 0, y = 0, nmax = 0, margin = 0, ystep = 1; uint32_t m24_yz = 0, m24_z = 0, m24_mw = 0, s24 = 0; } win;   // window form (xr_dial3.h, WIN); x = 0: off
     DevBuf<unsigned short> list_scratch;
     // split observation
     DevBuf<int32_t> plan_region, plan_unit_net;
@@ -187,7 +188,7 @@ void xr_config_default(xr_config* c) {
     c->obs_helper_blocks = 0;
     c->launch_order = 0;
     c->debug_round_cap = 0;
-    c->reserved0 = 0;
+    c->window = 0;
     c->w_violation = 500.0;    // baseline/DQN/train_DQN.py:99
     c->w_via = 4.0;
     c->w_wirelength = 0.5;
@@ -270,6 +271,23 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     int64_t ext_max = 0;                 // widest span of a region's tracks in x or y, DBU
     std::map<uint64_t, uint64_t> magic_cache;   // (divisor, limit) -> multiplier << 8 | shift (0xFF: none)
     bool div24_all = true;               // every region has its exact 24-bit division constants
+    // exact 24-bit magics (largest shift whose multiplier and products fit, then checked for every n below `lim`)
+    auto magic24 = [&](uint32_t dv, uint32_t lim, uint32_t& M, uint32_t& S) -> bool {
+        const uint64_t key = ((uint64_t)dv << 32) | lim;
+        auto it = magic_cache.find(key);
+        if (it != magic_cache.end()) { M = (uint32_t)(it->second >> 8); S = (uint32_t)(it->second & 0xFF); return S != 0xFF; }
+        bool found = false;
+        if (lim <= (1u << 24))
+            for (int sh = 31; sh >= 0 && !found; sh--) {
+                const uint64_t m = (((uint64_t)1 << sh) + dv - 1) / dv;
+                if (m >= (1u << 24) || (uint64_t)(lim > 0 ? lim - 1 : 0) * m >= ((uint64_t)1 << 32)) continue;
+                bool ok = true;
+                for (uint32_t nn = 0; nn < lim && ok; nn++) ok = (uint32_t)(((uint64_t)nn * m) >> sh) == nn / dv;
+                if (ok) { M = (uint32_t)m; S = (uint32_t)sh; found = true; }
+            }
+        magic_cache[key] = found ? (((uint64_t)M << 8) | S) : 0xFF;
+        return found;
+    };
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
@@ -304,23 +322,6 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             R.magic_z = zz >= 2 ? (uint32_t)((1ULL << 32) / zz) : 0xFFFFFFFFu;
             const uint32_t mwv = (uint32_t)((n64 + 31) / 32);
             R.magic_mw = mwv >= 2 ? (uint32_t)((1ULL << 32) / mwv) : 0xFFFFFFFFu;
-            // exact 24-bit magics (largest shift whose multiplier and products fit, then checked for every n below `lim`)
-            auto magic24 = [&](uint32_t dv, uint32_t lim, uint32_t& M, uint32_t& S) -> bool {
-                const uint64_t key = ((uint64_t)dv << 32) | lim;
-                auto it = magic_cache.find(key);
-                if (it != magic_cache.end()) { M = (uint32_t)(it->second >> 8); S = (uint32_t)(it->second & 0xFF); return S != 0xFF; }
-                bool found = false;
-                if (lim <= (1u << 24))
-                    for (int sh = 31; sh >= 0 && !found; sh--) {
-                        const uint64_t m = (((uint64_t)1 << sh) + dv - 1) / dv;
-                        if (m >= (1u << 24) || (uint64_t)(lim > 0 ? lim - 1 : 0) * m >= ((uint64_t)1 << 32)) continue;
-                        bool ok = true;
-                        for (uint32_t nn = 0; nn < lim && ok; nn++) ok = (uint32_t)(((uint64_t)nn * m) >> sh) == nn / dv;
-                        if (ok) { M = (uint32_t)m; S = (uint32_t)sh; found = true; }
-                    }
-                magic_cache[key] = found ? (((uint64_t)M << 8) | S) : 0xFF;
-                return found;
-            };
             uint32_t s_yz = 0, s_z = 0, s_mw = 0;
             const bool okd = n64 < 65536 && magic24(yz, (uint32_t)n64, R.m24_yz, s_yz) && magic24(zz, yz, R.m24_z, s_z) &&
                              magic24(std::max(1u, mwv), (uint32_t)n64, R.m24_mw, s_mw);
@@ -573,6 +574,46 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                 if (hipGetDeviceProperties(&prop, b->cfg.device) == hipSuccess && B <= 4 * prop.multiProcessorCount) big_threads = 1024;
             }
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : big_threads;
+            // the LDS router inside a window of the region first (xr_dial3.h, WIN; xr_config.window: 0 = the largest square window that
+            // fits LDS, > 0 = that many tracks, < 0 = off): every region must have the same layer count and hold the window, rows of the
+            // state arrays must start on 16-byte boundaries wherever a window row may start, the arithmetic limits are those of the form
+            b->win = {};
+            const bool v2cfg = b->cfg.guide_cost > 0 || b->cfg.maze_end_iter > 1;
+            const int64_t pen_w = (int64_t)b->cfg.drc_cost * b->cfg.drc_unit;
+            if (b->cfg.window >= 0 && !v2cfg && z_min == z_max && edge_max + pen_w < XR3_STEP_LIMIT) {
+                const int Zw = z_max;
+                int ystep = 1;
+                while ((ystep * Zw) % 8) ystep *= 2;                 // rows start at y0 * Z elements: a multiple of 8 of them (16 bytes of int16)
+                bool rows_ok = true;
+                int xmin = 1 << 30, ymin = 1 << 30;
+                for (int r = 0; r < n_regions; r++) {
+                    rows_ok = rows_ok && ((int64_t)regs[r].dim_y * Zw) % 8 == 0;
+                    xmin = std::min(xmin, (int)regs[r].dim_x); ymin = std::min(ymin, (int)regs[r].dim_y);
+                }
+                int w = b->cfg.window > 0 ? b->cfg.window : 64;
+                w = std::min(w, std::min(xmin, ymin));
+                for (; w >= 8 && rows_ok; w--) {
+                    if ((w * Zw) % 8) continue;                          // a chunk of 8 nodes never straddles two window rows
+                    const int64_t nw = (int64_t)w * w * Zw;
+                    const size_t wl = XR3_LDS_BYTES((nw + 7) & ~7, w, w);
+                    // (a batch of more than ~4 routes per CU runs two 512-thread workgroups per CU: the window then gets half the LDS)
+                    const size_t lds_cap = (big_threads == 1024 || b->cfg.window > 0) ? kLdsLimit : kLdsLimit / 2;
+                    if (nw >= 65536 || std::max(wl, big_lds) + 2 * kLdsStatic > lds_cap || (int64_t)w * edge_max >= XR3_EXTENT_LIMIT) continue;
+                    uint32_t myz, syz, mz, sz, mmw, smw;
+                    const uint32_t mwv = (uint32_t)((nw + 31) / 32);
+                    if (!magic24((uint32_t)(w * Zw), (uint32_t)nw, myz, syz) || !magic24((uint32_t)Zw, (uint32_t)std::max(w, 1) * Zw * 2, mz, sz) ||
+                        !magic24(mwv, (uint32_t)nw, mmw, smw)) continue;
+                    b->win.x = w; b->win.y = w; b->win.nmax = (int)((nw + 7) & ~7); b->win.ystep = ystep;
+                    // tracks kept free around the net's box (the row alignment is checked per net).  A forced window (tests) keeps a small
+                    // margin; the automatic one a quarter of the window: a net whose box nearly fills the window floods past its faces, fails
+                    // its certificate and has paid for the attempt on top of the fallback (profiles/r04_k_config5_window.txt)
+                    b->win.margin = b->cfg.window > 0 ? std::max(1, std::min(4, w / 8)) : std::max(1, w / 4);
+                    if (const char* em = getenv("XR_WINDOW_MARGIN")) b->win.margin = std::max(1, atoi(em));      // (A/B runs)
+                    b->win.m24_yz = myz; b->win.m24_z = mz; b->win.m24_mw = mmw; b->win.s24 = syz | (sz << 8) | (smw << 16);
+                    b->route_lds = std::max(b->route_lds, wl);
+                    break;
+                }
+            }
         }
         // round 3's LDS form (xr_dial3.h) where it applies: the field fits with its queues, node ids fit 16 bits, and its 27-bit distance
         // arithmetic cannot wrap: every distance that exists is below XR_DIST_CAP = 0x07F00000 (spec; a candidate at or above the cap is
@@ -741,6 +782,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     d.dial_mult = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : ((b->kzch == -3 || b->kzch == -4) ? 12 : 8);
     d.dial_mult_big = b->cfg.dial_mult > 0 ? b->cfg.dial_mult : 8;
     d.round_cap = b->cfg.debug_round_cap;
+    d.win_x = b->dial_big ? b->win.x : 0; d.win_y = b->win.y; d.win_nmax = b->win.nmax; d.win_margin = b->win.margin; d.win_ystep = b->win.ystep;
+    d.win_m24_yz = b->win.m24_yz; d.win_m24_z = b->win.m24_z; d.win_m24_mw = b->win.m24_mw; d.win_s24 = b->win.s24;
     d.guide_cost = b->cfg.guide_cost; d.guide_margin = b->cfg.guide_margin; d.maze_end_iter = b->cfg.maze_end_iter;
     d.dg_field = b->dg_field.p; d.dg_masks = b->dg_masks.p; d.dg_touch = b->dg_touch.p; d.dg_path = b->dg_path.p;
     d.dist_scratch = b->dist_scratch.p; d.cls_scratch = b->cls_scratch.p; d.list_scratch = b->list_scratch.p; d.phase_cycles = b->phase_cycles.p;

@@ -159,5 +159,9 @@ struct XrBatchDev {
     int32_t dial_mult_big;   // the same for the HBM-scratch form
     int32_t dial_mult;       // bucket width of the frontier router in units of the region's smallest edge length
     int32_t round_cap;       // relaxation rounds one search may take before the router aborts (0: 1024 + N), XR_ENV_ROUTER_ABORT
+    // window form of the LDS router for regions that do not fit LDS (xr_dial3.h, WIN; 0 = off): window of win_x x win_y tracks on every
+    // layer, win_nmax = its nodes padded to 8, margin kept around the net's access-point box, rows start at multiples of win_ystep
+    int32_t win_x, win_y, win_nmax, win_margin, win_ystep;
+    uint32_t win_m24_yz, win_m24_z, win_m24_mw, win_s24;   // exact 24-bit magics of the window's Y*Z, of Z and of its mask-word count (shifts packed like XrRegionDev::s24)
     double w_violation, w_via, w_wirelength;
 };

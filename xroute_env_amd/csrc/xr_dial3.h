@@ -70,8 +70,21 @@ __device__ __forceinline__ int xr3_mbcnt(unsigned long long m) {
 }
 
 // V2: XR-Maze v2 knobs compiled in (guide cost, rip-up-and-reroute), as in xr_dial.h
-template <bool V2>
-__device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const int e, const int a, char* smem) {
+// WIN (round 4, regions too large for LDS — BASELINE config 5): the SAME router inside a window of the region.  The window
+// (b.win_x x b.win_y tracks, every layer; fixed per batch so that its index arithmetic is constant) is centred on the box of the net's
+// access points; its nodes are loaded with coalesced 16-byte loads, the search, the trace and the claims run on window-local indices, and
+// after every search an EXACTNESS CERTIFICATE is checked: face = the smallest key d(u) + len(u, v) + h(v) over the window's boundary
+// nodes u and their neighbours v outside (penalty of v unknown: 0, a lower bound).  If face > the distance of the chosen target (or
+// nothing was reached and no boundary node was either), no shortest path to any node with d + h <= best leaves the window: take the
+// first edge (u, v) out of the window on such a path — its prefix lies inside, so u holds its exact distance here, and by consistency
+// of h key(v) <= best, i.e. face <= best.  Then the window's field equals the region's wherever the target choice and the trace look:
+// same target, same path, same metrics as the HBM-scratch form / the oracle.  Otherwise (or when the net's box does not fit) the
+// function returns false having changed nothing that counts (claims are deferred, the record is written last) and the caller routes
+// the net with xr_dial_route_env_big.  Returns true when the step is complete.
+template <bool V2, bool WIN = false>
+__device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const int e, const int a, char* smem) {
+    static_assert(!(V2 && WIN), "the window form carries XR-Maze v1 only");
+    constexpr bool DEFER = V2 || WIN;                           // claims are written by the attempt that stands, not by the trace
     __shared__ unsigned short s_ap_f[XR_MAX_AP_PER_NET];
     __shared__ short s_ap_pin[XR_MAX_AP_PER_NET];
     __shared__ unsigned char s_ap_conn[XR_MAX_AP_PER_NET];      // 0 target, 1 connected, 2 isolated (static, from the load)
@@ -84,14 +97,39 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ int s_remaining, s_abort;
     __shared__ int s_gb[4], s_retry, s_ngb;                     // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
     __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                  // ... and its guide (xr_guide_load, xr_dial.h): only read by the marking pass
+    __shared__ uint32_t s_face;                                 // window form: smallest key of an edge that leaves the window (this search)
+    __shared__ int s_fallback;
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    if (!xr_step_prologue(b, e, a)) return;
+    if (!xr_step_prologue(b, e, a)) return true;
 
     XR_T0();
     const XrRegionDev R = b.regions[b.env_region[e]];
-    const int X = R.X, Y = R.Y, Z = R.Z, N = R.N;
+    const int RX = R.X, RY = R.Y, Z = R.Z;                      // the region; X, Y, N below: the grid the router works on (the window)
+    const int RYZ = RY * Z;
+    int wx0 = 0, wy0 = 0;                                       // window origin (track indices of the region)
+    if (WIN) {
+        // ---- does the net fit?  Box of its access points (+ margin) against the window; the window is centred on it, kept inside the
+        // region and moved down to a row whose nodes start on a 16-byte boundary of the state rows
+        if (tid == 0) { s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1; s_fallback = 0; }
+        __syncthreads();
+        const int lo_ = b.net_csr[R.net_off + a], hi_ = b.net_csr[R.net_off + a + 1];
+        for (int i = lo_ + tid; i < hi_; i += nthr) {
+            const int apf = b.ap_node[R.ap_off + i];
+            const int gy = (apf / Z) % RY, gx = apf / RYZ;
+            atomicMin(&s_gb[0], gx); atomicMax(&s_gb[1], gx); atomicMin(&s_gb[2], gy); atomicMax(&s_gb[3], gy);
+        }
+        __syncthreads();
+        const int bx0 = s_gb[0], bx1 = s_gb[1], by0 = s_gb[2], by1 = s_gb[3];
+        const int spx = bx1 - bx0 + 1, spy = by1 - by0 + 1;
+        if (b.win_x > RX || b.win_y > RY || spx + 2 * b.win_margin > b.win_x || spy + 2 * b.win_margin > b.win_y) return false;    // uniform
+        wx0 = min(max(bx0 - ((b.win_x - spx) >> 1), 0), RX - b.win_x);
+        wy0 = min(max(by0 - ((b.win_y - spy) >> 1), 0), RY - b.win_y) & ~(b.win_ystep - 1);
+        if (by1 > wy0 + b.win_y - 1 || by0 < wy0) return false;
+        __syncthreads();                                        // (s_gb is initialised again below)
+    }
+    const int X = WIN ? b.win_x : RX, Y = WIN ? b.win_y : RY, N = WIN ? b.win_x * b.win_y * Z : R.N;
     const int YZ = Y * Z;
     const uint32_t ldir = R.ldir_mask;
     const int mw = (N + 31) >> 5;
@@ -100,21 +138,31 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     const int round_cap = b.round_cap > 0 ? b.round_cap : 1024 + N;
     const int16_t* __restrict__ node_net = b.rg_node_net + R.node_off;
     int16_t* __restrict__ owner = b.owner + (int64_t)e * b.n_max;
+    const uint32_t m24_yz = WIN ? b.win_m24_yz : R.m24_yz, m24_mw = WIN ? b.win_m24_mw : R.m24_mw, m24_z = WIN ? b.win_m24_z : R.m24_z;
+    const uint32_t s24w = WIN ? b.win_s24 : R.s24;
+    // working flat index -> flat index of the region (the state rows, the recorded path, the hash chain)
+    auto gflat = [&](int f) __attribute__((always_inline)) -> int {
+        if (!WIN) return f;
+        uint32_t xw, r;
+        xr3_divmod((uint32_t)f, uYZ, m24_yz, s24w & 31u, xw, r);
+        return ((wx0 + (int)xw) * RY + wy0) * Z + (int)r;
+    };
 
     // LDS carve:  field u32[n_max] | open | defer | wmin (u32[mw_max] each) | tab u32[x_max+2 + y_max+2] | tmp u16[TMP]
     //   open    bit f: node lowered but not expanded yet (transposed bit order, xr_dial.h: node f <-> word f % mw, bit f / mw)
     //   defer   bit f: an edge out of f was refused only because of the search bound; re-opened when the next search starts
     //   wmin[w] lower bound of the keys of the open nodes of word w (XR_DIAL_INF: none)
     uint32_t* field = reinterpret_cast<uint32_t*>(smem);
-    const int mw_max = (b.n_max >> 5) + 1;
-    uint32_t* s_open = field + b.n_max;
+    const int n_work = WIN ? b.win_nmax : b.n_max;              // (window form: the carve of XR3_LDS_BYTES(win_nmax, win_x, win_y))
+    const int mw_max = (n_work >> 5) + 1;
+    uint32_t* s_open = field + n_work;
     uint32_t* s_defer = s_open + mw_max;
     uint32_t* s_wmin = s_defer + mw_max;
     // coordinate tables (x32, relative to the first track): tab[k] = 32*(xs[clamp(k-1)] - xs[0]), k = 0 .. X+1 (the coordinate of
     // track x is tab[x+1]; padded at both ends); the y table follows at XO
     uint32_t* s_tab = s_wmin + mw_max;
-    const int XO = b.x_max + 2;
-    unsigned short* s_tmp = reinterpret_cast<unsigned short*>(s_tab + XO + b.y_max + 2);
+    const int XO = (WIN ? b.win_x : b.x_max) + 2;
+    unsigned short* s_tmp = reinterpret_cast<unsigned short*>(s_tab + XO + (WIN ? b.win_y : b.y_max) + 2);
 
     // loads that depend on (e, a) only: issued now, consumed after the grid build
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
@@ -125,9 +173,12 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         my_ap_f = b.ap_node[R.ap_off + ap_lo + tid]; my_ap_pin = b.ap_pin[R.ap_off + ap_lo + tid];
         my_ap_iso = b.ap_flags[R.ap_off + ap_lo + tid];
     }
+    // (window form: entry k is the track wx0 + k - 1 of the REGION — the two pad entries hold the coordinates of the tracks just outside
+    //  the window where the region goes on: what the certificate's edge lengths need — relative to the lowest of them)
+    const int cbx = b.coords[R.xs_off + max(wx0 - 1, 0)], cby = b.coords[R.ys_off + max(wy0 - 1, 0)];
     uint32_t my_xc = 0, my_yc = 0;
-    if (tid <= X + 1) my_xc = (uint32_t)(b.coords[R.xs_off + min(max(tid - 1, 0), X - 1)] - b.coords[R.xs_off]) << 5;
-    if (tid <= Y + 1) my_yc = (uint32_t)(b.coords[R.ys_off + min(max(tid - 1, 0), Y - 1)] - b.coords[R.ys_off]) << 5;
+    if (tid <= X + 1) my_xc = (uint32_t)(b.coords[R.xs_off + min(max(wx0 + tid - 1, 0), RX - 1)] - cbx) << 5;
+    if (tid <= Y + 1) my_yc = (uint32_t)(b.coords[R.ys_off + min(max(wy0 + tid - 1, 0), RY - 1)] - cby) << 5;
     const int first_pin = ninfo & 0x3FFF, npins = (ninfo >> 14) & 0xFF;
     const int n_isolated = (ninfo >> 30) & 1 ? npins - 1 : (ninfo >> 22) & 0xFF;      // unreachable pins known up front
 
@@ -140,8 +191,10 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             for (int u = 0; u < 4; u++) {
                 const int ci = c0 + u * nthr;
                 if (ci < nchunk) {
-                    vn[u] = *reinterpret_cast<const int4*>(node_net + (ci << 3));
-                    vo[u] = *reinterpret_cast<const int4*>(owner + (ci << 3));
+                    const int g0 = gflat(ci << 3);            // (window form: a chunk of 8 never straddles a window row — (win_y * Z) % 8 == 0 — and
+                                                              //  starts on a 16-byte boundary of the rows: wy0 is a multiple of win_ystep)
+                    vn[u] = *reinterpret_cast<const int4*>(node_net + g0);
+                    vo[u] = *reinterpret_cast<const int4*>(owner + g0);
                 }
             }
 #pragma unroll
@@ -173,16 +226,16 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     if (tid <= X + 1) s_tab[tid] = my_xc;
     if (tid <= Y + 1) s_tab[XO + tid] = my_yc;
     for (int i = tid + nthr; i <= X + 1; i += nthr)
-        s_tab[i] = (uint32_t)(b.coords[R.xs_off + min(i - 1, X - 1)] - b.coords[R.xs_off]) << 5;
+        s_tab[i] = (uint32_t)(b.coords[R.xs_off + min(wx0 + i - 1, RX - 1)] - cbx) << 5;
     for (int i = tid + nthr; i <= Y + 1; i += nthr)
-        s_tab[XO + i] = (uint32_t)(b.coords[R.ys_off + min(i - 1, Y - 1)] - b.coords[R.ys_off]) << 5;
+        s_tab[XO + i] = (uint32_t)(b.coords[R.ys_off + min(wy0 + i - 1, RY - 1)] - cby) << 5;
     if (tid == 0) { s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1; }
     if (V2 && b.guide_cost) __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
         const int apf = i < nthr ? my_ap_f : b.ap_node[R.ap_off + ap_lo + i];
         const int iso = i < nthr ? my_ap_iso : (int)b.ap_flags[R.ap_off + ap_lo + i];
-        s_ap_f[i] = (unsigned short)apf;
+        s_ap_f[i] = (unsigned short)(WIN ? ((apf / RYZ - wx0) * Y + ((apf / Z) % RY - wy0)) * Z + apf % Z : apf);
         s_ap_pin[i] = (short)pin;
         s_ap_conn[i] = (unsigned char)((iso & 1) ? 2 : (pin == first_pin ? 1 : 0));
         s_ap_slot[i] = (unsigned char)((iso >> 1) & 3);
@@ -209,11 +262,11 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     uint32_t pen5 = (uint32_t)b.pen_cost << 5;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
     const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;  // bucket width (keys f = d + h, DBU)
     const uint32_t guide5 = V2 ? (uint32_t)b.guide_cost << 5 : 0u;
-    const uint32_t sh_yz = R.s24 & 31u, sh_z = (R.s24 >> 8) & 31u, sh_mw = (R.s24 >> 16) & 31u;
+    const uint32_t sh_yz = s24w & 31u, sh_z = (s24w >> 8) & 31u, sh_mw = (s24w >> 16) & 31u;       // (window form: its own magics)
     auto node_xyz = [&](uint32_t f, int& x, int& y, int& z) __attribute__((always_inline)) {
         uint32_t ux, ur, uy, uz;
-        xr3_divmod(f, uYZ, R.m24_yz, sh_yz, ux, ur);
-        xr3_divmod(ur, uZ, R.m24_z, sh_z, uy, uz);
+        xr3_divmod(f, uYZ, m24_yz, sh_yz, ux, ur);
+        xr3_divmod(ur, uZ, m24_z, sh_z, uy, uz);
         x = (int)ux; y = (int)uy; z = (int)uz;
     };
     if (V2 && b.guide_cost) {
@@ -264,7 +317,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     const uint32_t pdH = (planar ? (sgn > 0 ? 2u : 0u) : (sgn > 0 ? 5u : 4u)) << 2, pdV = (planar ? (sgn > 0 ? 1u : 3u) : (sgn > 0 ? 5u : 4u)) << 2;
 
     // node f <-> (word f % mw, bit f / mw) of the node bitmasks
-    auto mask_pos = [&](uint32_t f, uint32_t& q, uint32_t& r) __attribute__((always_inline)) { xr3_divmod(f, umw, R.m24_mw, sh_mw, q, r); };
+    auto mask_pos = [&](uint32_t f, uint32_t& q, uint32_t& r) __attribute__((always_inline)) { xr3_divmod(f, umw, m24_mw, sh_mw, q, r); };
     // a node becomes a source: distance 0, open
     // a node becomes a source: distance 0.  Bits 2..4 of a source word carry no predecessor; bit 2 = "the node has an owner" (it was
     // claimed by this route, or was held before it began): the terminal node of a trace is claimed iff it has none, and the answer must
@@ -286,6 +339,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     int sv_vio = 0, sv_wl = 0, sv_via = 0, sv_plen = 0, sv_status = XR_ENV_OK, sv_rem = 0;
     uint64_t sv_h = h0;
     bool resume = false;
+    bool win_fail = false;                                  // window form, tracing wave: a certificate failed
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     // component = all access points of the lowest pin id (a resumed attempt: of every pin connected so far; its path nodes are sources still)
     for (int i = tid; i < nap; i += nthr)
@@ -513,10 +567,48 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
             cur = nx1;
         }
 
+        if (WIN) {
+            // ---- exactness certificate of this search (see the function's header): the smallest key of an edge that leaves the window.
+            // Every boundary node the search reached, with its distance as it stands (a node with d + h <= best holds its exact one), the
+            // true length of the edge to the track outside (pad entries of the coordinate tables), no penalty for the node out there.
+            if (tid == 0) s_face = XR_DIAL_INF;
+            xr_lds_barrier();
+            uint32_t fm = XR_DIAL_INF;
+            const int XZ = X * Z;
+            for (int i = tid; i < 2 * YZ; i += nthr) {                  // x faces (columns 0 and X - 1): edges of horizontal layers
+                const int side = i >= YZ ? 1 : 0, r = side ? i - YZ : i;
+                if (!(side ? wx0 + X < RX : wx0 > 0)) continue;         // the region ends here too
+                uint32_t yw, z;
+                xr3_divmod((uint32_t)r, uZ, m24_z, sh_z, yw, z);
+                if ((ldir >> z) & 1u) continue;
+                const uint32_t w = field[(side ? (X - 1) * YZ : 0) + r];
+                if (w == 0u || (w >> 5) == XR3_DMAX) continue;
+                const uint32_t cin = s_tab[side ? X : 1], cout = s_tab[side ? X + 1 : 0];
+                const uint32_t key = (w >> 5) + ((side ? cout - cin : cin - cout) >> 5) + heur_c((int)cout, (int)s_tab[XO + yw + 1], (int)z);
+                fm = key < fm ? key : fm;
+            }
+            for (int i = tid; i < 2 * XZ; i += nthr) {                  // y faces (rows 0 and Y - 1): edges of vertical layers
+                const int side = i >= XZ ? 1 : 0, r = side ? i - XZ : i;
+                if (!(side ? wy0 + Y < RY : wy0 > 0)) continue;
+                uint32_t xw, z;
+                xr3_divmod((uint32_t)r, uZ, m24_z, sh_z, xw, z);
+                if (!((ldir >> z) & 1u)) continue;
+                const uint32_t w = field[((int)xw * Y + (side ? Y - 1 : 0)) * Z + (int)z];
+                if (w == 0u || (w >> 5) == XR3_DMAX) continue;
+                const uint32_t cin = s_tab[XO + (side ? Y : 1)], cout = s_tab[XO + (side ? Y + 1 : 0)];
+                const uint32_t key = (w >> 5) + ((side ? cout - cin : cin - cout) >> 5) + heur_c((int)s_tab[xw + 1], (int)cout, (int)z);
+                fm = key < fm ? key : fm;
+            }
+            fm = xr3_wave_min(fm);
+            if (lane == 0 && fm != XR_DIAL_INF) atomicMin(&s_face, fm);
+            xr_lds_barrier();
+        }
+
         // ===================== the tracing wave: target, back-trace, new sources (the others go on to the next barrier) ==========
         if (wv == sw) {
             int remaining = s_remaining;
-            if (aborted) {                        // round cap: the remaining pins are charged as unreachable, nothing is traced
+            if (WIN && aborted) { win_fail = true; remaining = 0; }          // (a round cap inside a window: let the HBM-scratch form decide)
+            else if (aborted) {                   // round cap: the remaining pins are charged as unreachable, nothing is traced
                 d_vio += remaining; status |= XR_ENV_ROUTER_ABORT | XR_ENV_UNREACHABLE; remaining = 0;
             } else {
                 // ---- nearest access point of an unconnected pin; ties -> lowest flat index --------------------------------
@@ -524,7 +616,8 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                 for (int i = lane; i < nap; i += 64)
                     if (!s_ap_conn[i]) { const uint32_t d = field[s_ap_f[i]] >> 5; md = d < md ? d : md; }
                 const uint32_t bd = xr3_wave_min(md);
-                if (bd == XR3_DMAX) {             // every remaining pin unreachable
+                if (WIN && s_face <= bd) { win_fail = true; remaining = 0; }   // certificate failed (bd = XR3_DMAX when nothing was reached: any finite face key fails it)
+                else if (bd == XR3_DMAX) {        // every remaining pin unreachable
                     d_vio += remaining; status |= XR_ENV_UNREACHABLE; remaining = 0;
                 } else {
                     uint32_t mf = 0xFFFFFFFFu;
@@ -554,13 +647,13 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         for (int i = lane; i < np; i += 64) {
                             const uint32_t f = s_tmp[i];
                             const uint32_t w0 = field[f];
-                            if (pl0 + i < b.path_cap) path[pl0 + i] = (int)f;
+                            if (pl0 + i < b.path_cap) path[pl0 + i] = gflat((int)f);
                             make_source(f, true);               // (whatever it was before: it has an owner from here on)
                             // claimed if nobody OWNS it.  Not held (bit 1 clear) = owner 0 or this net itself (a used access point of
                             // it): the store of `a` is right in both cases and needs no load.  Held = owned by another net OR another
                             // net's still unowned access point: only then the owner is read.  XR-Maze v2 defers all of this to the attempt
                             // that stands (the acceptance scan below finds these words: source + owner bit).
-                            if (!V2) { if (!(w0 & 2u)) owner[f] = (int16_t)a; else if (owner[f] == 0) owner[f] = (int16_t)a; }
+                            if (!DEFER) { if (!(w0 & 2u)) owner[f] = (int16_t)a; else if (owner[f] == 0) owner[f] = (int16_t)a; }
                         }
                         XR3_WSYNC();
                         np = 0;
@@ -577,7 +670,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         if (pd >= 4u) d_via += 1; else d_wl += (int)(step5 >> 5);
                         if (lane == 0) s_tmp[np] = (unsigned short)v;
                         plen++; np++;
-                        fnv_mix(h, (uint32_t)v);
+                        fnv_mix(h, (uint32_t)gflat(v));
                         v = u; vw = uw;
                         if (np == XR3_TMP) { flush(); dirty = true; }
                     }
@@ -588,9 +681,9 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                         // terminal node of the component: claimed (and recorded) only if nobody holds it yet
                         // (a source: not held and no owner bit <=> owner[v] == 0, see make_source; XR-Maze v2: the owner it will have)
                         if ((vw & 6u) == 0u) {
-                            if (lane == 0) { if (!V2) owner[v] = (int16_t)a; if (plen < b.path_cap) path[plen] = v; field[v] = vw | 4u; }
+                            if (lane == 0) { if (!DEFER) owner[v] = (int16_t)a; if (plen < b.path_cap) path[plen] = gflat(v); field[v] = vw | 4u; }
                             plen++;
-                            fnv_mix(h, (uint32_t)v);
+                            fnv_mix(h, (uint32_t)gflat(v));
                         }
                         remaining -= 1;
                         // the reached pin joins the component with all of its access points
@@ -599,6 +692,7 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
                     }
                 }
             }
+            if (WIN && win_fail && lane == 0) s_fallback = 1;
             if (lane == 0) s_remaining = remaining;
         }
         xr_lds_barrier();      // every thread has left the round loop (its exit test reads s_min / s_bst) before the next search resets them
@@ -607,8 +701,8 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     // ---- does the attempt stand (XR-Maze v2)?  Its path uses a node held by another net and attempts are left: rip it up ----
     if (wv == sw) {
         const bool retry = V2 && b.maze_end_iter > 1 && d_held > 0 && attempt + 1 < b.maze_end_iter;
-        if (V2 && lane == 0 && !retry) s_retry = 0;             // (a doomed trace wrote 1 or 2: a held node is only ever met by one)
-        if (!retry && lane == 0) {
+        if (DEFER && lane == 0 && !retry) s_retry = 0;          // (a doomed trace wrote 1 or 2: a held node is only ever met by one)
+        if (!retry && lane == 0 && !(WIN && win_fail)) {
             if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
 #ifdef XR_PHASE_TIMING
             xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h, attempt + 1);       // (probe builds: XR_FETCH_TOUCHED = attempts)
@@ -618,8 +712,9 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         }
     }
     XR_LAP(5);
-    if (!V2) break;
+    if (!DEFER) break;
     xr_lds_barrier();                                         // s_retry and the last sources are visible
+    if (WIN && s_fallback) return false;                      // uniform: a certificate failed — nothing that counts was written
     const int retry_kind = s_retry;
     const bool retry = retry_kind != 0;
     if (!retry) {
@@ -628,7 +723,10 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
         // net's wire (stays) or another net's unowned access point on the path (claimed, as XR-Maze v1 does): the owner is read.
         const int nq = (N + 3) >> 2;
         auto accept = [&](uint32_t w, int f) __attribute__((always_inline)) {
-            if ((w >> 5) == 0u && (w & 4u)) { if (!(w & 2u)) owner[f] = (int16_t)a; else if (owner[f] == 0) owner[f] = (int16_t)a; }
+            if ((w >> 5) == 0u && (w & 4u)) {
+                const int g = gflat(f);
+                if (!(w & 2u)) owner[g] = (int16_t)a; else if (owner[g] == 0) owner[g] = (int16_t)a;
+            }
         };
         for (int c = tid; c < nq; c += nthr) {
             const uint4 w = *reinterpret_cast<const uint4*>(field + (c << 2));
@@ -676,4 +774,5 @@ __device__ __forceinline__ void xr_dial3_route_env(const XrBatchDev& b, const in
     XR_LAP(7);
     }
     XR_TDUMP();
+    return true;
 }

@@ -846,7 +846,12 @@ __device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int
         else xr_dial_route_env_big<true>(b, e, a, smem);
     } else if constexpr (ZCH == XR_ZCH_DIAL) {
         if constexpr (LDS_DIST) xr_dial_route_env<false>(b, e, a, smem);
-        else xr_dial_route_env_big<false>(b, e, a, smem);
+        else {
+            // regions too large for LDS (round 4): first the LDS router inside a window around the net, with an exactness certificate
+            // (xr_dial3.h, WIN); the HBM-scratch form only for nets that do not fit the window or whose certificate fails
+            if (b.win_x > 0 && xr_dial3_route_env<false, true>(b, e, a, smem)) return;
+            xr_dial_route_env_big<false>(b, e, a, smem);
+        }
     } else {
         xr_route_env<LDS_DIST, ZCH>(b, e, a, smem);
     }
