@@ -143,11 +143,12 @@ typedef struct xr_config {
                                  struct's former tail padding: sizeof(xr_config) is unchanged.) */
     int32_t debug_round_cap;  /* 0 = default.  > 0: relaxation rounds one search of the router may take before it aborts with
                                  XR_ENV_ROUTER_ABORT (tests force the abort path with 1) */
-    int32_t window;           /* regions whose distance field does not fit LDS (BASELINE config 5): the router first runs inside an LDS window of
-                                 the region centred on the net and accepts the result only with an exactness certificate (no shortest path to
-                                 anything the step looks at leaves the window), else the HBM-scratch form routes the net.  0 = default: the
-                                 largest square window that fits LDS (52 tracks at 12 layers); > 0: that many tracks (tests force fallbacks
-                                 with small ones); < 0: off.  Results never depend on it.  (ABI 6; was reserved0 = 0.) */
+    int32_t window;           /* regions whose distance field does not fit LDS (BASELINE config 5), > 0: the router first runs inside an LDS window
+                                 of the region centred on the net (the largest square window of at most this many tracks that fits LDS: 52 at 12
+                                 layers) and accepts the result only with an exactness certificate — no shortest path to anything the step looks
+                                 at leaves the window — else the HBM-scratch form routes the net.  0 (default) / < 0: off — built and bit-exact,
+                                 but measured no faster than the HBM-scratch form alone on config 5.  Results never depend on
+                                 it.  (ABI 6; was reserved0 = 0.) */
 } xr_config;
 
 /* One region = one simulator Request (net_ordering.proto:29-45) in dense form; host pointers. */

@@ -487,7 +487,7 @@ def test_round_cap_aborts_the_net_not_the_device(kw):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(router=3), dict(router=1), dict(force_scratch_field=True, window=-1),
-                                dict(maze_end_iter=2), dict(maze_end_iter=2, force_scratch_field=True), dict(force_scratch_field=True, window=0),
+                                dict(maze_end_iter=2), dict(maze_end_iter=2, force_scratch_field=True), dict(force_scratch_field=True, window=1000),
                                 dict(force_scratch_field=True, window=160)],
                          ids=["lds", "lds-round2", "sweeps", "scratch", "lds-v2", "scratch-v2", "window", "window-160"])
 def test_distance_cap_rule_in_every_router_form(kw):
@@ -504,13 +504,13 @@ def test_distance_cap_rule_in_every_router_form(kw):
     assert n == len(regions)
 
 
-@pytest.mark.parametrize("window,forms", [(0, {False}), (16, {False, True}), (4, {True}), (-1, {True})])
+@pytest.mark.parametrize("window,forms", [(1000, {False}), (16, {False, True}), (4, {True}), (0, {True})])
 def test_window_form_of_the_lds_router_matches_the_oracle(window, forms):
     """Round 4 (BASELINE config 5's path): regions whose field is kept out of LDS are routed by the LDS router inside a WINDOW of the
     region around the net, accepted only with the exactness certificate (no shortest path to anything the step looks at leaves the
     window), else by the HBM-scratch form.  Whole episodes on ispd18_test1-sized regions forced onto that path (`force_scratch_field`)
-    equal the oracle whatever the window: the default (24 tracks: the region's width), 16 tracks (some nets fit, some do not, some
-    certificates fail: both forms must have run), 4 tracks (below the smallest window: the form is off), off."""
+    equal the oracle whatever the window: the largest that fits (24 tracks: the region's width), 16 tracks (some nets fit, some do not,
+    some certificates fail: both forms must have run), 4 tracks (below the smallest window: the form is off), 0 (the default: off)."""
     regions = [generate_region(3900 + i) for i in range(16)]
     n = _run_episode_parity(regions, policy="random", force_scratch_field=True, window=window, expect_forms=forms)
     assert n > 150

@@ -67,7 +67,7 @@ class RegionBatch:
         cfg.obs_helper_blocks = int(obs_helper_blocks)   # queue form: LDS-free helper writers beside the step kernel (0 = none = the default; < 0 is rejected)
         cfg.debug_round_cap = int(debug_round_cap)       # 0 default (1024 + N rounds per search); tests force XR_ENV_ROUTER_ABORT with 1
         cfg.guide_cost, cfg.guide_margin, cfg.maze_end_iter = int(guide_cost), int(guide_margin), int(maze_end_iter)   # XR-Maze v2
-        cfg.window = int(window)                         # regions too large for LDS: LDS-window router first (0 auto, > 0 tracks, < 0 off)
+        cfg.window = int(window)                         # regions too large for LDS: > 0 = LDS-window router first (at most that many tracks); 0 = off (measured no faster)
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg
         self._h = C.c_void_p()

@@ -574,13 +574,14 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                 if (hipGetDeviceProperties(&prop, b->cfg.device) == hipSuccess && B <= 4 * prop.multiProcessorCount) big_threads = 1024;
             }
             b->route_threads = b->cfg.block_threads ? b->cfg.block_threads : big_threads;
-            // the LDS router inside a window of the region first (xr_dial3.h, WIN; xr_config.window: 0 = the largest square window that
-            // fits LDS, > 0 = that many tracks, < 0 = off): every region must have the same layer count and hold the window, rows of the
-            // state arrays must start on 16-byte boundaries wherever a window row may start, the arithmetic limits are those of the form
+            // the LDS router inside a window of the region first (xr_dial3.h, WIN; xr_config.window: > 0 = that many tracks at most — the
+            // largest square window <= it that fits LDS; 0 (default) and < 0 = off: measured no faster on BASELINE config 5):
+            // every region must have the same layer count and hold the window, rows of the state arrays must start on 16-byte boundaries
+            // wherever a window row may start, the arithmetic limits are those of the form
             b->win = {};
             const bool v2cfg = b->cfg.guide_cost > 0 || b->cfg.maze_end_iter > 1;
             const int64_t pen_w = (int64_t)b->cfg.drc_cost * b->cfg.drc_unit;
-            if (b->cfg.window >= 0 && !v2cfg && z_min == z_max && edge_max + pen_w < XR3_STEP_LIMIT) {
+            if (b->cfg.window > 0 && !v2cfg && z_min == z_max && edge_max + pen_w < XR3_STEP_LIMIT) {
                 const int Zw = z_max;
                 int ystep = 1;
                 while ((ystep * Zw) % 8) ystep *= 2;                 // rows start at y0 * Z elements: a multiple of 8 of them (16 bytes of int16)
@@ -590,24 +591,22 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
                     rows_ok = rows_ok && ((int64_t)regs[r].dim_y * Zw) % 8 == 0;
                     xmin = std::min(xmin, (int)regs[r].dim_x); ymin = std::min(ymin, (int)regs[r].dim_y);
                 }
-                int w = b->cfg.window > 0 ? b->cfg.window : 64;
-                w = std::min(w, std::min(xmin, ymin));
+                int w = std::min(b->cfg.window, std::min(xmin, ymin));
                 for (; w >= 8 && rows_ok; w--) {
                     if ((w * Zw) % 8) continue;                          // a chunk of 8 nodes never straddles two window rows
                     const int64_t nw = (int64_t)w * w * Zw;
                     const size_t wl = XR3_LDS_BYTES((nw + 7) & ~7, w, w);
-                    // (a batch of more than ~4 routes per CU runs two 512-thread workgroups per CU: the window then gets half the LDS)
-                    const size_t lds_cap = (big_threads == 1024 || b->cfg.window > 0) ? kLdsLimit : kLdsLimit / 2;
-                    if (nw >= 65536 || std::max(wl, big_lds) + 2 * kLdsStatic > lds_cap || (int64_t)w * edge_max >= XR3_EXTENT_LIMIT) continue;
+                    if (nw >= 65536 || std::max(wl, big_lds) + 2 * kLdsStatic > kLdsLimit || (int64_t)w * edge_max >= XR3_EXTENT_LIMIT) continue;
                     uint32_t myz, syz, mz, sz, mmw, smw;
                     const uint32_t mwv = (uint32_t)((nw + 31) / 32);
                     if (!magic24((uint32_t)(w * Zw), (uint32_t)nw, myz, syz) || !magic24((uint32_t)Zw, (uint32_t)std::max(w, 1) * Zw * 2, mz, sz) ||
                         !magic24(mwv, (uint32_t)nw, mmw, smw)) continue;
                     b->win.x = w; b->win.y = w; b->win.nmax = (int)((nw + 7) & ~7); b->win.ystep = ystep;
-                    // tracks kept free around the net's box (the row alignment is checked per net).  A forced window (tests) keeps a small
-                    // margin; the automatic one a quarter of the window: a net whose box nearly fills the window floods past its faces, fails
-                    // its certificate and has paid for the attempt on top of the fallback (profiles/r04_k_config5_window.txt)
-                    b->win.margin = b->cfg.window > 0 ? std::max(1, std::min(4, w / 8)) : std::max(1, w / 4);
+                    // tracks kept free around the net's box (the row alignment is checked per net).  A net whose box nearly fills the window
+                    // floods past its faces, fails its certificate and has paid for the attempt on top of the fallback: margins of 4 / 8 /
+                    // 13 / 18 tracks of a 52-track window send 27 / 33 / 48 / 68 % of BASELINE config 5's routes to the fallback
+                    // (profiles/r04_l_config5_window_form.txt)
+                    b->win.margin = std::max(1, std::min(4, w / 8));
                     if (const char* em = getenv("XR_WINDOW_MARGIN")) b->win.margin = std::max(1, atoi(em));      // (A/B runs)
                     b->win.m24_yz = myz; b->win.m24_z = mz; b->win.m24_mw = mmw; b->win.s24 = syz | (sz << 8) | (smw << 16);
                     b->route_lds = std::max(b->route_lds, wl);
