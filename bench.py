@@ -1082,15 +1082,15 @@ def config5_leg(args, c5_regions, dev):
     ent["bytes_8d_full_sweep_formula"] = formula_8d
     # the roofline that bounds this kernel: L2 atomics.  Ceilings from tools/micro/atomic_rate.hip on this pool; the per-launch
     # atomic count from the TCC counters of a rocprofv3 --pmc pass — quoted only for the same build and batch size
-    ent["l2_atomic_roofline"] = {"bound": "l2-atomic", "peak": 27.0, "peak_hbm_resident": 18.0, "unit": "G atomics/s", "achieved": None, "frac": None,
+    ent["l2_atomic_roofline"] = {"bound": "l2-atomic", "peak": 18.0, "peak_l2_resident": 27.0, "unit": "G atomics/s", "achieved": None, "frac": None,
                                  "dependent_atomic_latency_ns": [309, 436],
-                                 "note": "peak: sustained agent-scope returning atomics on random words, footprint <= 256 MiB (4 GiB: 18 G/s); a route is a "
+                                 "note": "peak: sustained agent-scope returning atomics on random words over a 4 GiB footprint (this leg's scratch is 13 GB; <= 256 MiB: 27 G/s); a route is a "
                                          "chain of DEPENDENT atomics (309-436 ns each), so the launch is as long as its longest chain, not atomics / peak"}
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "config5_atomics.json")))
         if pj.get("source_sha") == source_sha() and pj.get("envs") == Bc and pj.get("tcc_atomic_per_launch"):
             ach = pj["tcc_atomic_per_launch"] / (ms * 1e-3) / 1e9
-            ent["l2_atomic_roofline"].update(achieved=round(ach, 3), frac=round(ach / 27.0, 4), atomics_per_launch=pj["tcc_atomic_per_launch"],
+            ent["l2_atomic_roofline"].update(achieved=round(ach, 3), frac=round(ach / 18.0, 4), atomics_per_launch=pj["tcc_atomic_per_launch"],
                                              l2_requests_per_launch=pj.get("tcc_req_per_launch"))
     except Exception:
         pass
@@ -1101,6 +1101,35 @@ def config5_leg(args, c5_regions, dev):
     gpu_hash = b5.fetch("hash").cpu().numpy().view("uint64")
     gpu_cum = b5.fetch("cum").cpu().numpy()
     b5.close()
+    try:        # the same launches with the LDS-window form in front (xr_config.window: off by default — this is the measurement behind that)
+        bw = RegionBatch(c5_regions, n_envs=Bc, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
+                         launch_order=args.launch_order, window=1000)
+        bw.reset()
+        for sd in c5_seeds[:2]:
+            bw.random_actions(sd, a5)
+            bw.step(a5)
+        evw = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
+        fb = routed = 0.0
+        for i, (e0, e1) in enumerate(evw):
+            bw.random_actions(c5_seeds[2 + i], a5)
+            e0.record()
+            bw.step(a5)
+            e1.record()
+            st = bw.fetch("status")
+            real_m = (a5 > 0) & ((st & 9) == 0)
+            routed += float(real_m.sum().item())
+            fb += float(((bw.fetch("touched") > 0) & real_m).sum().item())
+        torch.cuda.synchronize(dev)
+        same = bool((bw.fetch("hash").cpu().numpy().view("uint64") == gpu_hash).all())
+        ent["window_form"] = {"ms": round(sum(a.elapsed_time(bb) for a, bb in evw) / n_t, 4), "window_tracks": 52,
+                              "window_bytes_per_attempt": int(4 * 52 * 52 * 12), "fallback_share": round(fb / max(routed, 1.0), 4),
+                              "same_hash_chains_as_the_default": same,
+                              "note": "xr_config.window = 1000: the LDS router inside a 52 x 52 x 12 window around the net, accepted with an exactness "
+                                      "certificate over the window faces, HBM-scratch form otherwise; same results, not faster (the launch is as long "
+                                      "as its heaviest routes, which do not fit a window): off by default"}
+        bw.close()
+    except Exception as ex:
+        ent["window_form"] = {"error": str(ex)}
     try:        # oracle replay of the leg's own actions on its first slots (a Dijkstra over 786 k nodes per search: 16 slots x 7 steps)
         n_chk = min(16, len(c5_regions), Bc)
         ent["parity"] = parity_check([c5_regions[e % len(c5_regions)] for e in range(n_chk)], c5_seeds, None, gpu_hash, gpu_cum, n_check=n_chk)
