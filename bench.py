@@ -757,7 +757,8 @@ def extras_leg(args, regions, dev, batch, obs):
         del obs
         batch.close()
         torch.cuda.empty_cache()
-        g = Game(regions=regions[:8], device=dev)
+        from xroute_env_amd.regions import config_regions
+        g = Game(regions=config_regions(1, 8), device=dev)       # BASELINE config 1: 24x40x9, K = 10 — not the headline's K ~ U[4,36] regions
         g.reset()
         ts = []
         for ep in range(5):
@@ -771,7 +772,7 @@ def extras_leg(args, regions, dev, batch, obs):
         ts.sort()
         ex["config1_game_step"] = {"ms_median": round(ts[len(ts) // 2] * 1e3, 4), "ms_p10": round(ts[len(ts) // 10] * 1e3, 4),
                                    "ms_p90": round(ts[9 * len(ts) // 10] * 1e3, 4), "steps": len(ts),
-                                   "what": "BASELINE config 1: Game.step on one ispd18_test1-sized region through the reference-shaped API, "
+                                   "what": "BASELINE config 1: Game.step on one ispd18_test1-sized region (24x40x9, K = 10: the config's generator) through the reference-shaped API, "
                                            "in-process simulator, observation returned as a CPU tensor like the reference's (PCIe-inclusive)"}
         del g
     except Exception as exn:

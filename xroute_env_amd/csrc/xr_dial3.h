@@ -91,6 +91,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ unsigned char s_ap_own[XR_MAX_AP_PER_NET];       // the access point's node had an owner when the route began (a used access point of this net)
     __shared__ unsigned char s_ap_slot[XR_MAX_AP_PER_NET];      // which heuristic box the access point's pin is dealt to (static, from the load)
     __shared__ uint32_t s_min[3], s_bst[3];                     // rotating per round: smallest open key, smallest target distance
+    __shared__ int s_cnt[3];                                    // ... and the nodes the round took from the mask (XR3_ADAPT: sparse rounds widen the bucket)
     __shared__ int s_hb[3][6];                                  // heuristic: three boxes over the unconnected pins (x, y: coordinates x32; z), see the search start
     __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
     __shared__ unsigned short s_qn[XR_QUAD_POOL];
@@ -354,6 +355,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         if (tid == 0) {
             s_min[0] = 0; s_min[1] = XR_DIAL_INF; s_min[2] = XR_DIAL_INF;
             s_bst[0] = XR_DIAL_INF; s_bst[1] = XR_DIAL_INF; s_bst[2] = XR_DIAL_INF;
+            s_cnt[0] = 1 << 20; s_cnt[1] = 0; s_cnt[2] = 0;
         }
         if (tid < 18) { const int k = tid % 6; s_hb[tid / 6][k] = (k & 1) ? -0x3FFFFFFF : 0x3FFFFFFF; }      // (empty: min > max)
         for (int i = tid; i < mw; i += nthr) {
@@ -401,6 +403,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         };
         XR_LAP(4);
         int cur = 0;
+        int bscale = 1;                       // (XR3_ADAPT_LO builds: bucket width of the round, in units of delta)
         bool aborted = false;                 // (round cap: xr_dial.h)
         for (int nsr = 0;; nsr++) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
@@ -410,11 +413,15 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
 #ifdef XR3_GROW_AFTER        // A/B only (profiles/r03_q_ab_growing_bucket_width.txt: wider late buckets cost 3-18 % --
                              // the extra re-expansions outweigh the rounds saved); off in the shipped build
             const uint32_t hi = m + (nsr >= XR3_GROW_AFTER ? delta * XR3_GROW_BY : delta);
+#elif defined(XR3_ADAPT_LO)  // A/B (round 4): a round that took fewer than XR3_ADAPT_LO nodes from the mask doubles the next bucket (up to
+                             // XR3_ADAPT_MAX x), one that took more than XR3_ADAPT_HI goes back to one width.  Bucket widths never change results.
+            { const int pc = s_cnt[cur]; if (pc < XR3_ADAPT_LO) bscale = min(bscale << 1, XR3_ADAPT_MAX); else if (pc > XR3_ADAPT_HI) bscale = 1; }
+            const uint32_t hi = m + delta * (uint32_t)bscale;
 #else
             const uint32_t hi = m + delta;
 #endif
             uint32_t lmin = XR_DIAL_INF;
-            if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; }
+            if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; s_cnt[nx2] = 0; }
             // bound for the next round: smallest tentative distance of an unconnected target
             // (by the threads at the END of the workgroup: the first wave carries the words beyond one per thread)
             for (int i = nthr - 1 - tid; i < nap; i += nthr)
@@ -494,6 +501,9 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
                     }
                     __builtin_amdgcn_wave_barrier();
                     const int nq = min(__builtin_amdgcn_readfirstlane(*qcnt), qcap);
+#ifdef XR3_ADAPT_LO
+                    if (lane == 0 && nq) atomicAdd(&s_cnt[nx1], nq);
+#endif
                     // ---- quads: lanes 4g .. 4g+3 follow ONE chain, lane 4g+d relaxes direction d of the chain's current node
                     int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
                     for (int nhop = 0;; nhop++) {
