@@ -706,7 +706,8 @@ def main():
                                    + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
                        "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}",
                        "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (nst * B * world), 4),
-                       "router": {0: "default", 1: "sweep", 2: "dial"}[args.router], "source_sha": source_sha()},
+                       "router": {0: "default", 1: "sweep", 2: "dial"}[args.router], "source_sha": source_sha(),
+                       "bench_args": bench_args_key(args, world)},
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
@@ -743,7 +744,8 @@ def main():
 def bench_args_key(args, world):
     return {"gpus": world, "steps": args.steps, "warmup": args.warmup, "envs": args.envs, "global_envs": args.global_envs,
             "config": args.config, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
-            "no_stagger": bool(args.no_stagger)}
+            "no_stagger": bool(args.no_stagger), "region_pack": os.path.basename(args.region_pack) if args.region_pack else None,
+            "maze_v2": bool(args.maze_v2)}
 
 
 def extras_leg(args, regions, dev, batch, obs):

@@ -162,3 +162,16 @@ def test_bench_value_is_stationary_in_warmup():
     b = _run(["--no-legs", "--no-cpu-baseline", "--envs", "1024", "--steps", "10", "--warmup", "25"])
     ka, kb = a["config"]["mean_nets_left"], b["config"]["mean_nets_left"]
     assert abs(ka - kb) / kb < 0.04, (ka, kb)
+
+
+def test_bench_region_pack_with_the_reference_configuration():
+    """`bench.py --region-pack <the design-derived pack> --maze-v2`: the main batch itself routes with the reference's simulator
+    configuration (XR-Maze v2: maze_end_iter 3, guide cost over the design's guide rectangles) — the command `tools/final_round4.sh`
+    profiles under rocprofv3.  One JSON line, the queue form, the workload text says what ran."""
+    pack = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--envs", "512",
+                          "--no-cpu-baseline", "--no-legs", "--region-pack", pack, "--maze-v2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert "XR-Maze v2" in d["config"]["workload"] and "region pack" in d["config"]["workload"] and d["value"] > 0
+    assert d["kernels"][0]["kernel"] == "xr_step_queue_kernel" and d["roofline"]["frac"] > 0

@@ -34,8 +34,8 @@ cal = {"fill_1GiB_WRITE_SIZE_KiB": fill_w, "add_1GiB_FETCH_SIZE_KiB": add_r, "ad
 wfac = (GiB / (fill_w * 1024.0)) if fill_w > 1e5 else 1.0
 rfac = (GiB / (add_r * 1024.0)) if add_r > 1e5 else 2.0
 # identity of the measurement: bench.py quotes this file only for the same kernel sources and the same command
-bench_args = {"gpus": 1, "steps": bench["steps"], "warmup": bench["warmup"], "envs": bench["config"]["envs_per_gpu"], "global_envs": 0,
-              "config": 3, "seed": 2024, "router": 0, "obs_mode": 0, "no_stagger": False}
+bench_args = bench["config"].get("bench_args") or {"gpus": 1, "steps": bench["steps"], "warmup": bench["warmup"], "envs": bench["config"]["envs_per_gpu"], "global_envs": 0,
+                                                  "config": 3, "seed": 2024, "router": 0, "obs_mode": 0, "no_stagger": False}
 out = {"source_sha": bench["config"].get("source_sha"), "bench_args": bench_args,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --pmc-calibrate`",
        "units": "HBM bytes per launch, mean over the timed launches (KiB counters x 1024 x calibration factor)",
