@@ -798,25 +798,28 @@ def agent_leg(args, regions, dev, world):
     import torch
     from xroute_env_amd import agents
     from xroute_env_amd.batch import RegionBatch
-    B = len(regions)
+    mixed = len({tuple(int(v) for v in r.dims) for r in regions}) > 1          # a region pack: several grid shapes in one batch
+    B = args.envs if mixed else len(regions)
     torch.manual_seed(0)
     if os.environ.get("XR_CUDNN_BENCHMARK"):        # experiments: let MIOpen search its convolution algorithms (fixed conv batch shapes)
         torch.backends.cudnn.benchmark = True
     model = (agents.RepActor() if args.agent == "dqn" else agents.ActorCritic(64)).to(dev).eval()
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
-                        launch_order=args.launch_order)
+                        launch_order=args.launch_order, **(dict(max_route_count=1 << 30) if mixed else {}),
+                        **(dict(V2_KNOBS, guide_margin=1) if (mixed and args.maze_v2) else {}))
     batch.reset(rotate=True)
     dims = regions[0].dims
-    full = args.agent_full_obs
+    full = args.agent_full_obs and not mixed
     buf = batch.alloc_observation() if full else batch.alloc_head()
     if full:
         batch.observation(buf)
     else:
         _head_of(batch, buf)
-    cache = agents.NetVectorCache(len(regions), batch.k_max, dev)
+    grouped = agents.GroupedFusedPolicy(model, batch, dev) if mixed else None      # (per grid shape: its own fused tower; one actor head, one cache)
+    cache = grouped.cache if mixed else agents.NetVectorCache(len(regions), batch.k_max, dev)
     # the obstacle tower as one fused HIP kernel (csrc/xr_agent.hip); --agent-lib-tower keeps the framework's convolutions (A/B)
-    tower = None if args.agent_lib_tower else agents.FusedObstacleTower(model.representation_network, (dims[2], dims[1], dims[0]), dev)
-    head_k = None if (args.agent_lib_tower or full) else agents.FusedActorHead(model.actor, dev)     # (+ the actor MLP and the arg-max as one kernel)
+    tower = None if (args.agent_lib_tower or mixed) else agents.FusedObstacleTower(model.representation_network, (dims[2], dims[1], dims[0]), dev)
+    head_k = None if (args.agent_lib_tower or full or mixed) else agents.FusedActorHead(model.actor, dev)     # (+ the actor MLP and the arg-max as one kernel)
     if head_k is not None:      # every (region, net) through the net tower once, up front: no cache-miss check (= no host round trip) per step
         cache.prefill(model.representation_network, [r.n_nets for r in regions], batch.net_planes, dims)
     nl = torch.empty(B, dtype=torch.int32, device=dev)
@@ -825,6 +828,8 @@ def agent_leg(args, regions, dev, world):
     def act():
         batch.fetch("nlegal", nl)
         batch.fetch("region", reg)
+        if mixed:
+            return grouped.actions(buf, nl, reg, sample=(args.agent == "ppo"))
         kw = dict(cache=cache, region=reg, ob_tower=tower, actor_head=head_k)
         if not full:
             kw["planes_fn"] = batch.net_planes
@@ -856,20 +861,24 @@ def agent_leg(args, regions, dev, world):
     real = batch.total_steps() - s0
     agent_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / n
     env_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / n
-    N = float(regions[0].n_nodes)
+    N = float(sum(regions[e % len(regions)].n_nodes for e in range(B))) / B
     kfloat = float(batch.fetch("nlegal").double().mean().item())
     env_bytes = B * (4.0 * N + (4.0 * N * (2 + 7 * kfloat) if full else 8.0 * N))
     return {"metric": f"env-steps/sec, {args.agent.upper()} counterpart attached (batched regions), ispd18_test1-sized regions",
             "value": round(real / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3/4 shape: {B} ispd18_test1-sized regions, full maze route per step, "
+            "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack ({len(grouped.shapes)} grid shapes, fused tower for "
+                                    f"{sum(t is not None for t in grouped.towers)} of them; XR-Maze {'v2 (the reference configuration)' if args.maze_v2 else 'v1'}), full maze route per step, "
+                                    if mixed else f"BASELINE config 3/4 shape: {B} ispd18_test1-sized regions, full maze route per step, ")
+                                   +
                                    f"{args.agent.upper()} counterpart (random-init weights of the reference architecture, eval mode) choosing every action; "
                                    + ("full fp32 observation (xr_batch_step_observe)" if full else
                                       "compact-consumer mode (xr_batch_step_compact: planes 0..1 per step; net planes once per (region, net) via xr_batch_net_planes + NetVectorCache)"),
                        "envs_per_gpu": B, "global_envs": B, "parallelism": "env-shard x1", "mean_nets_left": round(kfloat, 2)},
             "env_share_of_step_time": round(env_ms / max(env_ms + agent_ms, 1e-9), 4),
-            "obstacle_tower": "framework convolutions" if tower is None or not tower.supported else "fused HIP kernel (xr_agent_obstacle_tower)",
+            "obstacle_tower": ("fused HIP kernel per grid shape (agents.GroupedFusedPolicy)" if mixed else
+                               "framework convolutions" if tower is None or not tower.supported else "fused HIP kernel (xr_agent_obstacle_tower)"),
             "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(env_ms, 4),
             "net_grids_through_the_tower": cache.computed,
             "roofline": {"kernel": "xr_route_kernel (+ planes 0..1)" if not full else "xr_step_queue_kernel", "bound": "hbm",
