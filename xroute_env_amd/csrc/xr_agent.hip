@@ -372,11 +372,13 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
     static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
     const int64_t Np = (int64_t)(D + 2) * (H + 2) * (W + 2);
+    int64_t c1_alloc = nC1;                                   // floats behind b: the first activation of the 7-channel block, or more (below)
     if (2 * Np + N <= nC1) g.pad_in_b = 0;
     else if (Np <= nB && Np + N <= nC1) g.pad_in_b = 1;
-    else return XR_ERR_RANGE;
+    else { g.pad_in_b = 0; c1_alloc = 2 * Np + N; }           // a narrow grid (e.g. 7 x 34 x 9): the 1-channel block's padded copies need more than the
+                                                              // 7-channel stages — the allocation simply grows (it is small anyway)
     if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
-    const size_t lds = (size_t)(nB + nC1) * sizeof(float);
+    const size_t lds = (size_t)(nB + c1_alloc) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
     const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
                    : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512>);

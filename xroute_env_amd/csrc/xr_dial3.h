@@ -403,7 +403,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         };
         XR_LAP(4);
         int cur = 0;
-        int bscale = 1;                       // (XR3_ADAPT_LO builds: bucket width of the round, in units of delta)
+        [[maybe_unused]] int bscale = 1;      // (XR3_ADAPT_LO builds: bucket width of the round, in units of delta)
         bool aborted = false;                 // (round cap: xr_dial.h)
         for (int nsr = 0;; nsr++) {
             const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
