@@ -112,9 +112,9 @@ typedef struct xr_config {
     int32_t router;           /* XR-Maze v1 relaxation scheme (same results, bit for bit): 0 = auto (XR_ROUTER_DIAL wherever it applies;
                                  only the full-rewrite queue launch of a batch of >= 4096 slots takes XR_ROUTER_SWEEP, measured
                                  1-2 % faster there), XR_ROUTER_SWEEP = line-segment sweeps over dirty-line
-                                 worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm; regions that fit
-                                 LDS take round 3's form — one searching wave, explicit bucket queues, predecessor directions in the
-                                 field word — unless distances could exceed its 27 bits), XR_ROUTER_DIAL_R2 = round 2's LDS form of it */
+                                 worklists (round 1), XR_ROUTER_DIAL = bucketed frontier expansion (Dial's algorithm with A* keys; regions that fit
+                                 LDS take round 3's form — mask rounds, quads of lanes per chain, predecessor directions in the field word — whenever one
+                                 edge with its penalties stays below 2^20; larger regions the HBM-scratch form), XR_ROUTER_DIAL_R2 = round 2's LDS form of it */
     int32_t dial_mult;        /* XR_ROUTER_DIAL: bucket width in units of the region's smallest edge length (0 = default 8) */
     int32_t guide_cost;       /* XR-Maze v2 (all three neutral by default = XR-Maze v1): entering a node outside the net's guide costs this
                                  much extra, DBU-equivalent (the role of `-follow_guide 1`, run-net-ordering-training.tcl:3); the guide of

@@ -77,4 +77,5 @@ timeout 300 python tools/config5_probe.py 1024 64 2>&1 | grep -v amdgpu > $OUT/c
 (timeout 400 python tools/soak.py 4096 300 3 obs 2>&1 | tail -1; timeout 400 python tools/soak.py 4096 300 3 inplace 2>&1 | tail -1; timeout 400 python tools/soak.py 4096 300 3 2>&1 | tail -1; timeout 500 python tools/soak.py 1024 24 5 2>&1 | tail -1
  timeout 600 python tools/soak.py 4096 120 3 obs pack-v2 2>&1 | tail -1; timeout 600 python tools/soak.py 4096 120 3 route pack-v2 2>&1 | tail -1; timeout 600 python tools/soak.py 4096 120 3 obs pack 2>&1 | tail -1) > $OUT/parity_soak.txt
 cat $OUT/parity_soak.txt
+(timeout 900 python tools/fuzz_router.py 3000 11 2>&1 | grep -v amdgpu | tail -2; XR_LIB=libxroute_hip_tinylists.so timeout 600 python tools/fuzz_router.py 1000 12 2>&1 | grep -v amdgpu | tail -2) > $OUT/fuzz_router.txt; cat $OUT/fuzz_router.txt
 find $OUT -name "*.db" -size +4M -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete; find $OUT -name "*kernel_trace.csv" -size +4M -delete

@@ -831,7 +831,7 @@ __device__ __forceinline__ void xr_route_env(const XrBatchDev& b, const int e, c
 // else the line-segment sweeps above (xr_config.router = XR_ROUTER_SWEEP)
 #define XR_ZCH_DIAL (-1)
 #define XR_ZCH_DIAL2 (-2)      // the frontier router (either form) with the XR-Maze v2 knobs compiled in
-#define XR_ZCH_DIAL3 (-3)      // round 3's LDS form (xr_dial3.h: one searching wave, explicit queues, predecessor directions in the field)
+#define XR_ZCH_DIAL3 (-3)      // round 3's LDS form (xr_dial3.h: mask rounds, quads of lanes per chain, predecessor directions in the field word)
 #define XR_ZCH_DIAL3V2 (-4)    // ... with the XR-Maze v2 knobs
 template <bool LDS_DIST, int ZCH>
 __device__ __forceinline__ void xr_route_dispatch(const XrBatchDev& b, const int e, const int a, char* smem) {
