@@ -516,3 +516,15 @@ def test_window_form_of_the_lds_router_matches_the_oracle(window, forms):
     assert n > 150
     n = _run_episode_parity(regions[:6], policy="max", force_scratch_field=True, window=window, via_cost=5000, drc_cost=0, drc_unit=400)
     assert n > 50
+
+
+def test_router_fuzz_against_the_oracle():
+    """tools/fuzz_router.py, 40 trials: random region shapes / densities / net shapes, costs, XR-Maze v2 knobs (guide cost, margin, attempts,
+    random guide boxes), router form (round-3 LDS, round-2 LDS, HBM-scratch, LDS-window in front of it, sweeps), policy — whole episodes
+    equal the oracle in every field.  (`tools/final_round4.sh` runs 4000 trials: profiles/r04_z_fuzz_router.txt.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_router", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_router.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    steps, tally = mod.run(40, 5)
+    assert steps > 1500 and len(tally) >= 6, (steps, tally)
