@@ -190,3 +190,15 @@ def test_vector_env_observations_lie_in_the_advertised_space():
         a = denv.random_actions(5 + it)
         dobs, rew, done, dinfo = denv.step(a)
         obs, *_ = venv.step(a)
+
+
+def test_examples_run():
+    """examples/ispd18_rollout.py (the reference's workload: ispd18_test1 regions, its TCL knobs, the DQN counterpart through the fused
+    kernels) and examples/vector_rollout.py run as written."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, argv in (("ispd18_rollout.py", ["256", "6"]), ("vector_rollout.py", ["64"])):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + argv, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (script, out.stderr[-2000:])
+        assert "step" in out.stdout
