@@ -1,6 +1,7 @@
 """Game drop-in on the GPU: protocol mode replays the reference Game's recorded traces (G3) byte for
 byte; in-process mode equals the oracle env; gym façade and vector env follow the same numbers."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
