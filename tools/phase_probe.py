@@ -23,12 +23,16 @@ for i in range(n):
     sw += batch.fetch("sweeps").double().mean().item()
 torch.cuda.synchronize()
 ph = batch.fetch("phases").double().mean(0).cpu() / n
-names = (["build+setup", "relax:T", "relax:V+bound", "select+trace", "mark", "epilogue", "-", "-"] if router == 1 else
-         ["build+setup", "round: scan", "round: expand", "select+trace", "sources", "epilogue", "-", "-"] if router == 3 else
-         ["build+setup", "search start (classify)", "round: hop loop", "select+trace+sources", "-", "epilogue", "-", "-"])
+sweeps_router = router == 1
+names = (["build+setup", "relax:T", "relax:V+bound", "select+trace", "mark", "epilogue", "-", "-"] if sweeps_router else
+         # slots of the frontier router's LDS forms (xr_dial3.h / xr_dial.h): XR_LAP(k)
+         ["build + set-up", "round: scan", "round: hop loop", "select + trace + sources", "search start", "epilogue", "round: reduce + barrier", "rip-up (XR-Maze v2)"])
 tot = ph[:7].sum().item()
-print(f"router={router} mult={mult} block_threads={thr or 'auto'}  mean sweeps/step {sw / n:.2f}  total {tot:.0f} cycles/WG-step")
-for k in range(6):
-    print(f"  {names[k]:24s} {ph[k].item():10.0f} cycles  {100 * ph[k].item() / tot:5.1f}%")
-print(f"  {'round: reduce+barrier' if router == 3 else 'round: advance+partition (+ search end)'} {ph[6].item():10.0f} cycles  {100 * ph[6].item() / tot:5.1f}%" if router != 1 else "")
-print(f"  lines visited/step {ph[6].item():.1f}  iterations/step {ph[7].item():.2f}  lines/iteration {ph[6].item() / max(ph[7].item(), 1e-9):.1f}")
+print(f"router={router} mult={mult} block_threads={thr or 'auto'}  mean rounds/step {sw / n:.2f}  total {tot:.0f} cycles/WG-step")
+if sweeps_router:
+    for k in range(6):
+        print(f"  {names[k]:26s} {ph[k].item():10.0f} cycles  {100 * ph[k].item() / tot:5.1f}%")
+    print(f"  lines visited/step {ph[6].item():.1f}  iterations/step {ph[7].item():.2f}  lines/iteration {ph[6].item() / max(ph[7].item(), 1e-9):.1f}")
+else:
+    for k in (0, 4, 1, 2, 6, 3, 5):
+        print(f"  {names[k]:26s} {ph[k].item():10.0f} cycles  {100 * ph[k].item() / tot:5.1f}%")
