@@ -203,3 +203,27 @@ def test_examples_run():
         out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + argv, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (script, out.stderr[-2000:])
         assert "step" in out.stdout
+
+
+def test_static_region_env_plays_the_reference_region():
+    """`StaticRegionEnv(region=<the reference's dict>)`: the one region the reference describes, replayed; with the reference's simulator
+    configuration; episode results equal the oracle's."""
+    from oracle import xr_oracle as orc
+    from xroute_env_amd.envs import StaticRegionEnv
+    from xroute_env_amd.envs.facade import STATIC_REGIONS, load_static_region
+    v2 = dict(guide_cost=800, guide_margin=1, maze_end_iter=3)
+    env = StaticRegionEnv(STATIC_REGIONS[0], **v2)
+    ref = orc.OracleEnv(load_static_region("region1"), **v2)
+    obs, info = env.reset()
+    assert len(info["legal_actions"]) == 27 and tuple(obs.shape) == (2 + 7 * 27, 9, 34, 24)
+    total = 0.0
+    for _ in range(27):
+        a = info["legal_actions"][len(info["legal_actions"]) // 2]
+        obs, rew, term, _, info = env.step(a)
+        r = ref.step(a)
+        assert rew == orc.reward(*[int(v) for v in r["delta"]]) and term == r["done"]
+        assert np.array_equal(obs.cpu().numpy(), ref.observation())
+        total += rew
+    assert term and total < 0
+    obs, info = env.reset()                       # replayed forever
+    assert len(info["legal_actions"]) == 27

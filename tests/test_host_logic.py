@@ -129,3 +129,41 @@ def test_fixed_shape_spaces_with_and_without_gymnasium():
     finally:
         del sys.modules["gymnasium"], sys.modules["gymnasium.spaces"]
     assert sp.backend() is sp
+
+
+def test_static_region_of_the_reference_sketch_loads():
+    """The reference sketches `xroute_env/static-region1-v0` (xroute_env/__init__.py:13-33: a `static_regions` list with one entry and a
+    registration loop, commented out; `StaticRegionEnv` is an empty class).  Here the entry resolves to the region extracted from the
+    reference's own ispd18_test1 inputs at the recorded position (package data, tools/extract_regions.py --static-region1)."""
+    from xroute_env_amd.envs.facade import STATIC_REGIONS, load_static_region
+    assert STATIC_REGIONS[0]["benchmark"] == "region1" and STATIC_REGIONS[0]["position"] == [(199500, 245100), (205200, 250800)]
+    reg = load_static_region(STATIC_REGIONS[0])
+    assert reg.name == "region1" and reg.dims == (24, 34, 9) and reg.n_nets == 27 and reg.guide_off is not None
+    assert load_static_region("region1").n_nets == 27
+    # the tracks cover the routeBox + 2000 DBU
+    assert reg.xs[0] >= 199500 - 2000 and reg.xs[-1] <= 205200 + 2000 and reg.ys[0] >= 245100 - 2000 and reg.ys[-1] <= 250800 + 2000
+    import pytest
+    with pytest.raises(KeyError):
+        load_static_region("region2")
+
+
+def test_register_gym_registers_the_reference_ids(monkeypatch):
+    """`register_gym()` with a stub gymnasium: the id the reference registers (xroute_env/__init__.py:3-6) and the static-region id its
+    commented-out loop would produce (`xroute_env/static-region1-v0`, :25-33) with the region dict as kwargs."""
+    import sys
+    import types
+    import xroute_env_amd
+    calls = []
+    gym = types.ModuleType("gymnasium")
+    envs = types.ModuleType("gymnasium.envs")
+    reg = types.ModuleType("gymnasium.envs.registration")
+    reg.register = lambda **kw: calls.append(kw)
+    gym.envs, envs.registration = envs, reg
+    monkeypatch.setitem(sys.modules, "gymnasium", gym)
+    monkeypatch.setitem(sys.modules, "gymnasium.envs", envs)
+    monkeypatch.setitem(sys.modules, "gymnasium.envs.registration", reg)
+    assert xroute_env_amd.register_gym() is True
+    ids = {c["id"]: c for c in calls}
+    assert ids["xroute_env/ordering-training-v0"]["entry_point"] == "xroute_env_amd.envs:OrderingTrainingEnv"
+    st = ids["xroute_env/static-region1-v0"]
+    assert st["entry_point"] == "xroute_env_amd.envs:StaticRegionEnv" and st["kwargs"]["region"]["position"] == [(199500, 245100), (205200, 250800)]

@@ -18,10 +18,16 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--count", type=int, default=256)
 ap.add_argument("--stride", type=int, default=16, help="keep every stride-th non-empty region (spreads over the die)")
 ap.add_argument("--min-nets", type=int, default=2)
+ap.add_argument("--static-region1", default=None, metavar="OUT",
+                help="also write the one region the reference describes (xroute_env/__init__.py:13-23: ISPD-2018 test1, 1x1, position "
+                     "(199500, 245100)-(205200, 250800)) as a one-region pack: xroute_env_amd/data/static_regions.npz")
 args = ap.parse_args()
 t0 = time.time()
 design = lefdef.load_design(args.lef, args.deff, args.guide)
 ex = lefdef.RegionExtractor(design)
+if args.static_region1:
+    rb = (199500, 245100, 205200, 250800)
+    lefdef.save_region_pack(args.static_region1, [ex.extract((rb[0] - 2000, rb[1] - 2000, rb[2] + 2000, rb[3] + 2000), name="region1", route_box=rb)])
 regs = ex.gcell_regions(min_nets=args.min_nets)
 keep = regs[::args.stride][:args.count]
 lefdef.save_region_pack(args.out, keep)

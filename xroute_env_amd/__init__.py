@@ -44,4 +44,9 @@ def register_gym():
     except Exception:
         return False
     register(id=ENV_ID, entry_point="xroute_env_amd.envs:OrderingTrainingEnv")
+    # the static-region ids the reference sketches (xroute_env/__init__.py:25-33): `xroute_env/static-region1-v0`
+    from .envs.facade import STATIC_REGIONS
+    for region in STATIC_REGIONS:
+        register(id="xroute_env/static-{}-v0".format(region["benchmark"]), entry_point="xroute_env_amd.envs:StaticRegionEnv",
+                 kwargs={"region": region})
     return True

@@ -118,9 +118,30 @@ class OrderingEvaluationEnv(XRouteEnv):
         super().__init__(regions, **kw)
 
 
+# the static regions the reference sketches (xroute_env/__init__.py:13-23), extracted from its own benchmark inputs by
+# tools/extract_regions.py --static-region1 (data derived from the ispd18_test1 LEF / DEF / guide files, like tests/golden's region pack)
+STATIC_REGIONS = [{"benchmark": "region1", "from": "ISPD-2018 test1", "size": "1x1", "position": [(199500, 245100), (205200, 250800)]}]
+
+
+def load_static_region(key):
+    """A static region by the reference's description: its benchmark name ("region1") or the dict of `static_regions`
+    (matched by "benchmark").  Returns a `Region` (worker model: the 1x1 GCell is the routeBox, +2000 DBU of routing resource)."""
+    import os
+    from ..lefdef import load_region_pack
+    name = key.get("benchmark") if isinstance(key, dict) else str(key)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "static_regions.npz")
+    for reg in load_region_pack(path):
+        if reg.name == name:
+            return reg
+    raise KeyError(f"no static region {name!r} (known: {[r['benchmark'] for r in STATIC_REGIONS]})")
+
+
 class StaticRegionEnv(XRouteEnv):
     """One fixed region replayed forever (reference xroute_env/__init__.py:13-33 sketches
-    `static-{benchmark}-v0` registrations with a `region` kwarg; the class itself is empty)."""
+    `static-{benchmark}-v0` registrations with a `region` kwarg — a dict with "benchmark", "position" ...; the class itself is empty).
+    `region`: a `Region`, the reference's dict, or the benchmark name."""
 
     def __init__(self, region, **kw):
+        if isinstance(region, (dict, str)):
+            region = load_static_region(region)
         super().__init__([region], **kw)

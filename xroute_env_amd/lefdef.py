@@ -514,6 +514,8 @@ def save_region_pack(path: str, regions: List[Region]):
         out[f"r{i}_ldir"] = r.layer_dir
         out[f"r{i}_idx"], out[f"r{i}_rec"] = idx, r.nodes[idx]
         out[f"r{i}_k"] = np.array(r.n_nets)
+        if r.name:
+            out[f"r{i}_name"] = np.array(str(r.name))
         if r.guide_off is not None:
             out[f"r{i}_goff"] = np.asarray(r.guide_off, np.int32)
             out[f"r{i}_gbox"] = np.asarray(r.guide_box, np.int16).reshape(-1, 6)
@@ -528,7 +530,7 @@ def load_region_pack(path: str) -> List[Region]:
         nodes = np.full(dims[0] * dims[1] * dims[2], NORMAL, np.uint32)
         nodes[z[f"r{i}_idx"]] = z[f"r{i}_rec"]
         regs.append(Region(dims, z[f"r{i}_xs"], z[f"r{i}_ys"], z[f"r{i}_ldir"], nodes, int(z[f"r{i}_k"]),
-                           np.zeros(3, np.int32), f"pack{i}"))
+                           np.zeros(3, np.int32), str(z[f"r{i}_name"]) if f"r{i}_name" in z.files else f"pack{i}"))
         if f"r{i}_goff" in z.files:
             regs[-1].guide_off, regs[-1].guide_box = z[f"r{i}_goff"], z[f"r{i}_gbox"]
     return regs
