@@ -1,0 +1,59 @@
+"""Obstacle tower alone: time per launch and agreement of library builds on the same input.
+python tools/tower_probe.py [envs] [D H W] — libraries from XR_TOWER_LIBS (comma separated, default libxroute_hip.so); one subprocess per
+library (the loader binds one build per process), outputs compared in the parent."""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(B, dims, out_path):
+    import torch
+    from xroute_env_amd import agents
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    rep = agents.RepresentationNetwork().to(dev).eval()
+    with torch.no_grad():                       # BatchNorm statistics away from the identity, as a trained network has them
+        for m in rep.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    D, H, W = dims
+    tower = agents.FusedObstacleTower(rep, dims, dev)
+    assert tower.supported, dims
+    g = torch.Generator(device="cpu").manual_seed(5)
+    head = (torch.rand((B, D * H * W), generator=g) < 0.3).float().to(dev)
+    out = tower(head)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(3): tower(head)
+    ev[0].record()
+    for _ in range(20): out = tower(head)
+    ev[1].record(); torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / 20
+    with torch.no_grad():
+        ref = agents.normalize(rep.encode_obstacles(head[:64].reshape(64, 1, D, H, W)))
+    err = float((out[:64] - ref).abs().max())
+    torch.save(out.cpu(), out_path)
+    print(json.dumps({"lib": os.environ.get("XR_LIB", "libxroute_hip.so"), "envs": B, "dims": dims, "ms_per_launch": round(ms, 4),
+                      "ms_per_1024_envs": round(ms * 1024 / B, 4), "max_abs_err_vs_framework_path": err}))
+
+
+if __name__ == "__main__":
+    if sys.argv[1:2] == ["--child"]:
+        child(int(sys.argv[2]), tuple(int(v) for v in sys.argv[3:6]), sys.argv[6])
+        sys.exit(0)
+    a = [int(v) for v in sys.argv[1:]]
+    B = a[0] if a else 1024
+    dims = tuple(a[1:4]) if len(a) >= 4 else (9, 40, 24)
+    libs = os.environ.get("XR_TOWER_LIBS", "libxroute_hip.so").split(",")
+    outs = []
+    for rep_ in range(2):
+        for i, lib in enumerate(libs):
+            path = f"/tmp/tower_probe_{i}.pt"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(B)] + [str(v) for v in dims] + [path],
+                               env=dict(os.environ, XR_LIB=lib), capture_output=True, text=True)
+            print(r.stdout.strip() or r.stderr[-2000:])
+    if len(libs) > 1:
+        import torch
+        o = [torch.load(f"/tmp/tower_probe_{i}.pt") for i in range(len(libs))]
+        for i in range(1, len(libs)):
+            print(f"{libs[i]} vs {libs[0]}: max abs diff {float((o[i] - o[0]).abs().max()):.3e}")

@@ -25,6 +25,7 @@
 namespace {
 
 typedef float xt_f2 __attribute__((ext_vector_type(2)));     // pairs of output channels: v_pk_fma_f32
+typedef float xt_f4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_16x16x4_f32
 
 struct XtDims {
     int D, H, W;          // input grid
@@ -32,6 +33,7 @@ struct XtDims {
     int od, oh, ow;       // its output
     int cols;             // columns of the last stage: ow + 2
     int pad_in_b;         // the padded copy of x lives in b's LDS space (else everything of the 1-channel block fits the first activation's)
+    int tail;             // floats of b + the first activation's allocation: behind them a zero word (+3 pad) and the waves' column sums [nw][cols][3]
 };
 
 // packed weights (floats), offsets
@@ -43,6 +45,22 @@ constexpr int XT_C2 = XT_C1 + 1520;         // same       block(7).conv2
 constexpr int XT_AL2 = XT_C2 + 1520;        // 7*3*64*3   align2: [ch][d][h][kw]
 constexpr int XT_KV = XT_AL2 + 4032;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_TOTAL = XT_KV + 64;
+
+// A operand of the paired implicit GEMM (see the 7-channel block below): lane l holds row m = l & 15 = (dw, co) and k = l >> 4 = c4 of every
+// one of the 63 (kd, kh, ci) steps: W[co][ci][kd][kh][kw = c4 - dw], 0 where kw is no tap or co is the padding channel.
+// wc: the convolution's packed weights [ci][tap][co padded to 8].
+__device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lane, float (&wA)[63]) {
+    const int m = lane & 15, c4 = lane >> 4, dw = m >> 3, co = m & 7, kw = c4 - dw;
+    const bool ok = co < 7 && (unsigned)kw < 3u;
+    const float* __restrict__ src = wc + (ok ? kw * 8 + co : 0);
+#pragma unroll
+    for (int g = 0; g < 9; g++)
+#pragma unroll
+        for (int ci = 0; ci < 7; ci++) {
+            const float v = src[(ci * 27 + g * 3) * 8];
+            wA[g * 7 + ci] = ok ? v : 0.f;
+        }
+}
 
 template <int BT>
 __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
@@ -64,6 +82,10 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     float* xpad = g.pad_in_b ? bufB : bufC1;
     float* ypad = g.pad_in_b ? bufC1 : bufC1 + Np;
     float* bufX = ypad + Np;                          // a: [D][H][W]
+
+    const int zidx = g.tail;                          // a word that stays 0: what a tap outside the data reads
+    float* red = xt_smem + g.tail + 4;                // [nthr / 64][cols][3]: every wave's column sums of the last stage
+    for (int i = tid; i < 4 + (nthr >> 6) * g.cols * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
 
     const float* __restrict__ src = head + (int64_t)e * stride;
     for (int i = tid; i < Np; i += nthr) { xpad[i] = 0.f; ypad[i] = 0.f; }
@@ -130,13 +152,17 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
-    // (measured and dropped: a "column" form — one thread per (h, w) with its three depth slices, 12 packed FMAs per LDS read — 1.19 ms against
-    //  0.79 ms per 1024 envs; the convolution's weights in LDS instead of scalar loads — the extra 6 KB push the workgroup past what a CU
-    //  hands out at full speed: 6.1 ms; packed FMAs alone changed nothing; storing the first activation only where it depends on the data
-    //  (h <= oh, w <= ow; relu(bias) elsewhere) with one thread per (h, w') column in the last stage — 25 % fewer cells, every thread busy —
-    //  0.88 against 0.84 ms per agent step.  One cell per thread, weights through the scalar cache it stays.)
+    // Both 7 -> 7-channel 3x3x3 convolutions run on the matrix pipe as an implicit GEMM of v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered
+    // fma chain).  With 7 output channels a plain mapping fills 7 of the 16 rows; here one instruction computes TWO neighbouring output
+    // columns of 16 cell pairs:
+    //   M (A, rows)  = (dw, co): output column 2p + dw, channel co (8 slots, 7 used)                          -> 14 of 16 rows
+    //   N (B, cols)  = 16 consecutive cell pairs (h, p) of one depth slice, flattened over the rows
+    //   K            = the four input columns 2p - 1 .. 2p + 2 of ONE input channel at ONE (kd, kh): c4 = dw + kw, weight 0 where kw falls outside
+    // => 63 instructions (9 (kd, kh) x 7 channels) per 32 cells instead of 189 LDS reads + 756 packed FMAs per cell-thread; the weights
+    // sit in 63 VGPRs of every lane for the whole convolution (the scalar-load form spilled its weight SGPRs to VGPR lanes and waited for
+    // every s_load: 3.5x its FMA bound), the activations are one LDS read per instruction.  Lanes whose tap falls outside the data read a
+    // zero word instead (a zero WEIGHT would not do: 0 x garbage may be NaN).
     // Only the cells with h <= oh and w <= ow see any data (their taps reach h - 1 < oh, w - 1 < ow); every other stored cell is relu(bias).
-    // 3 x 39 x 23 = 2691 computed cells for a 24x40x9 region: three passes of 1024 threads instead of four (3075 = 3 x 1024 + 3).
     const int ncellC1 = 3 * he1 * we1;
     for (int i = tid; i < ncellC1; i += nthr) {
         const int w = i % we1, h = (i / we1) % he1;
@@ -145,103 +171,120 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             for (int co = 0; co < 7; co++) bufC1[co * ncellC1 + i] = fmaxf(wt[XT_C1 + 1512 + co], 0.f);
         }
     }
-    const int hc = oh + 1, wc = ow + 1, ncomp = 3 * hc * wc;
-    for (int q = tid; q < ncomp; q += nthr) {
-        const int w = q % wc, h = (q / wc) % hc, d = q / (wc * hc);
-        const int i = (d * he1 + h) * we1 + w;
-        xt_f2 acc[4];
+    const int lane = tid & 63, nw = nthr >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pn = lane & 15, q = lane >> 4;             // B operand: cell pair pn, input column offset q; D: rows 4q .. 4q + 3 of pair pn
+    const int dwv = q >> 1, co0 = 4 * (q & 1);           // D rows -> output column 2p + dwv, channels co0 .. co0 + 3
+    const int cbase = (int)(bufC1 - xt_smem);
+    {
+        float wA[63];
+        xt_load_wA(wt + XT_C1, lane, wA);
+        float bias[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C1 + 1512)[k];
-        for (int kd = 0; kd < 3; kd++) {
-            const int dd = d + kd - 1;
-            if ((unsigned)dd >= (unsigned)od) continue;              // (d >= od: standard padding; d < 0 or >= 3: the convolution's own)
-            for (int kh = 0; kh < 3; kh++) {
-                const int hh = h + kh - 1;
-                if ((unsigned)hh >= (unsigned)oh) continue;
+        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 1512 + co0 + i];
+        const int hc = oh + 1, wc = ow + 1, ppr = (wc + 1) >> 1, npair = hc * ppr, T = (npair + 15) >> 4;
+        for (int g = wv; g < 3 * T; g += nw) {          // (slices dealt round-robin: a wave's tiles mix the 42- and the 63-instruction kind)
+            const int d = g % 3, t = g / 3;
+            const int f = t * 16 + pn;
+            const bool lv = f < npair;
+            const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
+            const int col = 2 * p + q - 1;
+            const bool cv = lv && (unsigned)col < (unsigned)ow;
+            const int base = (d * oh + h) * ow + col;
+            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const int ww = w + kw - 1;
-                    const bool in = (unsigned)ww < (unsigned)ow;
-                    const int cell = (dd * oh + hh) * ow + (in ? ww : 0);
-                    const int tap = (kd * 3 + kh) * 3 + kw;
+            for (int kd = 0; kd < 3; kd++) {
+                const int dd = d + kd - 1;
+                if ((unsigned)dd >= (unsigned)od) continue;          // (d >= od: standard padding; d < 0 or >= 3: the convolution's own) — wave-uniform
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) {
+                    const bool m = cv && (unsigned)(h + kh - 1) < (unsigned)oh;
+                    int a = m ? base + ((kd - 1) * oh + (kh - 1)) * ow : zidx;
+                    const int st = m ? ncellB : 0;
 #pragma unroll
                     for (int ci = 0; ci < 7; ci++) {
-                        const float v = in ? bufB[ci * ncellB + cell] : 0.f;
-                        const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_C1 + (ci * 27 + tap) * 8);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a], acc, 0, 0, 0);
+                        a += st;
                     }
                 }
             }
-        }
+            const int w = 2 * p + dwv;
+            if (lv && w < wc) {
 #pragma unroll
-        for (int co = 0; co < 7; co++) bufC1[co * ncellC1 + i] = fmaxf(acc[co >> 1][co & 1], 0.f);
+                for (int i = 0; i < 4; i++)
+                    if (co0 + i < 7) bufC1[(co0 + i) * ncellC1 + (d * he1 + h) * we1 + w] = fmaxf(acc[i], 0.f);
+            }
+        }
     }
     __syncthreads();
     // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
-    // thread = (column w', row group); it keeps three sums: what its cells give to out[w' + 1], out[w'], out[w' - 1]
-    // (cols = ow + 2 exactly and the (row, depth) pairs dealt round-robin to the row groups: 120 pairs over 42 groups of 24 columns = three cells per
-    //  thread for a 24x40x9 region, where 32 groups of 32 columns walking whole rows took six)
-    const int cols = g.cols, G = nthr / cols;
-    const int wq = tid % cols, gi = tid / cols;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (gi < G) {
-        for (int pr = gi; pr < 3 * (oh + 2); pr += G) {
-            const int h = pr / 3;
-            {
-                const int d = pr - 3 * h;
-                xt_f2 acc[4];
+    // Same implicit GEMM; the epilogue multiplies every finished cell with its three align2 weights (what it gives to out[w + 1], out[w],
+    // out[w - 1]) and adds the products to the wave's own column sums in LDS (no atomics, a fixed order: same input, same bits).
+    const int cols = g.cols;
+    float* redw = red + wv * cols * 3;
+    {
+        float wA[63];
+        xt_load_wA(wt + XT_C2, lane, wA);
+        float bias[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_C2 + 1512)[k];
-                for (int kd = 0; kd < 3; kd++) {
-                    const int dd = d + kd - 1;
-                    if ((unsigned)dd >= 3u) continue;
-                    for (int kh = 0; kh < 3; kh++) {
-                        const int hh = h + kh - 1;
-                        if (hh < 0) continue;                          // (hh <= oh + 2 < he1: always stored)
+        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 1512 + co0 + i];
+        const int ppr = (cols + 1) >> 1, npair = (oh + 2) * ppr, T = (npair + 15) >> 4;
+        for (int g2 = wv; g2 < 3 * T; g2 += nw) {
+            const int d = g2 % 3, t = g2 / 3;
+            const int f = t * 16 + pn;
+            const bool lv = f < npair;
+            const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
+            const int col = 2 * p + q - 1;
+            const bool cv = lv && (unsigned)col < (unsigned)we1;
+            const int base = cbase + (d * he1 + h) * we1 + col;
+            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                        for (int kw = 0; kw < 3; kw++) {
-                            const int ww = wq + kw - 1;
-                            const bool in = ww >= 0;                   // (ww <= ow + 2 < we1)
-                            const int cell = (dd * he1 + hh) * we1 + (in ? ww : 0);
-                            const int tap = (kd * 3 + kh) * 3 + kw;
-        #pragma unroll
+            for (int kd = 0; kd < 3; kd++) {
+                const int dd = d + kd - 1;
+                if ((unsigned)dd >= 3u) continue;
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) {
+                    const bool m = cv && h + kh - 1 >= 0;          // (h + kh - 1 <= oh + 2 < he1: always stored)
+                    int a = m ? base + ((kd - 1) * he1 + (kh - 1)) * we1 : zidx;
+                    const int st = m ? ncellC1 : 0;
+#pragma unroll
                     for (int ci = 0; ci < 7; ci++) {
-                                const float v = in ? bufC1[ci * ncellC1 + cell] : 0.f;
-                                const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_C2 + (ci * 27 + tap) * 8);
-#pragma unroll
-                                for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
-                            }
-                        }
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a], acc, 0, 0, 0);
+                        a += st;
                     }
                 }
-                const bool inb = d < od && h < oh && wq < ow;
-                const int cellb = inb ? (d * oh + h) * ow + wq : 0;
+            }
+            const int w = 2 * p + dwv;
+            const bool ov = lv && w < cols;
+            const bool inb = ov && d < od && h < oh && w < ow;
+            const int cellb = inb ? (d * oh + h) * ow + w : 0;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int co = 0; co < 7; co++) {
-                    const float p = inb ? bufB[co * ncellB + cellb] : 0.f;
-                    const float c = fmaxf(acc[co >> 1][co & 1] + p, 0.f);
-                    const float* __restrict__ wk = wt + XT_AL2 + ((co * 3 + d) * 64 + h) * 3;
+            for (int i = 0; i < 4; i++) {
+                if (co0 + i < 7 && ov) {
+                    const float pv = inb ? bufB[(co0 + i) * ncellB + cellb] : 0.f;
+                    const float c = fmaxf(acc[i] + pv, 0.f);
+                    const float* __restrict__ wk = wt + XT_AL2 + (((co0 + i) * 3 + d) * 64 + h) * 3;
                     s0 += wk[0] * c; s1 += wk[1] * c; s2 += wk[2] * c;
                 }
             }
+            s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cell
+            // the tile's pairs lie in rows h0 .. h1: one row at a time, so that the lanes of a pass own distinct columns
+            const int h0 = (t * 16) / ppr, h1 = min(t * 16 + 15, npair - 1) / ppr;
+            for (int r = h0; r <= h1; r++) {
+                if (ov && !(q & 1) && h == r) {
+                    redw[w * 3 + 0] += s0; redw[w * 3 + 1] += s1; redw[w * 3 + 2] += s2;
+                }
+            }
         }
-    }
-    __syncthreads();                                   // every thread is done with bufB: it becomes the reduction array [G][cols][3]
-    float* red = bufB;
-    if (gi < G) {
-        red[(gi * cols + wq) * 3 + 0] = s0;
-        red[(gi * cols + wq) * 3 + 1] = s1;
-        red[(gi * cols + wq) * 3 + 2] = s2;
     }
     __syncthreads();
     if (tid < 64) {
         const int w = tid;
         float v = wt[XT_KV + w];
-        for (int q = 0; q < G; q++) {                  // fixed order
-            if (w < cols) v += red[(q * cols + w) * 3 + 1];
-            if (w >= 1 && w - 1 < cols) v += red[(q * cols + w - 1) * 3 + 0];
-            if (w + 1 < cols) v += red[(q * cols + w + 1) * 3 + 2];
+        for (int k = 0; k < nw; k++) {                 // fixed order
+            if (w < cols) v += red[(k * cols + w) * 3 + 1];
+            if (w >= 1 && w - 1 < cols) v += red[(k * cols + w - 1) * 3 + 0];
+            if (w + 1 < cols) v += red[(k * cols + w + 1) * 3 + 2];
         }
         if (normalize) {          // the reference's row-wise min-max normalisation (baseline/baseline_utils.py:45-63), wave 0 holds the 64 values
             float lo = v, hi = v;
@@ -378,7 +421,8 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     else { g.pad_in_b = 0; c1_alloc = 2 * Np + N; }           // a narrow grid (e.g. 7 x 34 x 9): the 1-channel block's padded copies need more than the
                                                               // 7-channel stages — the allocation simply grows (it is small anyway)
     if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
-    const size_t lds = (size_t)(nB + c1_alloc) * sizeof(float);
+    g.tail = (int)(nB + c1_alloc);
+    const size_t lds = (size_t)(nB + c1_alloc + 4 + (threads / 64) * g.cols * 3) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
     const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
                    : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512>);
