@@ -33,6 +33,13 @@ def child(B, dims, out_path):
         ref = agents.normalize(rep.encode_obstacles(head[:64].reshape(64, 1, D, H, W)))
     err = float((out[:64] - ref).abs().max())
     torch.save(out.cpu(), out_path)
+    if os.environ.get("XT_PHASES"):             # a -DXT_PHASE_TIMING build (make ttiming): thread 0's cycles per stage in the first floats of a row
+        names = ["zero + load x", "block(1) conv1", "block(1) conv2 + residual", "align1 5x5x5 1->7", "block(7) conv1 (MFMA)", "block(7) conv2 + align2 sums (MFMA)", "final sums + normalise"]
+        cyc = out[:, :7].double().mean(0).tolist()
+        tot = sum(cyc)
+        for n_, c in zip(names, cyc):
+            print(f"  {n_:40s} {c:9.0f} cycles {100 * c / tot:5.1f}%")
+        print(f"  {'total':40s} {tot:9.0f} cycles per env (thread 0)")
     print(json.dumps({"lib": os.environ.get("XR_LIB", "libxroute_hip.so"), "envs": B, "dims": dims, "ms_per_launch": round(ms, 4),
                       "ms_per_1024_envs": round(ms * 1024 / B, 4), "max_abs_err_vs_framework_path": err}))
 

@@ -62,6 +62,13 @@ __device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lan
         }
 }
 
+// -DXT_PHASE_TIMING (make ttiming; tools/tower_probe.py with XT_PHASES=1): thread 0's cycle count per stage replaces the first floats of the env's output row
+#ifdef XT_PHASE_TIMING
+#define XT_LAP(k) do { if (tid == 0) xt_lap[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XT_LAP(k) do { } while (0)
+#endif
+
 template <int BT>
 __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
                                                           const float* __restrict__ wt, float* __restrict__ out, int normalize) {
@@ -83,6 +90,10 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     float* ypad = g.pad_in_b ? bufC1 : bufC1 + Np;
     float* bufX = ypad + Np;                          // a: [D][H][W]
 
+#ifdef XT_PHASE_TIMING
+    unsigned long long xt_lap[9];
+#endif
+    XT_LAP(0);
     const int zidx = g.tail;                          // a word that stays 0: what a tap outside the data reads
     float* red = xt_smem + g.tail + 4;                // [nthr / 64][cols][3]: every wave's column sums of the last stage
     for (int i = tid; i < 4 + (nthr >> 6) * g.cols * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
@@ -95,6 +106,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         xpad[((d + 1) * Hp + h + 1) * Wp + w + 1] = src[i];
     }
     __syncthreads();
+    XT_LAP(1);
     // ---- ResidualBlock(1): y = relu(conv3(x) + b1) ------------------------------------------------------------------------------
     for (int i = tid; i < N; i += nthr) {
         const int w = i % W, h = (i / W) % H, d = i / HW;
@@ -109,6 +121,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         ypad[pi + (Hp + 1) * Wp + 1] = fmaxf(acc, 0.f);
     }
     __syncthreads();
+    XT_LAP(2);
     // a = relu(conv3(y) + b2 + x)
     for (int i = tid; i < N; i += nthr) {
         const int w = i % W, h = (i / W) % H, d = i / HW;
@@ -123,6 +136,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         bufX[i] = fmaxf(acc + xpad[pi + (Hp + 1) * Wp + 1], 0.f);
     }
     __syncthreads();
+    XT_LAP(3);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
     for (int i = tid; i < ncellB; i += nthr) {
@@ -151,6 +165,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int co = 0; co < 7; co++) bufB[co * ncellB + i] = acc[co >> 1][co & 1];
     }
     __syncthreads();
+    XT_LAP(4);
     // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
     // Both 7 -> 7-channel 3x3x3 convolutions run on the matrix pipe as an implicit GEMM of v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered
     // fma chain).  With 7 output channels a plain mapping fills 7 of the 16 rows; here one instruction computes TWO neighbouring output
@@ -216,6 +231,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
     }
     __syncthreads();
+    XT_LAP(5);
     // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
     // Same implicit GEMM; the epilogue multiplies every finished cell with its three align2 weights (what it gives to out[w + 1], out[w],
     // out[w - 1]) and adds the products to the wave's own column sums in LDS (no atomics, a fixed order: same input, same bits).
@@ -278,6 +294,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
     }
     __syncthreads();
+    XT_LAP(6);
     if (tid < 64) {
         const int w = tid;
         float v = wt[XT_KV + w];
@@ -296,6 +313,10 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
         out[(int64_t)e * 64 + w] = v;
     }
+#ifdef XT_PHASE_TIMING
+    XT_LAP(7);
+    if (tid == 0) for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
