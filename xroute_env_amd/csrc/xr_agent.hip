@@ -12,7 +12,7 @@
 // Outside the cells the data can influence (h < oh + 2, w < ow + 2) c equals the block's response to an all-zero grid, which does not
 // depend on the env: the caller folds that part (and the bias) into `kvec`, the kernel sums the inside cells only.
 //
-// One workgroup of 512 threads per env, everything in LDS (b: 7*od*oh*ow floats, the first activation of the 7-channel block:
+// One workgroup of 1024 threads per env, everything in LDS (b: 7*od*oh*ow floats, the first activation of the 7-channel block:
 // 7*3*(oh+3)*(ow+3) floats; the 1-channel stages live inside the latter's space), weights through scalar loads (every lane of a wave
 // uses the same weight), 7 output channels per thread and cell so that an LDS read feeds 7 FMAs.  fp32 throughout; the sums run in a
 // fixed order (no atomics): same input, same bits.
@@ -26,13 +26,18 @@ namespace {
 
 typedef float xt_f2 __attribute__((ext_vector_type(2)));     // pairs of output channels: v_pk_fma_f32
 typedef float xt_f4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_16x16x4_f32
+#ifndef XT_EXP
+#define XT_EXP 0
+#endif
 
 struct XtDims {
     int D, H, W;          // input grid
     int sd, sh, sw;       // stride of the aligning convolution
     int od, oh, ow;       // its output
     int cols;             // columns of the last stage: ow + 2
-    int pad_in_b;         // the padded copy of x lives in b's LDS space (else everything of the 1-channel block fits the first activation's)
+    int y_in_b;           // the 1-channel block's intermediate lives in b's LDS space (else behind x in the first activation's space, which then grows)
+    int strip;            // cells per thread of the 1-channel convolutions: 4 where the rows are whole strips, else 3
+    int vec_load;         // rows of x are multiples of 16 bytes at 16-byte aligned addresses: four cells per load
     int tail;             // floats of b + the first activation's allocation: behind them a zero word (+3 pad) and the waves' column sums [nw][cols][3]
 };
 
@@ -40,26 +45,65 @@ struct XtDims {
 constexpr int XT_A1 = 0;                    // 27 + 1     block(1).conv1 (BatchNorm folded)
 constexpr int XT_A2 = XT_A1 + 28;           // 27 + 1     block(1).conv2
 constexpr int XT_AL1 = XT_A2 + 28;          // 125*8 + 8  align1: [kd][kh][kw][co padded to 8], bias[8]
-constexpr int XT_C1 = XT_AL1 + 1008;        // 7*27*8 + 8 block(7).conv1: [ci][tap][co padded to 8], bias[8]
-constexpr int XT_C2 = XT_C1 + 1520;         // same       block(7).conv2
-constexpr int XT_AL2 = XT_C2 + 1520;        // 7*3*64*3   align2: [ch][d][h][kw]
-constexpr int XT_KV = XT_AL2 + 4032;        // 64         bias + contribution of every cell the data cannot influence
+constexpr int XT_C1 = XT_AL1 + 1008;        // 16*64*4 + 8 block(7).conv1 as the A operands of its 63 matrix instructions: [step / 4][lane][step % 4] (see xt_load_wA), bias[8]
+constexpr int XT_C2 = XT_C1 + 4104;         // same       block(7).conv2
+constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padded to 8][kw]: the 12 weights a lane of the last stage needs are neighbours
+constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_TOTAL = XT_KV + 64;
 
 // A operand of the paired implicit GEMM (see the 7-channel block below): lane l holds row m = l & 15 = (dw, co) and k = l >> 4 = c4 of every
-// one of the 63 (kd, kh, ci) steps: W[co][ci][kd][kh][kw = c4 - dw], 0 where kw is no tap or co is the padding channel.
-// wc: the convolution's packed weights [ci][tap][co padded to 8].
-__device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lane, float (&wA)[63]) {
-    const int m = lane & 15, c4 = lane >> 4, dw = m >> 3, co = m & 7, kw = c4 - dw;
-    const bool ok = co < 7 && (unsigned)kw < 3u;
-    const float* __restrict__ src = wc + (ok ? kw * 8 + co : 0);
+// one of the 63 (kd, kh, ci) steps: W[co][ci][kd][kh][kw = c4 - dw], 0 where kw is no tap or co is the padding channel — laid out by the caller
+// (agents.FusedObstacleTower) as [step / 4][lane][step % 4]: 16 coalesced 16-byte loads per lane (as 63 gathers from the convolution's own
+// layout the fetch took 15 k cycles per convolution and workgroup: a tenth of the kernel).
+__device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lane, float (&wA)[64]) {
+    const xt_f4* __restrict__ src = reinterpret_cast<const xt_f4*>(wc) + lane;
 #pragma unroll
-    for (int g = 0; g < 9; g++)
+    for (int s4 = 0; s4 < 16; s4++) {
+        const xt_f4 v = src[s4 * 64];
+        wA[s4 * 4 + 0] = v[0]; wA[s4 * 4 + 1] = v[1]; wA[s4 * 4 + 2] = v[2]; wA[s4 * 4 + 3] = v[3];
+    }
+}
+
+// One 3x3x3 convolution of the 1-channel block on zero-padded grids [D + 2][H + 2][W + 2]: a thread takes S neighbouring cells of a row, per
+// tap row S + 2 LDS reads feed 3 S FMAs (one cell per thread: 27 reads for 27 FMAs, and the index arithmetic once per cell).  Every cell's sum
+// runs in the order (kd, kh, kw).  Measured on a 24x40x9 region, cycles of the two convolutions: S = 1: 17.1 + 17.9 k, 2: 17.5 + 18.2 k,
+// 3: 19.8 + 21.1 k, 4: 14.0 + 14.9 k (profiles/r04_strip_tower_1ch_strips.txt); on 25x34x9 (rows of 25: the seventh strip holds one cell) the
+// whole kernel takes 0.294 ms per 1024 envs with S = 3 and 0.306 with S = 4: S = 4 where the rows are whole strips, else 3.  RES: out is the INPUT of the block (x) and holds x at the cell: out = relu(conv + x), in place.
+// (A strip may hang over the end of its row: those reads hit the next row or the floats behind the grid — inside the allocation — and feed
+//  only sums that are dropped.)
+template <int S, bool RES>
+__device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, const float* in, float* out, int D, int H, int W, int tid, int nthr) {
+    const int Hp = H + 2, Wp = W + 2, spr = (W + S - 1) / S, nstrip = D * H * spr;
+    float wk[27];
 #pragma unroll
-        for (int ci = 0; ci < 7; ci++) {
-            const float v = src[(ci * 27 + g * 3) * 8];
-            wA[g * 7 + ci] = ok ? v : 0.f;
-        }
+    for (int k = 0; k < 27; k++) wk[k] = wgt[k];
+    const float bias = wgt[27];
+    for (int i = tid; i < nstrip; i += nthr) {
+        const int sx = i % spr, r = i / spr, h = r % H, d = r / H, w0 = sx * S;
+        const int pi = (d * Hp + h) * Wp + w0;                 // tap (0, 0, 0) of the strip's first cell
+        float acc[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) acc[j] = bias;
+#pragma unroll
+        for (int kd = 0; kd < 3; kd++)
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                const float* row = in + pi + (kd * Hp + kh) * Wp;
+                float v[S + 2];
+#pragma unroll
+                for (int j = 0; j < S + 2; j++) v[j] = row[j];
+#pragma unroll
+                for (int j = 0; j < S; j++) {
+                    acc[j] += wk[(kd * 3 + kh) * 3 + 0] * v[j];
+                    acc[j] += wk[(kd * 3 + kh) * 3 + 1] * v[j + 1];
+                    acc[j] += wk[(kd * 3 + kh) * 3 + 2] * v[j + 2];
+                }
+            }
+        float* o = out + pi + (Hp + 1) * Wp + 1;
+#pragma unroll
+        for (int j = 0; j < S; j++)
+            if (w0 + j < W) o[j] = fmaxf(RES ? acc[j] + o[j] : acc[j], 0.f);
+    }
 }
 
 // -DXT_PHASE_TIMING (make ttiming; tools/tower_probe.py with XT_PHASES=1): thread 0's cycle count per stage replaces the first floats of the env's output row
@@ -67,6 +111,16 @@ __device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lan
 #define XT_LAP(k) do { if (tid == 0) xt_lap[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define XT_LAP(k) do { } while (0)
+#endif
+
+#if XT_EXP == 1        // timing experiment: the matrix pipe alone (no LDS reads)
+#define XT_STEP(wa, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, (float)a, acc, 0, 0, 0)
+#elif XT_EXP == 2      // timing experiment: the LDS reads alone
+#define XT_STEP(wa, bv) acc[0] += (bv) * (wa)
+#elif XT_EXP == 3      // timing experiment: two accumulators, alternating
+#define XT_STEP(wa, bv) do { if (ci & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc2, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc, 0, 0, 0); } while (0)
+#else
+#define XT_STEP(wa, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc, 0, 0, 0)
 #endif
 
 template <int BT>
@@ -80,81 +134,74 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     const int od = g.od, oh = g.oh, ow = g.ow;
     const int he1 = oh + 3, we1 = ow + 3;            // extent of the block's first activation that the inside cells read
     const int nB = 7 * od * oh * ow;
-    float* bufB = xt_smem;                            // [7][od][oh][ow]
-    float* bufC1 = xt_smem + nB;                      // [7][3][he1][we1]
-    // The 1-channel block works on ZERO-PADDED copies (a one-voxel halo): a tap is one LDS read at a fixed offset and one FMA — with bounds
-    // checks it was ~10 VALU instructions per FMA and a fifth of the kernel.  x (padded) sits in b's space or, when everything fits there, in the
-    // first activation's space (g.pad_in_b); y (padded) and a (unpadded, what the aligning convolution reads) in the first activation's space.
+    float* bufB = xt_smem;                            // [od][oh][ow][7]: the channels of a cell are neighbours
+    float* bufC1 = xt_smem + nB;                      // [3][he1][we1][7]
+    // The 1-channel block works on ZERO-PADDED grids (a one-voxel halo): a tap is one LDS read at a fixed offset — with bounds checks it was ~10 VALU
+    // instructions per FMA.  x sits in the first activation's space and becomes a = block(x) IN PLACE (the residual is the cell's own x, read by the
+    // thread that writes a there): the aligning convolution then reads a padded grid too; the intermediate y sits in b's space (dead before b is
+    // written) or, where that is too small (narrow grids), behind x.
     const int Hp = H + 2, Wp = W + 2, Np = (D + 2) * Hp * Wp;
-    float* xpad = g.pad_in_b ? bufB : bufC1;
-    float* ypad = g.pad_in_b ? bufC1 : bufC1 + Np;
-    float* bufX = ypad + Np;                          // a: [D][H][W]
+    float* xpad = bufC1;
+    float* ypad = g.y_in_b ? bufB : bufC1 + Np;
 
 #ifdef XT_PHASE_TIMING
     unsigned long long xt_lap[9];
 #endif
     XT_LAP(0);
-    const int zidx = g.tail;                          // a word that stays 0: what a tap outside the data reads
-    float* red = xt_smem + g.tail + 4;                // [nthr / 64][cols][3]: every wave's column sums of the last stage
-    for (int i = tid; i < 4 + (nthr >> 6) * g.cols * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
+    const int lane = tid & 63, nw = nthr >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pn = lane & 15, q = lane >> 4;             // (7-channel block) B operand: cell pair pn, input column offset q; D: rows 4q .. 4q + 3 of pair pn
+    const int dwv = q >> 1, co0 = 4 * (q & 1);           // D rows -> output column 2p + dwv, channels co0 .. co0 + 3
+    // the A operand of the 7-channel block's first convolution: 63 gathers per lane, issued here so that the 1-channel stages hide them
+    float wA[64];
+    xt_load_wA(wt + XT_C1, lane, wA);
+    const float kv = wt[XT_KV + lane];                // (what the last stage starts from: fetched here, not behind the last barrier)
+    const int zidx = g.tail;                          // seven words that stay 0: what a tap outside the data reads (one per channel)
+    float* red = xt_smem + g.tail + 8;                // [nthr / 64][cols][3]: every wave's column sums of the last stage
+    for (int i = tid; i < 8 + (nthr >> 6) * g.cols * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
 
     const float* __restrict__ src = head + (int64_t)e * stride;
     for (int i = tid; i < Np; i += nthr) { xpad[i] = 0.f; ypad[i] = 0.f; }
     __syncthreads();
-    for (int i = tid; i < N; i += nthr) {
-        const int w = i % W, h = (i / W) % H, d = i / HW;
-        xpad[((d + 1) * Hp + h + 1) * Wp + w + 1] = src[i];
+    if (g.vec_load) {
+        for (int i4 = tid; i4 < (N >> 2); i4 += nthr) {
+            const int i = i4 << 2, w = i % W, r = i / W, h = r % H, d = r / H;
+            const xt_f4 v = reinterpret_cast<const xt_f4*>(src)[i4];
+            float* o = xpad + ((d + 1) * Hp + h + 1) * Wp + w + 1;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        }
+    } else {
+        for (int i = tid; i < N; i += nthr) {
+            const int w = i % W, h = (i / W) % H, d = i / HW;
+            xpad[((d + 1) * Hp + h + 1) * Wp + w + 1] = src[i];
+        }
     }
     __syncthreads();
     XT_LAP(1);
-    // ---- ResidualBlock(1): y = relu(conv3(x) + b1) ------------------------------------------------------------------------------
-    for (int i = tid; i < N; i += nthr) {
-        const int w = i % W, h = (i / W) % H, d = i / HW;
-        const int pi = (d * Hp + h) * Wp + w;          // index of tap (0,0,0) in the padded grid
-        float acc = wt[XT_A1 + 27];
-#pragma unroll
-        for (int kd = 0; kd < 3; kd++)
-#pragma unroll
-            for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) acc += wt[XT_A1 + (kd * 3 + kh) * 3 + kw] * xpad[pi + (kd * Hp + kh) * Wp + kw];
-        ypad[pi + (Hp + 1) * Wp + 1] = fmaxf(acc, 0.f);
-    }
+    // ---- ResidualBlock(1): y = relu(conv3(x) + b1), then a = relu(conv3(y) + b2 + x) over x ------------------------------------------------
+    if (g.strip == 4) xt_conv1_strips<4, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
+    else xt_conv1_strips<3, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(2);
-    // a = relu(conv3(y) + b2 + x)
-    for (int i = tid; i < N; i += nthr) {
-        const int w = i % W, h = (i / W) % H, d = i / HW;
-        const int pi = (d * Hp + h) * Wp + w;
-        float acc = wt[XT_A2 + 27];
-#pragma unroll
-        for (int kd = 0; kd < 3; kd++)
-#pragma unroll
-            for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) acc += wt[XT_A2 + (kd * 3 + kh) * 3 + kw] * ypad[pi + (kd * Hp + kh) * Wp + kw];
-        bufX[i] = fmaxf(acc + xpad[pi + (Hp + 1) * Wp + 1], 0.f);
-    }
+    if (g.strip == 4) xt_conv1_strips<4, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    else xt_conv1_strips<3, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(3);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
     for (int i = tid; i < ncellB; i += nthr) {
         const int wz = i % ow, hz = (i / ow) % oh, dz = i / (ow * oh);
+        const float* ap = xpad + (dz * g.sd * Hp + hz * g.sh) * Wp + wz * g.sw;          // tap (0, 0, 0): the grid's halo is the convolution's padding
         xt_f2 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) acc[k] = reinterpret_cast<const xt_f2*>(wt + XT_AL1 + 1000)[k];
+#pragma unroll 1
         for (int kd = 0; kd < 5; kd++) {
-            const int dd = dz * g.sd + kd - 1;
-            if ((unsigned)dd >= (unsigned)D) continue;
+#pragma unroll 1
             for (int kh = 0; kh < 5; kh++) {
-                const int hh = hz * g.sh + kh - 1;
-                if ((unsigned)hh >= (unsigned)H) continue;
+                const float* row = ap + (kd * Hp + kh) * Wp;
 #pragma unroll
                 for (int kw = 0; kw < 5; kw++) {
-                    const int ww = wz * g.sw + kw - 1;
-                    const bool in = (unsigned)ww < (unsigned)W;
-                    const float v = in ? bufX[(dd * H + hh) * W + (in ? ww : 0)] : 0.f;
+                    const float v = row[kw];
                     const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XT_AL1 + ((kd * 5 + kh) * 5 + kw) * 8);
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc[k] += wk[k] * v;
@@ -162,7 +209,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int co = 0; co < 7; co++) bufB[co * ncellB + i] = acc[co >> 1][co & 1];
+        for (int co = 0; co < 7; co++) bufB[i * 7 + co] = acc[co >> 1][co & 1];
     }
     __syncthreads();
     XT_LAP(4);
@@ -183,19 +230,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         const int w = i % we1, h = (i / we1) % he1;
         if (h > oh || w > ow) {
 #pragma unroll
-            for (int co = 0; co < 7; co++) bufC1[co * ncellC1 + i] = fmaxf(wt[XT_C1 + 1512 + co], 0.f);
+            for (int co = 0; co < 7; co++) bufC1[i * 7 + co] = fmaxf(wt[XT_C1 + 4096 + co], 0.f);
         }
     }
-    const int lane = tid & 63, nw = nthr >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pn = lane & 15, q = lane >> 4;             // B operand: cell pair pn, input column offset q; D: rows 4q .. 4q + 3 of pair pn
-    const int dwv = q >> 1, co0 = 4 * (q & 1);           // D rows -> output column 2p + dwv, channels co0 .. co0 + 3
     const int cbase = (int)(bufC1 - xt_smem);
     {
-        float wA[63];
-        xt_load_wA(wt + XT_C1, lane, wA);
         float bias[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 1512 + co0 + i];
+        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 4096 + co0 + i];
         const int hc = oh + 1, wc = ow + 1, ppr = (wc + 1) >> 1, npair = hc * ppr, T = (npair + 15) >> 4;
         for (int g = wv; g < 3 * T; g += nw) {          // (slices dealt round-robin: a wave's tiles mix the 42- and the 63-instruction kind)
             const int d = g % 3, t = g / 3;
@@ -204,32 +246,41 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)ow;
-            const int base = (d * oh + h) * ow + col;
+            // the nine (kd, kh) tap rows of this lane: float index of channel 0 (the channels of a cell are neighbours: immediate offsets), or
+            // the zero words where the row or the column falls outside — computed once per tile, no vector work between the instructions
+            const int base = ((d * oh + h) * ow + col) * 7;
+            int am[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) am[kh] = cv && (unsigned)(h + kh - 1) < (unsigned)oh ? base + (kh - 1) * ow * 7 : -1;
             xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
+#if XT_EXP == 3
+            xt_f4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int kd = 0; kd < 3; kd++) {
                 const int dd = d + kd - 1;
                 if ((unsigned)dd >= (unsigned)od) continue;          // (d >= od: standard padding; d < 0 or >= 3: the convolution's own) — wave-uniform
+                const int koff = (kd - 1) * oh * ow * 7;
 #pragma unroll
                 for (int kh = 0; kh < 3; kh++) {
-                    const bool m = cv && (unsigned)(h + kh - 1) < (unsigned)oh;
-                    int a = m ? base + ((kd - 1) * oh + (kh - 1)) * ow : zidx;
-                    const int st = m ? ncellB : 0;
+                    const int a = am[kh] >= 0 ? am[kh] + koff : zidx;
 #pragma unroll
-                    for (int ci = 0; ci < 7; ci++) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a], acc, 0, 0, 0);
-                        a += st;
-                    }
+                    for (int ci = 0; ci < 7; ci++)
+                        XT_STEP(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci]);
                 }
             }
+#if XT_EXP == 3
+            acc += acc2;
+#endif
             const int w = 2 * p + dwv;
             if (lv && w < wc) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (co0 + i < 7) bufC1[(co0 + i) * ncellC1 + (d * he1 + h) * we1 + w] = fmaxf(acc[i], 0.f);
+                    if (co0 + i < 7) bufC1[((d * he1 + h) * we1 + w) * 7 + co0 + i] = fmaxf(acc[i], 0.f);
             }
         }
     }
+    xt_load_wA(wt + XT_C2, lane, wA);                 // (before the barrier: a wave that is done fetches while the others finish)
     __syncthreads();
     XT_LAP(5);
     // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
@@ -238,11 +289,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     const int cols = g.cols;
     float* redw = red + wv * cols * 3;
     {
-        float wA[63];
-        xt_load_wA(wt + XT_C2, lane, wA);
         float bias[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 1512 + co0 + i];
+        for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 4096 + co0 + i];
         const int ppr = (cols + 1) >> 1, npair = (oh + 2) * ppr, T = (npair + 15) >> 4;
         for (int g2 = wv; g2 < 3 * T; g2 += nw) {
             const int d = g2 % 3, t = g2 / 3;
@@ -251,36 +300,49 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)we1;
-            const int base = cbase + (d * he1 + h) * we1 + col;
+            const int base = cbase + ((d * he1 + h) * we1 + col) * 7;
+            int am[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) am[kh] = cv && h + kh - 1 >= 0 ? base + (kh - 1) * we1 * 7 : -1;          // (h + kh - 1 <= oh + 2 < he1: always stored)
+            // what the epilogue needs, fetched before the instructions run: the residual of the lane's four cells and their 12 align2 weights
+            const int w = 2 * p + dwv;
+            const bool ov = lv && w < cols;
+            const bool inb = ov && d < od && h < oh && w < ow;
+            const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
+            const xt_f4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2];          // [channel co0 .. co0 + 3][kw]
+            const float* __restrict__ pb = inb ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
+            float pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? pb[i] : 0.f;
             xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
+#if XT_EXP == 3
+            xt_f4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int kd = 0; kd < 3; kd++) {
                 const int dd = d + kd - 1;
                 if ((unsigned)dd >= 3u) continue;
+                const int koff = (kd - 1) * he1 * we1 * 7;
 #pragma unroll
                 for (int kh = 0; kh < 3; kh++) {
-                    const bool m = cv && h + kh - 1 >= 0;          // (h + kh - 1 <= oh + 2 < he1: always stored)
-                    int a = m ? base + ((kd - 1) * he1 + (kh - 1)) * we1 : zidx;
-                    const int st = m ? ncellC1 : 0;
+                    const int a = am[kh] >= 0 ? am[kh] + koff : zidx;
 #pragma unroll
-                    for (int ci = 0; ci < 7; ci++) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a], acc, 0, 0, 0);
-                        a += st;
-                    }
+                    for (int ci = 0; ci < 7; ci++)
+                        XT_STEP(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci]);
                 }
             }
-            const int w = 2 * p + dwv;
-            const bool ov = lv && w < cols;
-            const bool inb = ov && d < od && h < oh && w < ow;
-            const int cellb = inb ? (d * oh + h) * ow + w : 0;
+#if XT_EXP == 3
+            acc += acc2;
+#endif
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            if (ov) {
+                const float wl[12] = {wk0[0], wk0[1], wk0[2], wk0[3], wk1[0], wk1[1], wk1[2], wk1[3], wk2[0], wk2[1], wk2[2], wk2[3]};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (co0 + i < 7 && ov) {
-                    const float pv = inb ? bufB[(co0 + i) * ncellB + cellb] : 0.f;
-                    const float c = fmaxf(acc[i] + pv, 0.f);
-                    const float* __restrict__ wk = wt + XT_AL2 + (((co0 + i) * 3 + d) * 64 + h) * 3;
-                    s0 += wk[0] * c; s1 += wk[1] * c; s2 += wk[2] * c;
+                for (int i = 0; i < 4; i++) {
+                    if (co0 + i < 7) {
+                        const float c = fmaxf(acc[i] + pv[i], 0.f);
+                        s0 += wl[i * 3 + 0] * c; s1 += wl[i * 3 + 1] * c; s2 += wl[i * 3 + 2] * c;
+                    }
                 }
             }
             s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cell
@@ -297,7 +359,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     XT_LAP(6);
     if (tid < 64) {
         const int w = tid;
-        float v = wt[XT_KV + w];
+        float v = kv;
         for (int k = 0; k < nw; k++) {                 // fixed order
             if (w < cols) v += red[(k * cols + w) * 3 + 1];
             if (w >= 1 && w - 1 < cols) v += red[(k * cols + w - 1) * 3 + 0];
@@ -436,14 +498,14 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
     static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
     const int64_t Np = (int64_t)(D + 2) * (H + 2) * (W + 2);
-    int64_t c1_alloc = nC1;                                   // floats behind b: the first activation of the 7-channel block, or more (below)
-    if (2 * Np + N <= nC1) g.pad_in_b = 0;
-    else if (Np <= nB && Np + N <= nC1) g.pad_in_b = 1;
-    else { g.pad_in_b = 0; c1_alloc = 2 * Np + N; }           // a narrow grid (e.g. 7 x 34 x 9): the 1-channel block's padded copies need more than the
-                                                              // 7-channel stages — the allocation simply grows (it is small anyway)
+    g.y_in_b = Np <= nB;
+    const int64_t c1_alloc = nC1 > (g.y_in_b ? Np : 2 * Np) ? nC1 : (g.y_in_b ? Np : 2 * Np);      // floats behind b: the first activation of the 7-channel block, or
+                                                                                               // the 1-channel block's grids where they need more (narrow regions)
+    g.strip = W % 4 == 0 ? 4 : 3;
+    g.vec_load = (W % 4 == 0) && (head_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(head_dev) % 16 == 0);
     if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
     g.tail = (int)(nB + c1_alloc);
-    const size_t lds = (size_t)(nB + c1_alloc + 4 + (threads / 64) * g.cols * 3) * sizeof(float);
+    const size_t lds = (size_t)(nB + c1_alloc + 8 + (threads / 64) * g.cols * 3) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
     const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
                    : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512>);
