@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 256 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / v_pk_fma_f32, 256 FLOP per clock and CU
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 STAGGER_SEED = 0x5EED5EED
 
@@ -781,13 +782,23 @@ def extras_leg(args, regions, dev, batch, obs):
         ex["config1_game_step"] = {"error": str(exn)}
     try:
         a2 = copy.copy(args)
-        a2.agent, a2.agent_full_obs, a2.steps, a2.warmup = "dqn", False, 5, 3
+        a2.agent, a2.agent_full_obs, a2.steps, a2.warmup = "dqn", False, 20, 3
         r = agent_leg(a2, regions[:1024], dev, 1)
-        ex["config3_dqn_attached"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step")}
+        ex["config3_dqn_attached"] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step")}
         ex["config3_dqn_attached"]["what"] = r["config"]["workload"]
     except Exception as exn:
         ex["config3_dqn_attached"] = {"error": str(exn)}
     return ex
+
+
+def tower_macs(dims):
+    """Multiply-adds of the obstacle tower on one (D, H, W) grid as the reference computes it on the cells the data can influence
+    (baseline/baseline_utils.py:231-379): ResidualBlock(1) 2 x 27 per cell, the aligning 5x5x5 convolution 125 x 7 per output cell,
+    ResidualBlock(7) 2 x 27 x 49 per cell of its two activations, the (3, 64, 3) convolution 21 per cell."""
+    from xroute_env_amd import agents
+    D, H, W = dims
+    od, oh, ow = [(s + 2 - 5) // k + 1 for s, k in zip((D, H, W), agents.align_stride((D, H, W)))]
+    return 2 * 27 * D * H * W + 875 * od * oh * ow + 1323 * 3 * ((oh + 1) * (ow + 1) + (oh + 2) * (ow + 2)) + 21 * 3 * (oh + 2) * (ow + 2)
 
 
 def agent_leg(args, regions, dev, world):
@@ -864,6 +875,21 @@ def agent_leg(args, regions, dev, world):
     N = float(sum(regions[e % len(regions)].n_nodes for e in range(B))) / B
     kfloat = float(batch.fetch("nlegal").double().mean().item())
     env_bytes = B * (4.0 * N + (4.0 * N * (2 + 7 * kfloat) if full else 8.0 * N))
+    tower_roof = None
+    if tower is not None and tower.supported:       # the agent's dominant kernel alone, priced against the fp32 matrix (= vector) peak
+        tev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(3):
+            tower(buf)
+        tev[0].record()
+        for _ in range(10):
+            tower(buf)
+        tev[1].record()
+        torch.cuda.synchronize(dev)
+        tms = tev[0].elapsed_time(tev[1]) / 10
+        fl = 2.0 * B * tower_macs((dims[2], dims[1], dims[0]))
+        tower_roof = {"kernel": "xr_ob_tower_kernel (7 -> 7 convolutions on v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": round(fl / (tms * 1e-3) / 1e12, 2),
+                      "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (tms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                      "avg_launch_ms": round(tms, 4), "ms_per_1024_envs": round(tms * 1024 / B, 4), "algorithmic_flops_per_launch": int(fl)}
     return {"metric": f"env-steps/sec, {args.agent.upper()} counterpart attached (batched regions), ispd18_test1-sized regions",
             "value": round(real / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -880,7 +906,7 @@ def agent_leg(args, regions, dev, world):
             "obstacle_tower": ("fused HIP kernel per grid shape (agents.GroupedFusedPolicy)" if mixed else
                                "framework convolutions" if tower is None or not tower.supported else "fused HIP kernel (xr_agent_obstacle_tower)"),
             "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(env_ms, 4),
-            "net_grids_through_the_tower": cache.computed,
+            "net_grids_through_the_tower": cache.computed, "tower_roofline": tower_roof,
             "roofline": {"kernel": "xr_route_kernel (+ planes 0..1)" if not full else "xr_step_queue_kernel", "bound": "hbm",
                          "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
