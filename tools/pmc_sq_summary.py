@@ -7,7 +7,7 @@ waves_pass = collections.defaultdict(dict)
 for p in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True)):
     ps = p[len(out):].strip("/").split("/")[0]
     for r in csv.DictReader(open(p)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0] if "(anonymous namespace)::" not in r["Kernel_Name"] else r["Kernel_Name"].split("(anonymous namespace)::")[1].split("(")[0]
         c = r["Counter_Name"]
         if c == "SQ_WAVES":
             waves_pass[k][ps] = waves_pass[k].get(ps, 0.0) + float(r["Counter_Value"])
