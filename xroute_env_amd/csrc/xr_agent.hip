@@ -36,7 +36,7 @@ struct XtDims {
     int od, oh, ow;       // its output
     int cols;             // columns of the last stage: ow + 2
     int y_in_b;           // the 1-channel block's intermediate lives in b's LDS space (else behind x in the first activation's space, which then grows)
-    int strip;            // cells per thread of the 1-channel convolutions: 4 where the rows are whole strips, else 3
+    int strip;            // cells per thread of the 1-channel convolutions: 3 or 5, whichever takes fewer instructions over all passes
     int vec_load;         // rows of x are multiples of 16 bytes at 16-byte aligned addresses: four cells per load
     int tail;             // floats of b + the first activation's allocation: behind them a zero word (+3 pad) and the waves' column sums [nw][cols][3]
 };
@@ -64,22 +64,22 @@ __device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lan
     }
 }
 
-// One 3x3x3 convolution of the 1-channel block on zero-padded grids [D + 2][H + 2][W + 2]: a thread takes S neighbouring cells of a row, per
-// tap row S + 2 LDS reads feed 3 S FMAs (one cell per thread: 27 reads for 27 FMAs, and the index arithmetic once per cell).  Every cell's sum
-// runs in the order (kd, kh, kw).  Measured on a 24x40x9 region, cycles of the two convolutions: S = 1: 17.1 + 17.9 k, 2: 17.5 + 18.2 k,
-// 3: 19.8 + 21.1 k, 4: 14.0 + 14.9 k (profiles/r04_strip_tower_1ch_strips.txt); on 25x34x9 (rows of 25: the seventh strip holds one cell) the
-// whole kernel takes 0.294 ms per 1024 envs with S = 3 and 0.306 with S = 4: S = 4 where the rows are whole strips, else 3.  RES: out is the INPUT of the block (x) and holds x at the cell: out = relu(conv + x), in place.
-// (A strip may hang over the end of its row: those reads hit the next row or the floats behind the grid — inside the allocation — and feed
-//  only sums that are dropped.)
+// One 3x3x3 convolution of the 1-channel block on zero-padded grids [D + 2][H + 2][Wp] (Wp = W + 2 rounded up to an ODD number of words): a thread
+// takes S neighbouring cells of a row — per tap row S + 2 LDS reads feed 3 S FMAs (one cell per thread: 27 reads for 27 FMAs, and the index arithmetic
+// once per cell) — and consecutive lanes take the same strip of consecutive ROWS: their addresses are an odd pitch apart, every read of a wave
+// touches every bank once.  (With consecutive lanes along a row — strips four words apart — the reads were 4-way bank conflicts: half of the kernel's
+// LDS cycles, profiles/r04_pt_tower_sq_counters.txt.)  Every cell's sum runs in the order (kd, kh, kw).  RES: out is the INPUT of the block (x) and
+// holds x at the cell: out = relu(conv + x), in place.  (A strip may hang over the end of its row: those reads hit the next row or the floats behind
+// the grid — inside the allocation — and feed only sums that are dropped.)
 template <int S, bool RES>
 __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, const float* in, float* out, int D, int H, int W, int tid, int nthr) {
-    const int Hp = H + 2, Wp = W + 2, spr = (W + S - 1) / S, nstrip = D * H * spr;
+    const int Hp = H + 2, Wp = (W + 2) | 1, rows = D * H, nstrip = rows * ((W + S - 1) / S);
     float wk[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) wk[k] = wgt[k];
     const float bias = wgt[27];
     for (int i = tid; i < nstrip; i += nthr) {
-        const int sx = i % spr, r = i / spr, h = r % H, d = r / H, w0 = sx * S;
+        const int sx = i / rows, r = i - sx * rows, h = r % H, d = r / H, w0 = sx * S;
         const int pi = (d * Hp + h) * Wp + w0;                 // tap (0, 0, 0) of the strip's first cell
         float acc[S];
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     // instructions per FMA.  x sits in the first activation's space and becomes a = block(x) IN PLACE (the residual is the cell's own x, read by the
     // thread that writes a there): the aligning convolution then reads a padded grid too; the intermediate y sits in b's space (dead before b is
     // written) or, where that is too small (narrow grids), behind x.
-    const int Hp = H + 2, Wp = W + 2, Np = (D + 2) * Hp * Wp;
+    const int Hp = H + 2, Wp = (W + 2) | 1, Np = (D + 2) * Hp * Wp;          // (an odd row pitch: see xt_conv1_strips)
     float* xpad = bufC1;
     float* ypad = g.y_in_b ? bufB : bufC1 + Np;
 
@@ -178,11 +178,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     __syncthreads();
     XT_LAP(1);
     // ---- ResidualBlock(1): y = relu(conv3(x) + b1), then a = relu(conv3(y) + b2 + x) over x ------------------------------------------------
-    if (g.strip == 4) xt_conv1_strips<4, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
+    if (g.strip == 5) xt_conv1_strips<5, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     else xt_conv1_strips<3, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(2);
-    if (g.strip == 4) xt_conv1_strips<4, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    if (g.strip == 5) xt_conv1_strips<5, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
     else xt_conv1_strips<3, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(3);
@@ -497,11 +497,15 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     g.cols = g.ow + 2;
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
     static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
-    const int64_t Np = (int64_t)(D + 2) * (H + 2) * (W + 2);
+    const int64_t Np = (int64_t)(D + 2) * (H + 2) * ((W + 2) | 1);
     g.y_in_b = Np <= nB;
     const int64_t c1_alloc = nC1 > (g.y_in_b ? Np : 2 * Np) ? nC1 : (g.y_in_b ? Np : 2 * Np);      // floats behind b: the first activation of the 7-channel block, or
                                                                                                // the 1-channel block's grids where they need more (narrow regions)
-    g.strip = W % 4 == 0 ? 4 : 3;
+    {   // cells per thread of the 1-channel convolutions: 9 (S + 2) reads + 27 S FMAs + ~25 index instructions per strip, times the passes
+        auto cost = [&](int S) { const int64_t strips = (int64_t)D * H * ((W + S - 1) / S); return ((strips + threads - 1) / threads) * (36 * S + 43); };
+        g.strip = cost(5) < cost(3) ? 5 : 3;
+        if (const char* v = getenv("XR_TOWER_STRIP")) { const int S = atoi(v); if (S == 3 || S == 5) g.strip = S; }      // (A/B)
+    }
     g.vec_load = (W % 4 == 0) && (head_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(head_dev) % 16 == 0);
     if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
     g.tail = (int)(nB + c1_alloc);
