@@ -18,3 +18,4 @@ for P in "$P1" "$P2" "$P3"; do
 done
 python3 $R/tools/pmc_sq_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+rm -rf $OUT/p1 $OUT/p2 $OUT/p3          # (the raw traces exceed what gpurun copies back)

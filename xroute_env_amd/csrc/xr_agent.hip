@@ -26,9 +26,6 @@ namespace {
 
 typedef float xt_f2 __attribute__((ext_vector_type(2)));     // pairs of output channels: v_pk_fma_f32
 typedef float xt_f4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_16x16x4_f32
-#ifndef XT_EXP
-#define XT_EXP 0
-#endif
 
 struct XtDims {
     int D, H, W;          // input grid
@@ -113,16 +110,6 @@ __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, c
 #define XT_LAP(k) do { } while (0)
 #endif
 
-#if XT_EXP == 1        // timing experiment: the matrix pipe alone (no LDS reads)
-#define XT_STEP(wa, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, (float)a, acc, 0, 0, 0)
-#elif XT_EXP == 2      // timing experiment: the LDS reads alone
-#define XT_STEP(wa, bv) acc[0] += (bv) * (wa)
-#elif XT_EXP == 3      // timing experiment: two accumulators, alternating
-#define XT_STEP(wa, bv) do { if (ci & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc2, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc, 0, 0, 0); } while (0)
-#else
-#define XT_STEP(wa, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, bv, acc, 0, 0, 0)
-#endif
-
 template <int BT>
 __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
                                                           const float* __restrict__ wt, float* __restrict__ out, int normalize) {
@@ -151,9 +138,6 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     const int lane = tid & 63, nw = nthr >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pn = lane & 15, q = lane >> 4;             // (7-channel block) B operand: cell pair pn, input column offset q; D: rows 4q .. 4q + 3 of pair pn
     const int dwv = q >> 1, co0 = 4 * (q & 1);           // D rows -> output column 2p + dwv, channels co0 .. co0 + 3
-    // the A operand of the 7-channel block's first convolution: 63 gathers per lane, issued here so that the 1-channel stages hide them
-    float wA[64];
-    xt_load_wA(wt + XT_C1, lane, wA);
     const float kv = wt[XT_KV + lane];                // (what the last stage starts from: fetched here, not behind the last barrier)
     const int zidx = g.tail;                          // seven words that stay 0: what a tap outside the data reads (one per channel)
     float* red = xt_smem + g.tail + 8;                // [nthr / 64][cols][3]: every wave's column sums of the last stage
@@ -186,10 +170,16 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     else xt_conv1_strips<3, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(3);
+    // the A operand of the 7-channel block's first convolution: 16 loads per lane, issued here so that the aligning convolution hides them
+    // (it fetches nothing through the vector memory path; earlier, the 64 registers would squeeze the 1-channel stages)
+    float wA[64];
+    xt_load_wA(wt + XT_C1, lane, wA);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
-    for (int i = tid; i < ncellB; i += nthr) {
-        const int wz = i % ow, hz = (i / ow) % oh, dz = i / (ow * oh);
+    // (consecutive lanes take consecutive ROWS of one column: their reads are an odd pitch apart — along a row of ow < 32 cells a wave's read spans
+    //  several rows whose words share banks: 2-way conflicts on every one of the 125 reads)
+    for (int q = tid; q < ncellB; q += nthr) {
+        const int hz = q % oh, wz = (q / oh) % ow, dz = q / (ow * oh), i = (dz * oh + hz) * ow + wz;
         const float* ap = xpad + (dz * g.sd * Hp + hz * g.sh) * Wp + wz * g.sw;          // tap (0, 0, 0): the grid's halo is the convolution's padding
         xt_f2 acc[4];
 #pragma unroll
@@ -234,49 +224,56 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
     }
     const int cbase = (int)(bufC1 - xt_smem);
+    // A wave takes ALL THREE depth slices of its tiles: the lane geometry (two integer divisions, nine tap-row addresses) is computed once per
+    // three tiles and the addresses step from slice to slice by one add each — vector instructions and matrix instructions do not overlap
+    // on a SIMD (stage time = 32 cycles per matrix instruction + 4 per vector instruction, measured), so every one saved counts.
     {
         float bias[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 4096 + co0 + i];
         const int hc = oh + 1, wc = ow + 1, ppr = (wc + 1) >> 1, npair = hc * ppr, T = (npair + 15) >> 4;
-        for (int g = wv; g < 3 * T; g += nw) {          // (slices dealt round-robin: a wave's tiles mix the 42- and the 63-instruction kind)
-            const int d = g % 3, t = g / 3;
+        const int slice = oh * ow * 7;
+        for (int t = wv; t < T; t += nw) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)ow;
-            // the nine (kd, kh) tap rows of this lane: float index of channel 0 (the channels of a cell are neighbours: immediate offsets), or
-            // the zero words where the row or the column falls outside — computed once per tile, no vector work between the instructions
-            const int base = ((d * oh + h) * ow + col) * 7;
-            int am[3];
+            // the three kh tap rows of this lane in slice 0: float index of channel 0 (the channels of a cell are neighbours: immediate offsets),
+            // or the zero words where the row or the column falls outside; ds: what moves a row to the next slice (0 for the zero words)
+            const int base0 = (h * ow + col) * 7;
+            int am[3], ds[3];
 #pragma unroll
-            for (int kh = 0; kh < 3; kh++) am[kh] = cv && (unsigned)(h + kh - 1) < (unsigned)oh ? base + (kh - 1) * ow * 7 : -1;
-            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
-#if XT_EXP == 3
-            xt_f4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#endif
-#pragma unroll
-            for (int kd = 0; kd < 3; kd++) {
-                const int dd = d + kd - 1;
-                if ((unsigned)dd >= (unsigned)od) continue;          // (d >= od: standard padding; d < 0 or >= 3: the convolution's own) — wave-uniform
-                const int koff = (kd - 1) * oh * ow * 7;
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++) {
-                    const int a = am[kh] >= 0 ? am[kh] + koff : zidx;
-#pragma unroll
-                    for (int ci = 0; ci < 7; ci++)
-                        XT_STEP(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci]);
-                }
+            for (int kh = 0; kh < 3; kh++) {
+                const bool m = cv && (unsigned)(h + kh - 1) < (unsigned)oh;
+                ds[kh] = m ? slice : 0;
+                am[kh] = m ? base0 + (kh - 1) * ow * 7 : zidx;
             }
-#if XT_EXP == 3
-            acc += acc2;
-#endif
             const int w = 2 * p + dwv;
-            if (lv && w < wc) {
+            const bool st = lv && w < wc;
+            float* o = bufC1 + (h * we1 + w) * 7 + co0;
+#pragma unroll 1
+            for (int d = 0; d < 3; d++) {
+                xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (co0 + i < 7) bufC1[((d * he1 + h) * we1 + w) * 7 + co0 + i] = fmaxf(acc[i], 0.f);
+                for (int kd = 0; kd < 3; kd++) {
+                    const int dd = d + kd - 1;
+                    if ((unsigned)dd >= (unsigned)od) continue;       // (d >= od: standard padding; d < 0 or >= 3: the convolution's own) — wave-uniform
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) {
+                        const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
+#pragma unroll
+                        for (int ci = 0; ci < 7; ci++)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
+                    }
+                }
+                if (st) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = fmaxf(acc[i], 0.f);
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
             }
         }
     }
@@ -293,59 +290,61 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 4096 + co0 + i];
         const int ppr = (cols + 1) >> 1, npair = (oh + 2) * ppr, T = (npair + 15) >> 4;
-        for (int g2 = wv; g2 < 3 * T; g2 += nw) {
-            const int d = g2 % 3, t = g2 / 3;
+        const int slice = he1 * we1 * 7;
+        for (int t = wv; t < T; t += nw) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)we1;
-            const int base = cbase + ((d * he1 + h) * we1 + col) * 7;
-            int am[3];
+            const int base0 = cbase + (h * we1 + col) * 7;
+            int am[3], ds[3];
 #pragma unroll
-            for (int kh = 0; kh < 3; kh++) am[kh] = cv && h + kh - 1 >= 0 ? base + (kh - 1) * we1 * 7 : -1;          // (h + kh - 1 <= oh + 2 < he1: always stored)
-            // what the epilogue needs, fetched before the instructions run: the residual of the lane's four cells and their 12 align2 weights
+            for (int kh = 0; kh < 3; kh++) {
+                const bool m = cv && h + kh - 1 >= 0;                  // (h + kh - 1 <= oh + 2 < he1: always stored)
+                ds[kh] = m ? slice : 0;
+                am[kh] = m ? base0 + (kh - 1) * we1 * 7 : zidx;
+            }
             const int w = 2 * p + dwv;
             const bool ov = lv && w < cols;
-            const bool inb = ov && d < od && h < oh && w < ow;
-            const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
-            const xt_f4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2];          // [channel co0 .. co0 + 3][kw]
-            const float* __restrict__ pb = inb ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
-            float pv[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? pb[i] : 0.f;
-            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
-#if XT_EXP == 3
-            xt_f4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#endif
-#pragma unroll
-            for (int kd = 0; kd < 3; kd++) {
-                const int dd = d + kd - 1;
-                if ((unsigned)dd >= 3u) continue;
-                const int koff = (kd - 1) * he1 * we1 * 7;
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++) {
-                    const int a = am[kh] >= 0 ? am[kh] + koff : zidx;
-#pragma unroll
-                    for (int ci = 0; ci < 7; ci++)
-                        XT_STEP(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci]);
-                }
-            }
-#if XT_EXP == 3
-            acc += acc2;
-#endif
+            const bool inhw = ov && h < oh && w < ow;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            if (ov) {
-                const float wl[12] = {wk0[0], wk0[1], wk0[2], wk0[3], wk1[0], wk1[1], wk1[2], wk1[3], wk2[0], wk2[1], wk2[2], wk2[3]};
+#pragma unroll 1
+            for (int d = 0; d < 3; d++) {
+                // what the epilogue needs, fetched before the instructions run: the residual of the lane's four cells and their 12 align2 weights
+                const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
+                const xt_f4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2];          // [channel co0 .. co0 + 3][kw]
+                const float* __restrict__ pb = (inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
+                float pv[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (co0 + i < 7) {
-                        const float c = fmaxf(acc[i] + pv[i], 0.f);
-                        s0 += wl[i * 3 + 0] * c; s1 += wl[i * 3 + 1] * c; s2 += wl[i * 3 + 2] * c;
+                for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? pb[i] : 0.f;
+                xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+                for (int kd = 0; kd < 3; kd++) {
+                    const int dd = d + kd - 1;
+                    if ((unsigned)dd >= 3u) continue;                 // wave-uniform
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) {
+                        const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
+#pragma unroll
+                        for (int ci = 0; ci < 7; ci++)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
                     }
                 }
+                if (ov) {
+                    const float wl[12] = {wk0[0], wk0[1], wk0[2], wk0[3], wk1[0], wk1[1], wk1[2], wk1[3], wk2[0], wk2[1], wk2[2], wk2[3]};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (co0 + i < 7) {
+                            const float c = fmaxf(acc[i] + pv[i], 0.f);
+                            s0 += wl[i * 3 + 0] * c; s1 += wl[i * 3 + 1] * c; s2 += wl[i * 3 + 2] * c;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
             }
-            s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cell
+            s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cells
             // the tile's pairs lie in rows h0 .. h1: one row at a time, so that the lanes of a pass own distinct columns
             const int h0 = (t * 16) / ppr, h1 = min(t * 16 + 15, npair - 1) / ppr;
             for (int r = h0; r <= h1; r++) {
