@@ -356,7 +356,8 @@ int32_t xr_observation_from_records(const uint32_t* nodes_dev, int32_t dim_x, in
  * ob_conv2 -> ob_align_conv2, what its DQN / PPO agents run on plane 0 of every observation before choosing a net) as one fused
  * kernel, eval mode: head_dev fp32 [n_envs][head_stride] with plane 0 of every env first (the buffers of xr_batch_step_compact /
  * xr_batch_step_observe), (D, H, W) = the observation tensor's trailing dims (dim_z, dim_y, dim_x), weights_dev =
- * xr_agent_obstacle_tower_weights() floats packed by xroute_env_amd/agents.py (BatchNorm folded), out_dev fp32 [n_envs][64]
+ * xr_agent_obstacle_tower_weights() floats packed by xroute_env_amd/agents.py FusedObstacleTower.refresh (BatchNorm folded; the two 7 -> 7-channel
+ * convolutions as the per-lane A operands of the kernel's v_mfma_f32_16x16x4_f32 steps: csrc/xr_agent.hip XT_* offsets), out_dev fp32 [n_envs][64]
  * (normalize != 0: after the reference's row-wise min-max normalisation, baseline/baseline_utils.py:45-63).  XR_ERR_RANGE: a grid shape the kernel does not take (use the framework path). */
 int32_t xr_agent_obstacle_tower_weights(void);
 int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int32_t n_envs, int32_t dim_d, int32_t dim_h, int32_t dim_w,
