@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     float* ypad = g.y_in_b ? bufB : bufC1 + Np;
 
 #ifdef XT_PHASE_TIMING
-    unsigned long long xt_lap[9];
+    unsigned long long xt_lap[12];
 #endif
     XT_LAP(0);
     const int lane = tid & 63, nw = nthr >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
     }
     const int cbase = (int)(bufC1 - xt_smem);
+    XT_LAP(8);                                         // (timing build: wave 0 after the fill loop / after its own tiles / at the barrier)
     // A wave takes ALL THREE depth slices of its tiles: the lane geometry (two integer divisions, nine tap-row addresses) is computed once per
     // three tiles and the addresses step from slice to slice by one add each — vector instructions and matrix instructions do not overlap
     // on a SIMD (stage time = 32 cycles per matrix instruction + 4 per vector instruction, measured), so every one saved counts.
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             }
         }
     }
+    XT_LAP(9);
     xt_load_wA(wt + XT_C2, lane, wA);                 // (before the barrier: a wave that is done fetches while the others finish)
     __syncthreads();
     XT_LAP(5);
@@ -381,7 +383,12 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
 #ifdef XT_PHASE_TIMING
     XT_LAP(7);
-    if (tid == 0) for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
+    if (tid == 0) {
+        for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
+        out[(int64_t)e * 64 + 7] = (float)(xt_lap[8] - xt_lap[4]);          // conv 1 stage: the fill loop
+        out[(int64_t)e * 64 + 8] = (float)(xt_lap[9] - xt_lap[8]);          //               wave 0's own tiles
+        out[(int64_t)e * 64 + 9] = (float)(xt_lap[5] - xt_lap[9]);          //               operand fetch + waiting for the other waves
+    }
 #endif
 }
 
