@@ -281,6 +281,10 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
     XT_LAP(9);
     xt_load_wA(wt + XT_C2, lane, wA);                 // (before the barrier: a wave that is done fetches while the others finish)
+#ifdef XT_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XT_LAP(10);
+#endif
     __syncthreads();
     XT_LAP(5);
     // ---- second convolution + residual + relu on the inside cells (h < oh + 2, w < ow + 2), folded straight into align2's sums ----
@@ -387,7 +391,8 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
         out[(int64_t)e * 64 + 7] = (float)(xt_lap[8] - xt_lap[4]);          // conv 1 stage: the fill loop
         out[(int64_t)e * 64 + 8] = (float)(xt_lap[9] - xt_lap[8]);          //               wave 0's own tiles
-        out[(int64_t)e * 64 + 9] = (float)(xt_lap[5] - xt_lap[9]);          //               operand fetch + waiting for the other waves
+        out[(int64_t)e * 64 + 9] = (float)(xt_lap[10] - xt_lap[9]);         //               the next convolution's operands arrive
+        out[(int64_t)e * 64 + 10] = (float)(xt_lap[5] - xt_lap[10]);        //               waiting for the other waves
     }
 #endif
 }
