@@ -784,7 +784,7 @@ def extras_leg(args, regions, dev, batch, obs):
         a2 = copy.copy(args)
         a2.agent, a2.agent_full_obs, a2.steps, a2.warmup = "dqn", False, 20, 3
         r = agent_leg(a2, regions[:1024], dev, 1)
-        ex["config3_dqn_attached"] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step")}
+        ex["config3_dqn_attached"] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step", "tower_roofline")}
         ex["config3_dqn_attached"]["what"] = r["config"]["workload"]
     except Exception as exn:
         ex["config3_dqn_attached"] = {"error": str(exn)}

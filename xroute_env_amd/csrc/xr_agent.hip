@@ -103,6 +103,21 @@ __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, c
     }
 }
 
+// Which tiles a wave of the matrix stages takes: T tile groups (one group = the three depth slices of 16 cell pairs: 42 + 63 + 42 instructions)
+// dealt round-robin, whole groups — except in a last, partial round: there the waves that would idle take the MIDDLE slice of a group that
+// another wave (on another SIMD) owns, which keeps the outer two.  Item k of wave wv: tile group *t, slices *dm (bit d); false: no more items.
+// (30 groups over 16 waves: the SIMDs carry 1113 / 1113 / 1092 / 1092 instructions instead of 1176 / 1176 / 1029 / 1029.)
+__device__ __forceinline__ bool xt_tile_item(int k, int wv, int nw, int T, int* t, int* dm) {
+    const int J = T / nw, R = T - J * nw;
+    if (k < J) { *t = k * nw + wv; *dm = 7; return true; }
+    if (k > J || R == 0) return false;
+    if (wv < R) { *t = J * nw + wv; *dm = (wv + nw - R < nw && wv >= 2 * R - nw) ? 5 : 7; return true; }
+    const int v = wv - (nw - R);                       // an idle wave: the middle slice of wave v's group
+    if (v < 0) return false;
+    *t = J * nw + v; *dm = 2;
+    return true;
+}
+
 // -DXT_PHASE_TIMING (make ttiming; tools/tower_probe.py with XT_PHASES=1): thread 0's cycle count per stage replaces the first floats of the env's output row
 #ifdef XT_PHASE_TIMING
 #define XT_LAP(k) do { if (tid == 0) xt_lap[k] = __builtin_readcyclecounter(); } while (0)
@@ -235,7 +250,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 4096 + co0 + i];
         const int hc = oh + 1, wc = ow + 1, ppr = (wc + 1) >> 1, npair = hc * ppr, T = (npair + 15) >> 4;
         const int slice = oh * ow * 7;
-        for (int t = wv; t < T; t += nw) {
+        for (int item = 0, t = 0, dm = 0; xt_tile_item(item, wv, nw, T, &t, &dm); item++) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
@@ -256,6 +271,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             float* o = bufC1 + (h * we1 + w) * 7 + co0;
 #pragma unroll 1
             for (int d = 0; d < 3; d++) {
+                if (!((dm >> d) & 1)) {                               // another wave's slice (wave-uniform)
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
+                    continue;
+                }
                 xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
                 for (int kd = 0; kd < 3; kd++) {
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 4096 + co0 + i];
         const int ppr = (cols + 1) >> 1, npair = (oh + 2) * ppr, T = (npair + 15) >> 4;
         const int slice = he1 * we1 * 7;
-        for (int t = wv; t < T; t += nw) {
+        for (int item = 0, t = 0, dm = 0; xt_tile_item(item, wv, nw, T, &t, &dm); item++) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
             const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
@@ -318,6 +338,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 1
             for (int d = 0; d < 3; d++) {
+                if (!((dm >> d) & 1)) {                               // another wave's slice (wave-uniform)
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
+                    continue;
+                }
                 // what the epilogue needs, fetched before the instructions run: the residual of the lane's four cells and their 12 align2 weights
                 const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
                 const xt_f4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2];          // [channel co0 .. co0 + 3][kw]
