@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         }
     }
     const int cbase = (int)(bufC1 - xt_smem);
+#ifdef XT_PHASE_TIMING
+    const unsigned long long xt_w0 = __builtin_readcyclecounter();      // every wave: when it starts / ends its tiles of the first matrix stage
+#endif
     XT_LAP(8);                                         // (timing build: wave 0 after the fill loop / after its own tiles / at the barrier)
     // A wave takes ALL THREE depth slices of its tiles: the lane geometry (two integer divisions, nine tap-row addresses) is computed once per
     // three tiles and the addresses step from slice to slice by one add each — vector instructions and matrix instructions do not overlap
@@ -299,6 +302,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             }
         }
     }
+#ifdef XT_PHASE_TIMING
+    const unsigned long long xt_w1 = __builtin_readcyclecounter();
+#endif
     XT_LAP(9);
     xt_load_wA(wt + XT_C2, lane, wA);                 // (before the barrier: a wave that is done fetches while the others finish)
 #ifdef XT_PHASE_TIMING
@@ -412,6 +418,8 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     }
 #ifdef XT_PHASE_TIMING
     XT_LAP(7);
+    __syncthreads();                                   // (after wave 0 has written the row)
+    if (lane == 0) out[(int64_t)e * 64 + 16 + wv] = (float)(xt_w1 - xt_w0);
     if (tid == 0) {
         for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
         out[(int64_t)e * 64 + 7] = (float)(xt_lap[8] - xt_lap[4]);          // conv 1 stage: the fill loop
