@@ -231,13 +231,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     // every s_load: 3.5x its FMA bound), the activations are one LDS read per instruction.  Lanes whose tap falls outside the data read a
     // zero word instead (a zero WEIGHT would not do: 0 x garbage may be NaN).
     // Only the cells with h <= oh and w <= ow see any data (their taps reach h - 1 < oh, w - 1 < ow); every other stored cell is relu(bias).
-    const int ncellC1 = 3 * he1 * we1;
-    for (int i = tid; i < ncellC1; i += nthr) {
-        const int w = i % we1, h = (i / we1) % he1;
-        if (h > oh || w > ow) {
+    // (the fringe of a slice: its last two rows and the last two columns of the rows above — 2 we1 + 2 (oh + 1) cells, one pass)
+    const int nfr = 2 * we1 + 2 * (oh + 1);
+    for (int i = tid; i < 3 * nfr; i += nthr) {
+        const int d = i / nfr, r = i - d * nfr, r2 = r - 2 * we1;
+        const int h = r2 < 0 ? oh + 1 + r / we1 : r2 >> 1, w = r2 < 0 ? r % we1 : ow + 1 + (r2 & 1);
+        float* o = bufC1 + ((d * he1 + h) * we1 + w) * 7;
 #pragma unroll
-            for (int co = 0; co < 7; co++) bufC1[i * 7 + co] = fmaxf(wt[XT_C1 + 4096 + co], 0.f);
-        }
+        for (int co = 0; co < 7; co++) o[co] = fmaxf(wt[XT_C1 + 4096 + co], 0.f);
     }
     const int cbase = (int)(bufC1 - xt_smem);
 #ifdef XT_PHASE_TIMING
