@@ -13,9 +13,12 @@
 // depend on the env: the caller folds that part (and the bias) into `kvec`, the kernel sums the inside cells only.
 //
 // One workgroup of 1024 threads per env, everything in LDS (b: 7*od*oh*ow floats, the first activation of the 7-channel block:
-// 7*3*(oh+3)*(ow+3) floats; the 1-channel stages live inside the latter's space), weights through scalar loads (every lane of a wave
-// uses the same weight), 7 output channels per thread and cell so that an LDS read feeds 7 FMAs.  fp32 throughout; the sums run in a
-// fixed order (no atomics): same input, same bits.
+// 7*3*(oh+3)*(ow+3) floats, both channel-interleaved; the 1-channel stages live inside that space on zero-padded grids of an odd row pitch).
+// Stages: the 1-channel block on strips of cells (lanes on consecutive rows: no bank conflicts), its output in place of x; the aligning
+// convolution on packed FMAs with its weights through scalar loads (every lane of a wave uses the same weight); the two 7 -> 7-channel
+// convolutions as a paired implicit GEMM on v_mfma_f32_16x16x4_f32 (two output columns per instruction, weights as per-lane A operands
+// in VGPRs); the last convolution accumulated straight from the accumulators.  fp32 throughout; every sum runs in a fixed order (no
+// atomics): same input, same bits.  Stage cycles: `make ttiming` + tools/tower_probe.py (XT_PHASES=1); DESIGN.md §7.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -35,7 +38,7 @@ struct XtDims {
     int y_in_b;           // the 1-channel block's intermediate lives in b's LDS space (else behind x in the first activation's space, which then grows)
     int strip;            // cells per thread of the 1-channel convolutions: 3 or 5, whichever takes fewer instructions over all passes
     int vec_load;         // rows of x are multiples of 16 bytes at 16-byte aligned addresses: four cells per load
-    int tail;             // floats of b + the first activation's allocation: behind them a zero word (+3 pad) and the waves' column sums [nw][cols][3]
+    int tail;             // floats of b + the first activation's allocation: behind them 8 zero words and the waves' column sums [nw][cols + 2][3]
 };
 
 // packed weights (floats), offsets
