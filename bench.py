@@ -397,6 +397,10 @@ def main():
     n_par = min(B, 256 if world == 1 else 32)          # envs of this rank the oracle replays after the run (`parity`)
     acts_log = torch.zeros((max(nsteps_total, 1), n_par), dtype=torch.int32, device=dev)
     last_gather = [None]
+    # N > 1, weak scaling: the gather of step i runs on RCCL's stream WHILE step i + 1 computes — two record / result buffer pairs take turns,
+    # a pair is reused only after its collective has completed (Work.wait() = a stream dependency, no host stall)
+    rec_pairs = [(rec_local, rec_all), (torch.empty_like(rec_local), torch.empty_like(rec_all))] if rec_all is not None else None
+    pending = [None, None]
     n_nodes = torch.tensor([regions[e % len(regions)].n_nodes for e in range(B)], dtype=torch.float64, device=dev)
 
     # ---- stagger: every env to a uniform phase of its episode cycle (untimed, route-only steps) ----------------------
@@ -452,19 +456,32 @@ def main():
         if ev:
             ev[2].record()
         batch.fetch("nlegal", nlegal_log[i])
+        if world > 1 and rec_pairs is not None and not learner:
+            slot = i & 1
+            if pending[slot] is not None:
+                pending[slot].wait()
+            loc, glob = rec_pairs[slot]
+            batch.fetch("record", loc)
+            pending[slot] = dist.all_gather_into_tensor(glob, loc, async_op=True)      # RCCL over xGMI: the batched-env gather, overlapped with the next step
+            last_gather[0] = slot
+            return
         batch.fetch("record", rec_local)
         if world > 1:
             if learner:
                 batch.fetch("legal", legal_local)
                 dist.all_gather_into_tensor(legal_all, legal_local)
             if rec_all is not None:
-                last_gather[0] = gather_records_fixed(rec_local, rec_all)         # RCCL over xGMI: the batched-env gather
+                last_gather[0] = gather_records_fixed(rec_local, rec_all)         # (the learner needs the records before it can choose: not overlapped)
             else:
                 from xroute_env_amd.dist import gather_records
                 last_gather[0] = gather_records(rec_local)
 
     for i in range(args.warmup):
         one_step(i)
+    for w_ in pending:                              # (the warm-up's gathers are not the timed region's)
+        if w_ is not None:
+            w_.wait()
+    pending[:] = [None, None]
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     if world > 1:
@@ -474,6 +491,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i, events[i])
+    for w_ in pending:                              # every gather of the timed steps completes inside the timed region
+        if w_ is not None:
+            w_.wait()
+    pending[:] = [None, None]
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -490,13 +511,15 @@ def main():
     certify = None
     if world > 1:
         from xroute_env_amd.dist import verify_gather
-        gathered = last_gather[0]
+        gathered, sent = last_gather[0], rec_local
+        if isinstance(gathered, int):               # the overlapped gather: the buffer pair of the last step
+            sent, gathered = rec_pairs[gathered]
         if gathered is None:
             certify = {"ranks_seen": 0, "gather_verified": False, "rows": 0}
         else:
             if os.environ.get("XR_BENCH_TEST_CORRUPT_GATHER") == "1" and rank == 0:       # test hook: a slice that is NOT what its owner sent
                 gathered[-1, 0] ^= 0xFF
-            certify = verify_gather(rec_local, gathered, first_env)
+            certify = verify_gather(sent, gathered, first_env)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([float(real_steps)], dtype=torch.float64, device=dev)
@@ -702,7 +725,7 @@ def main():
                                    + (" (queue form: one persistent launch after a planning kernel)" if headline_form == 3 else
                                       " (split form: route kernel + concurrent net-plane writer)" if headline_form == 2 else
                                       " (fused launch: one workgroup per env)" if fused else "")
-                                   + (", RCCL all_gather of per-env results" if world > 1 else "")
+                                   + (", RCCL all_gather of per-env results" + ("" if learner else " overlapped with the next step (two buffer pairs, async)") if world > 1 else "")
                                    + (" + learner flow (policy on rank 0, i32 action broadcast)" if learner else "")
                                    + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
                        "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}",
