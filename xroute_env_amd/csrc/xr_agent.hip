@@ -450,15 +450,16 @@ constexpr int XA_TOTAL = XA_B3 + 1;
 
 __device__ __forceinline__ float xa_elu(float x) { return x > 0.f ? x : expm1f(x); }
 
+template <bool PRE>       // PRE: the net half of the first layer comes applied (cache_pre): no 32 KB copy of it in LDS — four workgroups per CU instead of two
 __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__ state, const float* __restrict__ head, int64_t head_stride, int ids_off,
                                                        const int32_t* __restrict__ nlegal, const int32_t* __restrict__ region,
                                                        const float* __restrict__ cache_vec, const float* __restrict__ cache_pre, int cache_kmax, const float* __restrict__ wt, int kcap,
                                                        float* __restrict__ logits, int32_t* __restrict__ action) {
-    __shared__ float s_w1n[64 * 128];       // net half of the first layer, [in][out]
+    __shared__ float s_w1n[PRE ? 1 : 64 * 128];       // net half of the first layer, [in][out]
     __shared__ float s_w2[128 * 64];
     __shared__ float s_st[64], s_vec[64], s_h1[128];
     const int j = threadIdx.x, e = blockIdx.x;
-    if (!cache_pre) for (int i = j; i < 64 * 128; i += 128) s_w1n[i] = wt[XA_W1T + 64 * 128 + i];
+    if (!PRE) for (int i = j; i < 64 * 128; i += 128) s_w1n[i] = wt[XA_W1T + 64 * 128 + i];
     for (int i = j; i < 128 * 64; i += 128) s_w2[i] = wt[XA_W2T + i];
     if (j < 64) s_st[j] = state[(int64_t)e * 64 + j];
     __syncthreads();
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     const float b2 = j < 64 ? wt[XA_B2 + j] : 0.f, w3 = j < 64 ? wt[XA_W3 + j] : 0.f, b3 = wt[XA_B3];
     float best = -INFINITY;
     int besta = 0;
-    if (cache_pre) {
+    if (PRE) {
         // two nets per round: both waves add their first-layer halves for both nets, then wave 0 runs the second layer of net k and wave 1 that of net
         // k + 1 (every lane busy, half the barriers); thread 0 takes the two logits in order
         __shared__ float s_h1b[2][128], s_lg[2];
@@ -588,8 +589,12 @@ int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t he
         ids_off < 0 || head_stride < (int64_t)ids_off + kcap)
         return XR_ERR_INVALID;
     if (n_envs == 0) return XR_OK;
-    hipLaunchKernelGGL(xr_actor_kernel, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
-                       region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+    if (cache_pre_dev)
+        hipLaunchKernelGGL(xr_actor_kernel<true>, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
+                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+    else
+        hipLaunchKernelGGL(xr_actor_kernel<false>, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
+                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
     return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
 }
 
