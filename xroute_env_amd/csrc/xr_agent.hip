@@ -447,6 +447,7 @@ constexpr int XA_B2 = XA_W2T + 128 * 64;
 constexpr int XA_W3 = XA_B2 + 64;           // [64]
 constexpr int XA_B3 = XA_W3 + 64;
 constexpr int XA_TOTAL = XA_B3 + 1;
+constexpr int XA_IDS_MAX = 256;             // net ids of an env staged in LDS (kcap beyond that is refused)
 
 __device__ __forceinline__ float xa_elu(float x) { return x > 0.f ? x : expm1f(x); }
 
@@ -474,14 +475,28 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     int besta = 0;
     if (PRE) {
         // two nets per round: both waves add their first-layer halves for both nets, then wave 0 runs the second layer of net k and wave 1 that of net
-        // k + 1 (every lane busy, half the barriers); thread 0 takes the two logits in order
+        // k + 1 (every lane busy, half the barriers); thread 0 takes the two logits in order.  The net ids are staged in LDS once and the first-layer
+        // products of the NEXT round are fetched while this round computes (as two dependent global loads per round they were most of the kernel).
         __shared__ float s_h1b[2][128], s_lg[2];
+        __shared__ int s_ids[XA_IDS_MAX];
         const int wv = j >> 6, o = j & 63;
         const float b2o = wt[XA_B2 + o], w3o = wt[XA_W3 + o];
+        for (int k = j; k < nl; k += 128) s_ids[k] = (int)ids[k];
+        __syncthreads();
+        float c0 = 0.f, c1 = 0.f;
+        if (nl > 0) {
+            c0 = cache_pre[(rbase + s_ids[0] - 1) * 128 + j];
+            c1 = cache_pre[(rbase + s_ids[nl > 1 ? 1 : 0] - 1) * 128 + j];
+        }
         for (int k = 0; k < nl; k += 2) {
-            const int id0 = (int)ids[k], id1 = k + 1 < nl ? (int)ids[k + 1] : id0;
-            s_h1b[0][j] = xa_elu(hs + cache_pre[(rbase + id0 - 1) * 128 + j]);
-            s_h1b[1][j] = xa_elu(hs + cache_pre[(rbase + id1 - 1) * 128 + j]);
+            const int id0 = s_ids[k], id1 = k + 1 < nl ? s_ids[k + 1] : id0;
+            float n0 = 0.f, n1 = 0.f;
+            if (k + 2 < nl) {
+                n0 = cache_pre[(rbase + s_ids[k + 2] - 1) * 128 + j];
+                n1 = cache_pre[(rbase + s_ids[k + 3 < nl ? k + 3 : k + 2] - 1) * 128 + j];
+            }
+            s_h1b[0][j] = xa_elu(hs + c0);
+            s_h1b[1][j] = xa_elu(hs + c1);
             __syncthreads();
             float h2 = b2o;
 #pragma unroll 8
@@ -497,6 +512,7 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
                 if (l0 > best) { best = l0; besta = id0; }
                 if (k + 1 < nl && l1 > best) { best = l1; besta = id1; }
             }
+            c0 = n0; c1 = n1;
         }
     } else {
     for (int k = 0; k < nl; k++) {
@@ -588,6 +604,7 @@ int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t he
     if (!state_dev || !head_dev || !nlegal_dev || !region_dev || !cache_vec_dev || !weights_dev || !action_dev || n_envs < 0 || kcap < 1 || cache_kmax < 1 ||
         ids_off < 0 || head_stride < (int64_t)ids_off + kcap)
         return XR_ERR_INVALID;
+    if (cache_pre_dev && kcap > XA_IDS_MAX) return XR_ERR_RANGE;
     if (n_envs == 0) return XR_OK;
     if (cache_pre_dev)
         hipLaunchKernelGGL(xr_actor_kernel<true>, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
