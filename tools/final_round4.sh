@@ -37,9 +37,6 @@ head -c 600 $OUT/packv2_pmc_traffic.json; echo
 # the split form: xr_obs_kernel measured on this build
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/nofuse_trace -o t -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --no-fuse > $OUT/nofuse_trace.log 2>&1
 python3 $R/tools/rocpd_summary.py $OUT/nofuse_trace > $OUT/nofuse_kernel_stats.csv 2>> $OUT/kernel_stats.err
-# the agent-attached step (fused obstacle tower + actor head): kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/agent_trace -o t -- python3 $R/bench.py --agent dqn --envs 1024 --steps 20 --warmup 3 > $OUT/agent_trace.log 2>&1
-python3 $R/tools/rocpd_summary.py $OUT/agent_trace 2>> $OUT/kernel_stats.err | head -40 > $OUT/agent_dqn_1024_kernel_stats.csv
 cd $R
 timeout 900 bash tools/pmc_sq.sh ${TAG}_sq 4096 6 > $OUT/sq_route.txt 2>&1; tail -25 $OUT/sq_route.txt
 timeout 1200 bash tools/config5_pmc.sh ${TAG}_c5 1024 > $OUT/c5.log 2>&1; tail -22 $OUT/c5.log
@@ -58,11 +55,6 @@ print(open("$OUT/config5_atomics.json").read())
 PY
 unset XR_BENCH_NO_FORK
 timeout 600 python tools/strong_scaling_one_gpu.py > $OUT/strong_scaling_one_gpu.json 2>/dev/null
-timeout 300 python bench.py --agent dqn --envs 1024 --steps 10 --warmup 3 > $OUT/agent_dqn_1024.json 2>/dev/null
-timeout 300 python bench.py --agent ppo --envs 4096 --steps 10 --warmup 3 > $OUT/agent_ppo_4096.json 2>/dev/null
-timeout 300 python bench.py --agent dqn --envs 1024 --steps 10 --warmup 3 --agent-lib-tower > $OUT/agent_dqn_1024_framework_path.json 2>/dev/null
-timeout 600 python bench.py --agent dqn --envs 4096 --steps 20 --warmup 3 --region-pack tests/golden/ispd18_test1_regions.npz > $OUT/agent_dqn_pack_4096.json 2>/dev/null
-timeout 600 python bench.py --agent dqn --envs 4096 --steps 20 --warmup 3 --region-pack tests/golden/ispd18_test1_regions.npz --maze-v2 > $OUT/agent_dqn_pack_4096_v2.json 2>/dev/null
 timeout 200 python tools/config1_probe.py 2>&1 | grep -v amdgpu > $OUT/config1_probe.txt
 timeout 100 python tools/phase_probe.py 1024 2>&1 | grep -v amdgpu > $OUT/route_phase_cycles.txt; cat $OUT/route_phase_cycles.txt
 timeout 300 python tools/phase_probe_v2.py 4096 1 1 2>&1 | grep -v amdgpu > $OUT/v2_phase_cycles_pack.txt; cat $OUT/v2_phase_cycles_pack.txt
@@ -79,3 +71,5 @@ timeout 300 python tools/config5_probe.py 1024 64 2>&1 | grep -v amdgpu > $OUT/c
 cat $OUT/parity_soak.txt
 (timeout 900 python tools/fuzz_router.py 3000 11 2>&1 | grep -v amdgpu | tail -2; XR_LIB=libxroute_hip_tinylists.so timeout 600 python tools/fuzz_router.py 1000 12 2>&1 | grep -v amdgpu | tail -2) > $OUT/fuzz_router.txt; cat $OUT/fuzz_router.txt
 find $OUT -name "*.db" -size +4M -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete; find $OUT -name "*kernel_trace.csv" -size +4M -delete
+# the agent side (agent-attached lines, kernel stats of the agent step, the tower alone): tools/final_round4b.sh without its suite / bench legs
+XR_FINAL_B_AGENT_ONLY=1 bash $R/tools/final_round4b.sh $TAG

@@ -6,8 +6,10 @@ TAG=${1:-r04_z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
 python3 -c "import bench; print('source_sha', bench.source_sha())" | tee $OUT/source_sha.txt
+if [ -z "$XR_FINAL_B_AGENT_ONLY" ]; then        # (tools/final_round4.sh has run these two itself)
 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "suite rc=$?"; tail -3 $OUT/pytest_gpu.log
 S0=$SECONDS; timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py --steps 20 --warmup 5: $((SECONDS - S0)) s of wall clock" | tee $OUT/bench_wall_seconds.txt; cut -c1-400 $OUT/bench.json
+fi
 timeout 300 python bench.py --agent dqn --envs 1024 --steps 20 --warmup 3 > $OUT/agent_dqn_1024.json 2>/dev/null
 timeout 300 python bench.py --agent dqn --envs 4096 --steps 20 --warmup 3 > $OUT/agent_dqn_4096.json 2>/dev/null
 timeout 300 python bench.py --agent ppo --envs 4096 --steps 20 --warmup 3 > $OUT/agent_ppo_4096.json 2>/dev/null
