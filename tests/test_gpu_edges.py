@@ -216,6 +216,30 @@ def test_env_state_restore_is_validated():
             RegionBatch(other, **kw).load_state_dict(dump)
     with pytest.raises(ValueError):
         RegionBatch(regions, via_cost=900, **kw).load_state_dict(dump)
+    #  all-or-nothing: a batch with a state of its own refuses a bad dump — whether the host check or the library's own range
+    # check (host_checks=False: region stored first, then the library refuses `legal`) catches it — and keeps EXACTLY the state it had
+    c = RegionBatch(regions, **kw)
+    c.reset()
+    c.random_actions(77, acts); c.step(acts)
+    before = {k: c.fetch(k).clone() for k in RegionBatch._STATE}
+    assert not torch.equal(before["owner"], a.fetch("owner"))
+    bad = dict(dump); bad["legal"] = dump["legal"].clone(); bad["legal"][2, 0] |= (1 << 40)
+    for host_checks in (True, False):
+        with pytest.raises(_lib.XRouteError):
+            c.load_state_dict(bad, host_checks=host_checks)
+        for k in RegionBatch._STATE:
+            assert torch.equal(c.fetch(k), before[k]), (k, host_checks)
+    bad = dict(dump); bad["cum"] = dump["cum"][:-1]                      # a LATE array of the wrong shape: refused before anything moved
+    with pytest.raises(ValueError):
+        c.load_state_dict(bad)
+    for k in RegionBatch._STATE:
+        assert torch.equal(c.fetch(k), before[k]), k
+    old = {k: v for k, v in dump.items() if k != "steps"}               # a dump from before `steps` was state: accepted, counter kept
+    steps_c = c.total_steps()
+    c.load_state_dict(old)
+    assert c.total_steps() == steps_c and torch.equal(c.fetch("owner"), a.fetch("owner"))
+    with pytest.raises(ValueError):
+        c.load_state_dict({k: v for k, v in dump.items() if k != "hash"})
     # the batch that refused is still usable
     b.random_actions(9, acts); a.step(acts); b.step(acts)
     assert torch.equal(a.fetch("record"), b.fetch("record"))

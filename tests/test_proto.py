@@ -151,5 +151,10 @@ def test_duplicate_vertex_lists_longer_than_the_region_and_two_pins():
         t, u, net, pin = unpack_records(rec)
         assert net[3] == 1 and pin[3] == 0 and u[3] == 1           # pins {3,1,3} -> lowest (1-based 1 -> 0-based 0); used if ANY entry says so
         assert net[5] == 1 and pin[5] == 1 and u[5] == 0           # pins {2,4} -> 2 (0-based 1)
+    #  an entry without a pin (-1) never hides the pin another entry of the same vertex names; no entry names one -> -1
+    for order in ([0, 1, 2], [2, 1, 0], [1, 0, 2]):
+        f, N_, P_ = np.array([4, 4, 6])[order], np.array([3, 3, 3])[order], np.array([-1, 5, -1])[order]
+        t, u, net, pin = unpack_records(records_from_entries(n, f, N_, np.zeros(3, int), P_))
+        assert net[4] == 2 and pin[4] == 4 and net[6] == 2 and pin[6] == -1
     with np.testing.assert_raises(ValueError):
         records_from_entries(n, [3, 3], [2, 3], [0, 0], [1, 1])   # two different NETS on one vertex: not representable

@@ -483,6 +483,33 @@ def gen_g5(ref_grid):
                 out[f"{tag}_{mode}_ppo_value"] = ac.critic(enc2).numpy()
     np.savez_compressed(os.path.join(OUT, "g5_agents.npz"), **out)
     print(f"G5: {len(cases)} observations x 2 modes x (DQN, PPO)")
+    # G5 "more" (round 5): the SAME seeded modules (state dicts in g5_agents.npz) on observations of the grid shapes the fused HIP tower
+    # takes — the design-derived pack's 25x34x9 / 22x36x9 / 7x34x9 and the synthetic 24x40x9 — with K in {1, 10, 36}; eval mode (the fused
+    # kernels are the eval-mode path).  Own file, so that g5_agents.npz stays byte-identical.
+    more = {}
+    more_cases = [("c", (25, 34, 9), 10, 73), ("d", (22, 36, 9), 36, 74), ("e", (7, 34, 9), 1, 75), ("f", (24, 40, 9), 36, 76),
+                  ("g", (25, 34, 9), 1, 77), ("h", (22, 36, 9), 10, 78)]
+    for tag, dims, k, seed in more_cases:
+        reg = generate_region(seed, dims=dims, k_range=(k, k), blockage=(0.05, 0.1))
+        obs = quiet(ref_grid.build_3Dgrid, reg.to_reference_data(), set(), False)[0]
+        more[f"{tag}_obs_i16"] = obs.numpy().astype(np.int16)
+        q_net.load_state_dict(sd0["dqn"]); ac.load_state_dict(sd0["ppo"])
+        q_net.eval(); ac.eval()
+        with torch.no_grad():
+            enc, amap = quiet(agent.representation, obs)
+            pol = quiet(agent.get_policy_from, enc, amap, None, False)[0]
+            more[f"{tag}_eval_dqn_state"] = torch.stack(list(enc)).numpy() if not isinstance(enc, torch.Tensor) else enc.numpy()
+            ids = sorted(amap[0].keys())
+            more[f"{tag}_eval_dqn_ids"] = np.array(ids, np.int32)
+            more[f"{tag}_eval_dqn_netvec"] = torch.stack([amap[0][i] for i in ids]).numpy()
+            d = dict(pol)
+            more[f"{tag}_eval_dqn_logits"] = np.array([float(d[i]) for i in ids], np.float32)
+            enc2, amap2 = quiet(ac.representation, obs)
+            d2 = dict(quiet(ac.get_policy_from, enc2, amap2)[0])
+            more[f"{tag}_eval_ppo_probs"] = np.array([float(d2[i]) for i in ids], np.float32)
+            more[f"{tag}_eval_ppo_value"] = ac.critic(enc2).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_agents_more.npz"), **more)
+    print(f"G5 more: {len(more_cases)} observations, eval mode, (DQN, PPO)")
 
 def main():
     os.makedirs(OUT, exist_ok=True)

@@ -70,6 +70,7 @@ class RegionBatch:
         cfg.window = int(window)                         # regions too large for LDS: > 0 = LDS-window router first (at most that many tracks); 0 = off (measured no faster)
         cfg.stream_per_region = int(stream_per_region)   # one single-workgroup launch per env slot on a pool of streams (<= 64 slots)
         self.cfg = cfg
+        self.region_epoch = 0      # bumped whenever the HOST changes which region a slot plays (assign, reset(rotate), load_state_dict)
         self._h = C.c_void_p()
         _lib.check(self.L.xr_batch_create(C.byref(cfg), C.byref(self._h)))
         with torch.cuda.device(self.device):
@@ -139,6 +140,7 @@ class RegionBatch:
         if a.size != self.n_envs:
             raise ValueError("env_region must have n_envs entries")
         _lib.check(self.L.xr_batch_assign(self._h, a.ctypes.data))
+        self.region_epoch += 1
 
     def reset(self, mask: Optional[torch.Tensor] = None, rotate: bool = False):
         """Game.reset for the masked envs (all when mask is None)."""
@@ -150,6 +152,7 @@ class RegionBatch:
             ptr = C.c_void_p(mask.data_ptr())
         with torch.cuda.device(self.device):
             _lib.check(self.L.xr_batch_reset(self._h, ptr, int(rotate), _stream_ptr(self.device)))
+        self.region_epoch += int(bool(rotate))
 
     def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, inplace: bool = False):
         """Game.step for every env: actions int32[B] on the device, 1-based net ids.  With `obs_out`
@@ -357,22 +360,68 @@ class RegionBatch:
                 h.update(np.ascontiguousarray(r.guide_box, np.int16).tobytes())
         return h.digest()
 
-    def load_state_dict(self, d: dict):
-        """Restore a state_dict() into a batch created with the same regions and config: it continues bit-identically."""
+    def load_state_dict(self, d: dict, host_checks: bool = True):
+        """Restore a state_dict() into a batch created with the same regions and config: it continues bit-identically.
+        All-or-nothing: a dict that is refused — here on the host, or by xr_batch_store (`host_checks=False` leaves the range checks to
+        the library: the rollback path) — leaves the batch in the state it had."""
         meta = [int(v) for v in d["_meta"]]
         if meta != [self.n_envs, self.n_regions, self.n_max, self.legal_words]:
             raise ValueError(f"state of a different batch: (n_envs, n_regions, n_max, legal_words) = {meta}")
         if "_fingerprint" in d and bytes(d["_fingerprint"].numpy().tobytes()) != self.fingerprint():
             raise ValueError("state of a different batch: the regions or the step-relevant config (costs, rotation, XR-Maze v2 knobs) differ")
+        # (ADVICE r4) nothing is stored until EVERYTHING has been checked: shapes of all arrays, then on the host what xr_batch_store would
+        # refuse later (a region index out of range, legal bits beyond the region's nets, a nets-left count that is not the popcount) — and
+        # should a store fail all the same, the batch is rolled back to the state it had, so a caller never holds a half-restored batch.
+        optional = ("steps",)                  # a dump written before `steps` was part of the state keeps the batch's own counter
+        missing = [k for k in self._STATE if k not in d and k not in optional]
+        if missing:
+            raise ValueError(f"state dict lacks {missing} (written by an older version of RegionBatch.state_dict?)")
+        staged = {}
+        for k in self._STATE:
+            if k not in d:
+                continue
+            sel, dtype, shape = self._FETCH[k]
+            t = torch.as_tensor(d[k]).to(dtype=dtype).contiguous()
+            if tuple(t.shape) != tuple(shape(self)):
+                raise ValueError(f"state array {k}: shape {tuple(t.shape)} != {tuple(shape(self))}")
+            staged[k] = t
+        if host_checks:
+            self._check_state_ranges(staged)
+        backup = {k: self.fetch(k) for k in staged}
+        self.region_epoch += 1
         with torch.cuda.device(self.device):
-            for k in self._STATE:
-                sel, dtype, shape = self._FETCH[k]
-                t = d[k].to(device=self.device, dtype=dtype).contiguous()
-                if tuple(t.shape) != tuple(shape(self)):
-                    raise ValueError(f"state array {k}: shape {tuple(t.shape)} != {tuple(shape(self))}")
+            try:
+                self._store_arrays({k: t.to(self.device) for k, t in staged.items()})
+            except Exception:
+                self._store_arrays(backup)
+                raise
+
+    def _check_state_ranges(self, staged: dict):
+        """What xr_batch_store range-checks (csrc/xr_batch.cpp), on the host and BEFORE anything is stored; same error convention."""
+        reg = staged["region"].cpu().numpy().astype(np.int64)
+        if reg.size and (reg.min() < 0 or reg.max() >= self.n_regions):
+            raise _lib.XRouteError(_lib.XR_ERR_RANGE, "state array region: index outside the batch's regions")
+        words = staged["legal"].cpu().numpy().view(np.uint64).reshape(self.n_envs, self.legal_words)
+        nn = np.array([int(r.n_nets) for r in self.regions], np.int64)[reg]
+        bit0 = np.arange(self.legal_words, dtype=np.int64)[None, :] * 64
+        nbits = np.clip(nn[:, None] - bit0, 0, 64)
+        allowed = np.where(nbits >= 64, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << nbits.astype(np.uint64)) - np.uint64(1))
+        if np.any(words & ~allowed):
+            raise _lib.XRouteError(_lib.XR_ERR_RANGE, "state array legal: bits beyond the nets of the region a slot plays")
+        pop = np.unpackbits(words.view(np.uint8), axis=1).sum(axis=1)
+        if not np.array_equal(pop, staged["nlegal"].cpu().numpy().reshape(-1).astype(np.int64)):
+            raise _lib.XRouteError(_lib.XR_ERR_RANGE, "state array nlegal: not the number of legal bits")
+
+    def _store_arrays(self, arrays: dict):
+        with torch.cuda.device(self.device):
+            for k in self._STATE:              # (restore order matters: see _STATE)
+                if k not in arrays:
+                    continue
+                sel = self._FETCH[k][0]
+                t = arrays[k]
                 _lib.check(self.L.xr_batch_store(self._h, sel, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
                                                  _stream_ptr(self.device)))
-            torch.cuda.current_stream(self.device).synchronize()          # the staging tensors die with this frame
+            torch.cuda.current_stream(self.device).synchronize()          # the staging tensors die with the caller's frame
 
     def legal_sets(self) -> List[set]:
         """netSet of every env as Python sets of 1-based ids (host sync)."""

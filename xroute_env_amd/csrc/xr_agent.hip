@@ -389,10 +389,15 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cells
             // the tile's pairs lie in rows h0 .. h1: one row at a time, so that the lanes of a pass own distinct columns
             const int h0 = (t * 16) / ppr, h1 = min(t * 16 + 15, npair - 1) / ppr;
+            // (rows are serialised by the wave's loop iterations: lanes of different rows update the same LDS word in different iterations.
+            // The fence + wave barrier per iteration makes that order a fact of the program, not of the compiler's mood — without it the loop
+            // body, which one thread runs at most once, could legally be collapsed to a range test and the rows would collide.)
             for (int r = h0; r <= h1; r++) {
                 if (ov && !(q & 1) && h == r) {
                     redw[w * 3 + 0] += s0; redw[w * 3 + 1] += s1; redw[w * 3 + 2] += s2;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }

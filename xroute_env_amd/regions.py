@@ -79,9 +79,12 @@ def records_from_entries(n: int, flat, Net, used, Pin) -> np.ndarray:
         ntype[any_acc] = ACCESS
         u[any_used | (any_blk & any_acc)] = 1
         net[flat[acc]] = Net[acc] - 1
-        plo = np.full(n, np.iinfo(np.int64).max, np.int64)
-        np.minimum.at(plo, flat[acc], np.maximum(Pin[acc] - 1, -1))
-        pin[any_acc] = plo[any_acc]
+        # lowest pin over the entries that NAME one (Pin >= 1); -1 only when no entry of the vertex does
+        big = np.iinfo(np.int64).max
+        plo = np.full(n, big, np.int64)
+        named = acc & (Pin >= 1)
+        np.minimum.at(plo, flat[named], Pin[named] - 1)
+        pin[any_acc] = np.where(plo[any_acc] == big, -1, plo[any_acc])
     return pack_records(ntype, u, net, pin)
 
 
