@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--global-envs", type=int, default=0,
                     help="total env slots over all ranks (strong scaling: each rank takes its contiguous share); overrides --envs")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (region generator)")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="distinct synthetic regions generated (the same on every rank), cycled over the env slots: global env g plays region g %% R "
+                         "(0 = one region per env slot; BASELINE config 5's multi-GPU form: --config 5 --envs 1024 --regions 128 --no-observation)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--router", type=int, default=0, help="xr_config.router: 0 default, 1 line-segment sweeps, 2 bucketed frontier")
     ap.add_argument("--dial-mult", type=int, default=0)
@@ -202,7 +205,7 @@ def cpu_baseline(regions, seconds, with_obs=True):
                       f"nets-left distribution) in {dt_a:.1f}s, oracle/xr_oracle.c, host cpu '{model}' ({os.cpu_count()} logical)"}
 
 
-def obs_sample_sha(obs, nlegal, slot_regions, n_check=256, n_sample=32):
+def obs_sample_sha(obs, nlegal, slot_regions, n_check=256, n_sample=32, head_only=False):
     """sha256 of the fp32 observation rows (reference layout, (2+7K)*N floats) of `n_sample` env slots among the first `n_check`,
     spread over the nets-left distribution (sorted by K, evenly spaced).  Called right after the timed region, BEFORE any leg
     touches the buffer again: these are bytes the timed launches wrote.  {env: (K, sha)}"""
@@ -213,12 +216,12 @@ def obs_sample_sha(obs, nlegal, slot_regions, n_check=256, n_sample=32):
     pick = sorted({int(order[int(round(j))]) for j in np.linspace(0, n - 1, min(n_sample, n))})
     out = {}
     for e in pick:
-        size = (2 + 7 * int(nl[e])) * slot_regions[e].n_nodes
+        size = (2 if head_only else 2 + 7 * int(nl[e])) * slot_regions[e].n_nodes          # head_only: the compact-consumer step's planes 0..1
         out[e] = (int(nl[e]), hashlib.sha256(obs[e, :size].cpu().numpy().tobytes()).hexdigest())
     return out
 
 
-def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256, obs_sha=None, v2=None, actions_log=None):
+def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256, obs_sha=None, v2=None, actions_log=None, head_only=False):
     """Checker leg (oracle as the CHECKER, never the thing measured): replays the bench's own action sequence — the
     device policy is a counter-based hash of (seed, env, step count), bit-identical in the oracle; `actions_log` (learner flow:
     the actions rank 0 broadcast) replaces it — on the first `n_check` envs (stagger pre-roll, warm-up and timed steps) and
@@ -251,6 +254,8 @@ def parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=256, obs_sh
             if e >= n:
                 continue
             o = ob.envs[e].observation()
+            if head_only:
+                o = np.ascontiguousarray(o).ravel()[:2 * regions[e].n_nodes]
             if ob.envs[e].nlegal() != k or hashlib.sha256(np.ascontiguousarray(o).tobytes()).hexdigest() != sha:
                 bad.append(int(e))
         checked = [e for e in obs_sha if e < n]
@@ -326,8 +331,15 @@ def main():
     if args.region_pack:
         from xroute_env_amd.lefdef import load_region_pack
         regions = load_region_pack(args.region_pack)
+    elif args.regions > 0:
+        # `--regions R`: R distinct regions of the config, the SAME on every rank, cycled over the env slots (global env g plays region
+        # g % R) — BASELINE config 5's multi-GPU form: 1024 slots of 256x256x12 per GPU over 128 distinct regions, like its one-GPU leg
+        regions = gen_regions(args.config, min(args.regions, max(B, 1)), 0) if not (world > 1 or strong) else gen_regions(args.config, args.regions, 0)
     else:
         regions = gen_regions(args.config, B, first_env)
+    learner_regions = None
+    if args.agent and args.learner and world > 1 and rank == 0 and not args.region_pack and args.regions == 0:
+        learner_regions = gen_regions(args.config, args.global_envs if strong else args.envs * world, 0)      # the central learner's region table: every env's region
     do_legs = world == 1 and rank == 0 and not args.no_legs and not args.region_pack
     c5_regions = gen_regions(5, min(args.c5_regions, args.c5_envs)) if do_legs and args.c5_envs > 0 else None
     pack_regions = None
@@ -366,23 +378,30 @@ def main():
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.dist import RECORD_BYTES, gather_records_fixed
 
-    if args.agent:
-        if world > 1:
-            if rank == 0:
-                print("bench.py: --agent runs on ONE GPU (rank 0 would report a one-GPU number for N): use --gpus 1", file=sys.stderr)
-            sys.exit(2)
-        if rank == 0:
-            print(json.dumps(agent_leg(args, regions, dev, 1)), flush=True)
+    if args.agent and (world > 1 or strong or args.learner):
+        # BASELINE config 4 as stated ("4096 regions sharded 8 x MI355X, PPO baseline, RCCL env gather"): every rank evaluates the policy
+        # counterpart on ITS shard (or, --learner, rank 0 for all envs from gathered compact state) — one self-certifying line
+        rc = agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner_regions)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        sys.exit(rc)
+    if args.agent:
+        print(json.dumps(agent_leg(args, regions, dev, 1)), flush=True)
         return
 
     main_v2 = dict(V2_KNOBS, guide_margin=1 if args.region_pack else 2) if args.maze_v2 else {}
     batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, block_threads=args.block_threads,
                         obs_mode=args.obs_mode, obs_writer_blocks=args.writer_blocks, router=args.router,
                         dial_mult=args.dial_mult, obs_helper_blocks=args.helper_blocks, obs_split_permille=args.quota,
-                        launch_order=args.launch_order, **main_v2)
+                        launch_order=args.launch_order, **(dict(max_route_count=1 << 30) if args.regions > 0 else {}), **main_v2)
+    # slot -> region: one region per slot (the default generator), the pack cycled in slot order, or — `--regions R` — GLOBAL env g on
+    # region g % R whatever the sharding (slots then keep their region: no rotation, the oracle subset can follow)
+    if args.regions > 0:
+        batch.assign([(first_env + e) % len(regions) for e in range(B)])
+        slot_regions = [regions[(first_env + e) % len(regions)] for e in range(B)]
+    else:
+        slot_regions = [regions[e % len(regions)] for e in range(B)]
     batch.reset(rotate=True)
     acts = torch.empty(B, dtype=torch.int32, device=dev)
     obs = None if args.no_observation else batch.alloc_observation()
@@ -395,13 +414,15 @@ def main():
     nsteps_total = args.warmup + args.steps
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
     n_par = min(B, 256 if world == 1 else 32)          # envs of this rank the oracle replays after the run (`parity`)
+    if regions[0].n_nodes > 100000:                    # (BASELINE config 5: a Dijkstra over 786 k nodes per search)
+        n_par = min(n_par, 16)
     acts_log = torch.zeros((max(nsteps_total, 1), n_par), dtype=torch.int32, device=dev)
     last_gather = [None]
     # N > 1, weak scaling: the gather of step i runs on RCCL's stream WHILE step i + 1 computes — two record / result buffer pairs take turns,
     # a pair is reused only after its collective has completed (Work.wait() = a stream dependency, no host stall)
     rec_pairs = [(rec_local, rec_all), (torch.empty_like(rec_local), torch.empty_like(rec_all))] if rec_all is not None else None
     pending = [None, None]
-    n_nodes = torch.tensor([regions[e % len(regions)].n_nodes for e in range(B)], dtype=torch.float64, device=dev)
+    n_nodes = torch.tensor([r.n_nodes for r in slot_regions], dtype=torch.float64, device=dev)
 
     # ---- stagger: every env to a uniform phase of its episode cycle (untimed, route-only steps) ----------------------
     stagger = None
@@ -505,7 +526,7 @@ def main():
     # bytes of the observation the LAST timed launch wrote, for envs spread over K (compared with the oracle in `parity`)
     obs_sha = None
     if obs is not None and nsteps_total > 0:
-        obs_sha = obs_sample_sha(obs, nlegal_log[nsteps_total - 1], [regions[e % len(regions)] for e in range(n_par)], n_check=n_par)
+        obs_sha = obs_sample_sha(obs, nlegal_log[nsteps_total - 1], slot_regions[:n_par], n_check=n_par)
 
     # ---- N > 1: the run certifies itself — the gather delivered every rank's records, and every rank's envs replay on the oracle
     certify = None
@@ -685,11 +706,11 @@ def main():
                 "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes"])}
 
     parity = None
-    can_replay = not args.region_pack and len(regions) >= B          # regions == env slots: rotation keeps every slot on its region, the oracle subset can follow
+    can_replay = not args.region_pack and (len(regions) >= B or args.regions > 0)      # regions == env slots: rotation keeps every slot on its region (--regions: no rotation), the oracle subset can follow
     if can_replay and (world > 1 or not args.no_cpu_baseline):
         try:
             seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
-            parity = parity_check(regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
+            parity = parity_check(slot_regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
                                   actions_log=acts_log.cpu().numpy() if learner else None, v2=main_v2 or None)
         except Exception as ex:
             parity = {"error": str(ex), "ok": False}
@@ -703,7 +724,7 @@ def main():
         mean_k = float(k_after.mean().item())
         Bg = args.global_envs if strong else B * world
         out = {
-            "metric": "env-steps/sec (batched regions), ispd18_test1-sized regions",
+            "metric": "env-steps/sec (batched regions), " + ("synthetic 256x256x12 regions (BASELINE config 5)" if args.config == 5 and not args.region_pack else "ispd18_test1-sized regions"),
             "value": round(total_real / elapsed_max, 1),
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -717,6 +738,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)}, "
                                     if args.region_pack else
+                                    f"BASELINE config 5: {Bg} env slots of synthetic 256x256x12 dense-congestion regions (K = 32"
+                                    + (f", {len(regions)} distinct regions cycled over the slots" if args.regions > 0 else "") + f"), {B} per GPU, "
+                                    if args.config == 5 else
                                     f"north_star target: a {Bg}-env batch of ispd18_test1-sized regions (24x40x9, K~U[4,36]; generator of "
                                     f"BASELINE configs 2-4), {B} per GPU, ")
                                    +
@@ -767,7 +791,7 @@ def main():
 
 def bench_args_key(args, world):
     return {"gpus": world, "steps": args.steps, "warmup": args.warmup, "envs": args.envs, "global_envs": args.global_envs,
-            "config": args.config, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
+            "config": args.config, "regions": args.regions, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
             "no_stagger": bool(args.no_stagger), "region_pack": os.path.basename(args.region_pack) if args.region_pack else None,
             "maze_v2": bool(args.maze_v2)}
 
@@ -934,6 +958,285 @@ def agent_leg(args, regions, dev, world):
                          "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                          "avg_launch_ms": round(env_ms, 4), "algorithmic_bytes_per_launch": int(env_bytes)}}
+
+
+def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner_regions=None):
+    """BASELINE config 4 as stated — "4096 regions sharded 8 x MI355X, PPO baseline, RCCL env gather" — as ONE self-certifying line
+    (`--gpus N [--global-envs 4096] --agent ppo`; also N = 1 and `--agent dqn`).  The reference's caller loop is
+    `action = ppo_agent.select_action(state); state, done, ... = game.step(action)` (baseline/PPO/train_PPO.py:96-99; the sampling:
+    baseline/PPO/PPO.py:205-217).  Two placements of the policy:
+
+      default     every rank evaluates the counterpart on ITS shard (weights replicated from a fixed seed, fused tower + actor head, net
+                  vectors of its own regions cached), steps its slice in compact-consumer mode, and the 48-byte result records are
+                  all-gathered (overlapped with the next step) — north_star's "RCCL only for the batched-env gather".
+      --learner   SURVEY §8e's central learner: every rank packs the compact state of its envs (xr_batch_pack_state: one bit per node +
+                  the legal bitmask), ONE all_gather carries it, rank 0 expands it to head rows (xr_batch_expand_state), evaluates the
+                  policy for ALL envs and broadcasts the actions (i32); the ranks step route-only.
+
+    PPO samples with counter-based uniforms of (seed, step, GLOBAL env id, net rank) (agents.counter_uniform), so both placements and
+    every sharding choose the same action for the same env: `actions_sha` / `hash_chains_sha` of an N-rank line equal the one-rank line's.
+    Self-certification as in the env-only N > 1 line: `gather_verified`, `ranks_seen`, `parity.all_ranks_ok` (oracle replay of the actions
+    the policy actually chose + the head planes the last step wrote)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from xroute_env_amd import agents
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.dist import RECORD_BYTES, gather_rows, verify_gather
+    learner = bool(args.learner)
+    cycled = bool(args.region_pack) or args.regions > 0            # global env g plays region g % len(regions); else one region per env slot
+    Bg = args.global_envs if strong else B * world
+    mixed = len({tuple(int(v) for v in r.dims) for r in regions}) > 1
+    v2 = dict(V2_KNOBS, guide_margin=1) if (args.maze_v2 and args.region_pack) else {}
+    torch.manual_seed(0)                                            # the SAME random-init weights on every rank
+    model = (agents.RepActor() if args.agent == "dqn" else agents.ActorCritic(64)).to(dev).eval()
+    batch = RegionBatch(regions, n_envs=B, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
+                        launch_order=args.launch_order, max_route_count=1 << 30, **v2)
+    if cycled:
+        batch.assign([(first_env + e) % len(regions) for e in range(B)])
+        slot_regions = [regions[(first_env + e) % len(regions)] for e in range(B)]
+    else:
+        slot_regions = list(regions[:B])
+    batch.reset()
+    acts = torch.empty(B, dtype=torch.int32, device=dev)
+    env_ids = torch.arange(first_env, first_env + B, dtype=torch.int64, device=dev)
+
+    # ---- the policy's side: who evaluates it, on which rows ---------------------------------------------------------------------
+    # default: this rank, on its own head buffer.  --learner: rank 0, on the rows expanded from everybody's packed state; its region
+    # table must hold every region of the job (the pack / the --regions set as they are; one region per env: all Bg of them)
+    pol_batch, pol_regions, region_base = batch, regions, 0
+    if learner and not cycled:
+        region_base = first_env
+        if rank == 0 and world > 1:
+            pol_regions = learner_regions                # (every region of the job, generated by main() before the GPU was touched)
+            pol_batch = RegionBatch(pol_regions, n_envs=1, device=dev)
+    evaluates = (not learner) or rank == 0
+    n_rows = Bg if learner else B
+    rb = batch.state_row_bytes()
+    if learner and world > 1:
+        t_rb = torch.tensor([max(rb, pol_batch.state_row_bytes())], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_rb, op=dist.ReduceOp.MAX)
+        rb = int(t_rb.item())
+    head = nl = reg = None
+    grouped = cache = tower = head_k = None
+    if evaluates:
+        head = torch.empty((n_rows, 2 * pol_batch.n_max), dtype=torch.float32, device=dev)
+        nl = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        reg = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        if mixed:
+            grouped = agents.GroupedFusedPolicy(model, pol_batch, dev)
+            cache = grouped.cache
+        else:
+            dims = pol_regions[0].dims
+            cache = agents.NetVectorCache(len(pol_regions), pol_batch.k_max, dev)
+            tower = agents.FusedObstacleTower(model.representation_network, (dims[2], dims[1], dims[0]), dev)
+            head_k = agents.FusedActorHead(model.actor, dev)
+            cache.prefill(model.representation_network, [r.n_nets for r in pol_regions], pol_batch.net_planes, dims)
+    row_ids = torch.arange(Bg, dtype=torch.int64, device=dev) if learner else env_ids
+    rows_local = torch.empty((B, rb), dtype=torch.uint8, device=dev) if learner else None
+    rows_all = torch.empty((Bg, rb), dtype=torch.uint8, device=dev) if learner and world > 1 and Bg % world == 0 else None
+    acts_all = torch.zeros(Bg, dtype=torch.int32, device=dev) if learner else None
+
+    def policy(i):
+        """actions of the rows this rank evaluates (head / nl / reg hold their current state)"""
+        uni = agents.counter_uniform(args.seed, i, row_ids) if args.agent == "ppo" else None
+        if mixed:
+            return grouped.actions(head, nl, reg, sample=(args.agent == "ppo"), uniform=uni)
+        kw = dict(cache=cache, region=reg, ob_tower=tower, actor_head=head_k, planes_fn=pol_batch.net_planes)
+        if args.agent == "dqn":
+            return agents.dqn_actions(model, head, nl, dims, **kw)
+        return agents.ppo_actions(model, head, nl, dims, uniform=uni, **kw)[0]
+
+    if not learner:
+        _head_of(batch, head)
+
+    # ---- stagger: every env to a uniform phase of its episode (untimed, random actions, route-only) ---------------------------------
+    stagger = None
+    if not args.no_stagger:
+        off = stagger_offsets(batch.fetch("nlegal").cpu().numpy(), first_env)
+        off_d = torch.from_numpy(off).to(dev)
+        mx = torch.tensor([int(off.max()) if B else 0], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        pre_seeds = [args.seed ^ 0xA6E7 ^ i for i in range(int(mx.item()))]          # (the same list on every rank: one oracle replay recipe)
+        zero = torch.zeros_like(acts)
+        for i, sd in enumerate(pre_seeds):
+            batch.random_actions(sd, acts)
+            torch.where(off_d > i, acts, zero, out=acts)
+            batch.step(acts)
+        stagger = (off, pre_seeds)
+        if not learner:
+            _head_of(batch, head)
+
+    nsteps_total = max(args.warmup, 2) + args.steps
+    acts_log = torch.zeros((nsteps_total, B), dtype=torch.int32, device=dev)
+    rec_pairs = [(torch.empty((B, RECORD_BYTES), dtype=torch.uint8, device=dev),
+                  torch.empty((Bg, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 and Bg % world == 0 else None) for _ in range(2)]
+    pending = [None, None]
+    last_slot = [0]
+    split = {"pack_gather": 0.0, "expand": 0.0, "policy": 0.0, "broadcast": 0.0, "env": 0.0}
+
+    def one_step(i, ev=None):
+        mark = (lambda j: ev[j].record()) if ev else (lambda j: None)
+        mark(0)
+        if learner:
+            batch.pack_state(rows_local, region_base=region_base)
+            if world > 1:
+                rows = rows_all if rows_all is not None else None
+                if rows is not None:
+                    dist.all_gather_into_tensor(rows, rows_local)          # the compact-state gather: Bg x row_bytes per step
+                else:
+                    rows = gather_rows(rows_local)
+            else:
+                rows = rows_local
+            mark(1)
+            if rank == 0:
+                pol_batch.expand_state(rows, head, nl, reg)
+                mark(2)
+                acts_all.copy_(policy(i))
+            else:
+                mark(2)
+            mark(3)
+            if world > 1:
+                dist.broadcast(acts_all, src=0)                             # the actions travel back as one i32[Bg]
+            acts.copy_(acts_all[first_env:first_env + B])
+        else:
+            mark(1); mark(2)
+            batch.fetch("nlegal", nl)
+            batch.fetch("region", reg)
+            acts.copy_(policy(i))
+            mark(3)
+        mark(4)
+        acts_log[i].copy_(acts)
+        if learner:
+            batch.step(acts)
+        else:
+            batch.step_compact(acts, head)
+        mark(5)
+        slot = i & 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        loc, glob = rec_pairs[slot]
+        batch.fetch("record", loc)
+        if world > 1 and glob is not None:
+            pending[slot] = dist.all_gather_into_tensor(glob, loc, async_op=True)          # the batched-env gather, overlapped with the next step
+        last_slot[0] = slot
+
+    n_w = max(args.warmup, 2)                       # (MIOpen kernel selection of the framework path, first-touch of the buffers)
+    for i in range(n_w):
+        one_step(i)
+    for j in range(2):
+        if pending[j] is not None:
+            pending[j].wait(); pending[j] = None
+    n = max(args.steps, 1)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    steps0 = batch.total_steps()
+    t0 = time.perf_counter()
+    for i in range(n):
+        one_step(n_w + i, events[i])
+    for j in range(2):
+        if pending[j] is not None:
+            pending[j].wait(); pending[j] = None
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    real_steps = batch.total_steps() - steps0
+    for k_, (a_, b_) in zip(split, ((0, 1), (1, 2), (2, 3), (3, 4), (4, 5))):
+        split[k_] = sum(e[a_].elapsed_time(e[b_]) for e in events) / n
+    gpu_hash = batch.fetch("hash").cpu().numpy().view("uint64")
+    gpu_cum = batch.fetch("cum").cpu().numpy()
+    nl_now = batch.fetch("nlegal")
+    n_par = min(B, 64 if world == 1 else 32)
+    obs_sha = None if learner else obs_sample_sha(head, nl_now, slot_regions[:n_par], n_check=n_par, head_only=True)
+
+    # ---- certification: the gather, every rank's oracle replay, and the sharding-invariant digests ---------------------------------
+    certify = None
+    if world > 1:
+        sent, gathered = rec_pairs[last_slot[0]]
+        if gathered is None:
+            gathered = gather_rows(sent)
+        if os.environ.get("XR_BENCH_TEST_CORRUPT_GATHER") == "1" and rank == 0:
+            gathered[-1, 0] ^= 0xFF
+        certify = verify_gather(sent, gathered, first_env)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    sm = torch.tensor([float(real_steps), split["policy"] + split["expand"], split["env"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tsum = sm.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)
+        total_real = float(tsum[0].item())
+    else:
+        total_real = float(real_steps)
+    elapsed_max = float(t.item())
+    # actions of every env at every step and every env's final hash chain, in GLOBAL env order (tiny gathers, outside the timed region)
+    al = acts_log.t().contiguous()                                   # [B, steps]
+    hs = torch.from_numpy(gpu_hash.view("int64").copy()).to(dev).reshape(B, 1)
+    if world > 1:
+        al, hs = gather_rows(al), gather_rows(hs)
+    actions_sha = hashlib.sha256(al.cpu().numpy().tobytes()).hexdigest()
+    chains_sha = hashlib.sha256(hs.cpu().numpy().tobytes()).hexdigest()
+    try:
+        seeds = list(range(nsteps_total))
+        parity = parity_check(slot_regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
+                              actions_log=acts_log.cpu().numpy(), v2=v2 or None, head_only=True)
+        parity["what"] = ("CPU oracle replay of the actions the POLICY chose (stagger pre-roll + warm-up + timed steps) on the first envs of the rank: "
+                          "hash chains, cumulative metrics" + ("" if learner else ", sha256 of planes 0..1 the last compact step wrote vs the oracle's build_3Dgrid restatement"))
+    except Exception as ex:
+        parity = {"error": str(ex), "ok": False}
+    if world > 1:
+        flag = torch.tensor([1 if parity.get("ok") else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity = dict(parity, all_ranks_ok=bool(flag.item() == 1), envs_per_rank=n_par)
+    good = world == 1 or (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
+    good = bool(good and parity.get("ok"))
+    if rank == 0:
+        agent_ms = split["pack_gather"] + split["expand"] + split["policy"] + split["broadcast"]
+        N_mean = float(sum(r.n_nodes for r in slot_regions)) / max(B, 1)
+        out = {"metric": f"env-steps/sec, {args.agent.upper()} counterpart attached (batched regions), ispd18_test1-sized regions",
+               "value": round(total_real / elapsed_max, 1), "unit": "env-steps/s", "n_gpus": world if good else None, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed_max / n * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong" if strong else "weak", "vs_baseline": None,
+               "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
+               "config": {"workload": (f"BASELINE config 4 shape: a {Bg}-env batch, {B} per GPU, "
+                                       + (f"over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)} (XR-Maze {'v2: the reference configuration' if v2 else 'v1'}), "
+                                          if args.region_pack else "of ispd18_test1-sized regions (24x40x9, K~U[4,36]), ")
+                                       + f"full maze route per step, {args.agent.upper()} counterpart (random-init weights of the reference architecture, replicated from one seed, eval mode"
+                                       + (", actions sampled with counter-based uniforms of (seed, step, global env, net rank)" if args.agent == "ppo" else "") + ") choosing every action; "
+                                       + ("policy on rank 0 for ALL envs from the gathered compact state (xr_batch_pack_state -> all_gather -> xr_batch_expand_state), i32 action broadcast, ranks step route-only"
+                                          if learner else
+                                          "policy evaluated by every rank on ITS shard, compact-consumer step (xr_batch_step_compact: planes 0..1 per step; net vectors cached per (region, net))")
+                                       + ("; RCCL all_gather of the 48-byte per-env records overlapped with the next step" if world > 1 else "")
+                                       + ("" if args.no_stagger else "; episodes staggered before timing")),
+                          "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}", "policy_placement": "rank 0 (central learner)" if learner else "every rank (its shard)",
+                          "mean_nets_left": round(float(nl_now.double().mean().item()), 2), "source_sha": source_sha()},
+               "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(split["env"], 4),
+               "env_share_of_step_time": round(split["env"] / max(split["env"] + agent_ms, 1e-9), 4),
+               "step_split_ms_rank0": {k_: round(v_, 4) for k_, v_ in split.items()},
+               "slowest_rank_ms": {"policy": round(float(sm[1].item()), 4), "env": round(float(sm[2].item()), 4)} if world > 1 else None,
+               "actions_sha": actions_sha, "hash_chains_sha": chains_sha, "parity": parity,
+               "roofline": {"kernel": "xr_route_kernel" + ("" if learner else " (+ planes 0..1)"), "bound": "hbm",
+                            "achieved": round(B * ((4.0 if learner else 12.0) * N_mean) / (max(split["env"], 1e-9) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(B * ((4.0 if learner else 12.0) * N_mean) / (max(split["env"], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                            "avg_launch_ms": round(split["env"], 4),
+                            "note": "the env step of this line is the LDS-resident router (latency-bound): its HBM bytes are the state load" + ("" if learner else " + the two head planes")}}
+        if learner:
+            out["compact_state"] = {"row_bytes": rb, "bytes_gathered_per_step": Bg * rb, "fp32_head_bytes_per_step": int(Bg * 8 * N_mean),
+                                    "ratio_to_fp32_planes": round(rb / (8.0 * N_mean), 5),
+                                    "what": "per env: region, nets left, legal-net bitmask, one occupancy bit per node (plane 0); plane 1 is the bitmask — "
+                                            "what SURVEY §8e's central learner gathers instead of observations"}
+        if certify is not None:
+            out["gather_verified"], out["ranks_seen"], out["gathered_rows"] = certify["gather_verified"], certify["ranks_seen"], certify["rows"]
+        if not good:
+            out["error"] = "self-certification failed: " + json.dumps({"certify": certify, "parity_ok": parity.get("ok"), "all_ranks_ok": parity.get("all_ranks_ok")})
+            print(out["error"], file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    return 0 if good else 3
 
 
 def _head_of(batch, head):

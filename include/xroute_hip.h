@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 6
+#define XR_ABI_VERSION 7
 
 /* status codes */
 #define XR_OK            0
@@ -283,6 +283,27 @@ int32_t xr_batch_step_compact(xr_batch* b, const int32_t* actions_dev, float* he
                               void* stream);
 int32_t xr_batch_net_planes(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs,
                             float* out_dev, int64_t pair_stride, void* stream);
+
+/* Compact state for a CENTRAL learner (ABI 7; SURVEY.md §8e, BASELINE config 4).  The reference's caller loop evaluates its policy on the
+ * observation of the env it just stepped (baseline/PPO/train_PPO.py:96-99: `action = ppo_agent.select_action(state); state, ... = game.step(action)`).
+ * When ONE learner process evaluates the policy for env slots that live on other GPUs, what has to travel per env-step is not the two fp32
+ * planes that change (8·N bytes) but what they are functions of: plane 0 (obstacle: blockage or used, baseline/build_3Dgrid.py:19-36,94-103) is
+ * one bit per node, plane 1 (the remaining nets' ids ascending at flat positions 0..K-1, :144-161) is the legal-net bitmask.
+ *   xr_batch_state_row_bytes  bytes of one packed row of THIS batch: 16 + 8·(legal_words + ceil(n_max / 64)); ranks agree on the maximum.
+ *   xr_batch_pack_state       one row per env slot at rows_dev + e*row_bytes (8-byte aligned, row_bytes % 8 == 0):
+ *                               int32 region + region_base | int32 nlegal | int32 legal_words | int32 occ_words |
+ *                               uint64 legal[legal_words] | uint64 occ[occ_words]  (bit f%64 of word f/64 = node f, flat observation order)
+ *                             region_base: what turns this batch's local region index into an index of the learner's region table.
+ *   xr_batch_expand_state     (learner side; `b` supplies the region table: it must hold every region the rows name) n_rows rows -> the
+ *                             fp32 head rows xr_batch_step_compact writes for those envs, byte for byte (planes 0..1 at
+ *                             head_out_dev + i*head_stride, each env in its own region's layout), plus nlegal / region of every row as
+ *                             int32 arrays for xr_agent_actor.  A row that does not parse (region outside the table, sizes that do not
+ *                             fit, nlegal != popcount(legal), a legal bit beyond the region's nets) is left unwritten and flagged
+ *                             nlegal = region = -1. */
+int32_t xr_batch_state_row_bytes(const xr_batch* b, int64_t* row_bytes);
+int32_t xr_batch_pack_state(xr_batch* b, uint8_t* rows_dev, int64_t row_bytes, int32_t region_base, void* stream);
+int32_t xr_batch_expand_state(xr_batch* b, const uint8_t* rows_dev, int64_t row_bytes, int32_t n_rows, float* head_out_dev, int64_t head_stride,
+                              int32_t* nlegal_out_dev, int32_t* region_out_dev, void* stream);
 
 /* Whole-order re-route, the step of the reference's two other env contracts: the A3C env answers the simulator with
  * a complete net list (baseline/A3C/utils.py:305-307, Response.net_list of net_ordering.proto v2 field 2) and the

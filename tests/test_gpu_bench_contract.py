@@ -138,6 +138,70 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert lines and json.loads(lines[0])["gather_verified"] is False and json.loads(lines[0])["n_gpus"] is None
 
 
+def _torchrun(nproc, bench_args, extra_env=None, expect_rc=0):
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, XR_BENCH_BACKEND="gloo", XR_BENCH_SAME_DEVICE="1", **(extra_env or {}))
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + bench_args
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + bench_args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if expect_rc is not None:
+        assert out.returncode == expect_rc, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_config4_ppo_attached_two_ranks_on_one_gpu():
+    """BASELINE config 4 as stated ("4096 regions sharded 8 x MI355X, PPO baseline, RCCL env gather") as ONE runnable, self-certifying
+    command, exercised with two gloo ranks sharing cuda:0:
+      (a) `--gpus N --global-envs G --agent ppo`: every rank evaluates the PPO counterpart on its shard; the line carries agent-attached
+          env-steps/s, env_share_of_step_time, gather_verified / ranks_seen / parity.all_ranks_ok (oracle replay of the actions the policy
+          chose + the head planes) — and chooses the SAME action for every env at every step as the one-rank line (`actions_sha`), with
+          identical final hash chains;
+      (b) `--learner`: rank 0 evaluates the policy for all envs from the gathered compact state (pack -> all_gather -> expand), i32
+          action broadcast — again the same actions env for env, plus the bytes it gathers;
+      (c) BASELINE config 5's multi-GPU form (`--config 5 --envs E --regions R --no-observation --gpus N`)."""
+    common = ["--global-envs", "192", "--agent", "ppo", "--steps", "3", "--warmup", "2"]
+    one = _torchrun(1, common)
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["value"] > 0 and one["parity"]["ok"] is True
+    assert one["parity"]["observations_equal"] is True and one["parity"]["observations_checked"] >= 16
+    assert 0 < one["env_share_of_step_time"] < 1 and one["config"]["policy_placement"].startswith("every rank")
+    # (a) two ranks, policy per rank
+    two = _torchrun(2, common)
+    assert two["n_gpus"] == 2 and two["config"]["global_envs"] == 192 and two["config"]["envs_per_gpu"] == 96 and two["value"] > 0
+    assert two["gather_verified"] is True and two["ranks_seen"] == 2 and two["gathered_rows"] == 192
+    assert two["parity"]["all_ranks_ok"] is True and two["parity"]["ok"] is True and two["parity"]["observations_equal"] is True
+    assert 0 < two["env_share_of_step_time"] < 1 and two["agent_ms_per_step"] > 0 and two["env_ms_per_step"] > 0
+    assert two["actions_sha"] == one["actions_sha"] and two["hash_chains_sha"] == one["hash_chains_sha"]
+    assert "PPO counterpart" in two["metric"] and "RCCL all_gather" in two["config"]["workload"]
+    # (b) the central learner: compact state gathered, expanded and evaluated on rank 0
+    ltwo = _torchrun(2, common + ["--learner"])
+    for d in (ltwo,):
+        assert d["config"]["policy_placement"].startswith("rank 0") and d["parity"]["ok"] is True
+        assert d["actions_sha"] == one["actions_sha"] and d["hash_chains_sha"] == one["hash_chains_sha"]
+        cs = d["compact_state"]
+        assert cs["bytes_gathered_per_step"] == 192 * cs["row_bytes"] and cs["ratio_to_fp32_planes"] < 0.02
+        assert d["step_split_ms_rank0"]["expand"] > 0 and d["step_split_ms_rank0"]["pack_gather"] > 0
+    assert ltwo["gather_verified"] is True and ltwo["ranks_seen"] == 2 and ltwo["parity"]["all_ranks_ok"] is True
+    # a corrupted gather fails this line too: rc 3, no N-GPU label
+    bad = _torchrun(2, ["--envs", "32", "--agent", "ppo", "--steps", "2", "--warmup", "2"], {"XR_BENCH_TEST_CORRUPT_GATHER": "1"}, expect_rc=None)
+    assert bad["gather_verified"] is False and bad["n_gpus"] is None
+    # DQN (greedy) and ragged shards (193 = 97 + 96) go through the same flow
+    dq2 = _torchrun(2, ["--global-envs", "193", "--agent", "dqn", "--steps", "2", "--warmup", "2"])
+    assert dq2["gather_verified"] is True and dq2["gathered_rows"] == 193 and dq2["parity"]["all_ranks_ok"] is True
+    assert dq2["config"]["envs_per_gpu"] == 97
+    # (c) BASELINE config 5, two ranks: 256x256x12 regions, route-only, compact state
+    c5 = _torchrun(2, ["--config", "5", "--envs", "8", "--regions", "4", "--no-observation", "--steps", "2", "--warmup", "1"])
+    assert c5["n_gpus"] == 2 and c5["config"]["global_envs"] == 16 and "config 5" in c5["config"]["workload"] and c5["value"] > 0
+    assert c5["gather_verified"] is True and c5["ranks_seen"] == 2 and c5["parity"]["all_ranks_ok"] is True and c5["parity"]["ok"] is True
+
+
 def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
     """`python bench.py --gpus 2` with no WORLD_SIZE must not benchmark ONE GPU under an N = 2 label: it starts the two ranks
     itself (a child torch.distributed.run) and forwards rank 0's line; a WORLD_SIZE that contradicts --gpus is refused."""

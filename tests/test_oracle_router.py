@@ -134,3 +134,41 @@ def test_distance_cap_rule():
         r2 = e2.step(1)
         assert bool(r2["status"] & 2) == (not ok), (col, r2)
         assert r2["path_len"] == (col + 1 if ok else 0)
+
+
+@pytest.mark.parametrize("knobs", [dict(maze_end_iter=3, guide_cost=800, guide_margin=1), dict(maze_end_iter=2, guide_cost=0, guide_margin=0),
+                                   dict(maze_end_iter=5, guide_cost=300, guide_margin=2)],
+                         ids=["the-reference-knobs", "two-attempts-no-guide", "five-attempts"])
+def test_rip_up_loop_has_one_outcome_the_last_attempts_route(knobs):
+    """XR-Maze v2, the theorem the GPU routers rely on since round 5: the rip-up-and-reroute loop — attempt t routes the
+    net with the penalty pen << t, an attempt whose path uses a held node is ripped up unless it is the last — always ends with the route
+    the LAST attempt would compute: if attempt t stands (no held node on its paths) every later attempt would repeat it search by search
+    (paths without a held node cost what they cost, every alternative through one only got dearer: same distances along them, same first
+    tight predecessors, same targets).  So the oracle with `maze_end_iter = m` must equal, step by step (paths, deltas, owners, hash
+    chains), the oracle with ONE attempt at penalty pen << (m - 1) — here: drc_cost x 2^(m-1), maze_end_iter 1 — and really differ from
+    plain XR-Maze v1 somewhere (the loop is not vacuous on these regions)."""
+    import os
+    from tests.helpers import GOLDEN
+    from xroute_env_amd.lefdef import load_region_pack
+    m = knobs["maze_end_iter"]
+    g = dict(guide_cost=knobs["guide_cost"], guide_margin=knobs["guide_margin"])
+    regions = [generate_region(4100 + i, dims=(12, 10, 5), k_range=(4, 9), blockage=(0.1, 0.3)) for i in range(30)]
+    regions += [generate_region(4200 + i, dims=(16, 14, 4), k_range=(6, 12), net_span=7) for i in range(10)]
+    regions += load_region_pack(os.path.join(GOLDEN, "ispd18_test1_regions.npz"))[3:40:6]          # design-derived regions with their guide boxes
+    steps = differs_from_v1 = 0
+    for ri, r in enumerate(regions):
+        loop = orc.OracleEnv(r, maze_end_iter=m, **g)
+        last = orc.OracleEnv(r, drc_cost=8 << (m - 1), maze_end_iter=1, **g)
+        v1 = orc.OracleEnv(r, maze_end_iter=1, **g)
+        rng = np.random.default_rng(ri)
+        while loop.nlegal():
+            act = int(rng.choice(sorted(loop.legal())))
+            a, b = loop.step(act), last.step(act)
+            steps += 1
+            assert a["delta"].tolist() == b["delta"].tolist() and a["path"].tolist() == b["path"].tolist(), (ri, act)
+            assert a["done"] == b["done"] and loop.hash() == last.hash() and np.array_equal(loop.owner(), last.owner()), (ri, act)
+            if v1 is not None and v1.step(act)["path"].tolist() != a["path"].tolist():
+                differs_from_v1 += 1
+                v1 = None                                          # (from here on v1 is in another state: the comparison is over for this region)
+        assert np.array_equal(loop.cum(), last.cum())
+    assert steps > 250 and differs_from_v1 >= 3, (steps, differs_from_v1)

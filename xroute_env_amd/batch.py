@@ -208,6 +208,47 @@ class RegionBatch:
                                                   C.c_void_p(out.data_ptr()), out.shape[1], _stream_ptr(self.device)))
         return out
 
+    # ---- compact state for a central learner (gather compact state, expand on the learner GPU) ----------------
+    def state_row_bytes(self) -> int:
+        """Bytes of one packed state row of this batch (region, nets left, legal bitmask, one occupancy bit per node)."""
+        n = C.c_int64()
+        _lib.check(self.L.xr_batch_state_row_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def pack_state(self, out: Optional[torch.Tensor] = None, region_base: int = 0, row_bytes: Optional[int] = None) -> torch.Tensor:
+        """One packed row per env slot (uint8 [n_envs, row_bytes]): what planes 0..1 of its observation are functions of — ready for
+        ONE all_gather to a learner.  `region_base` turns the local region index into an index of the learner's region table."""
+        rb = int(row_bytes) if row_bytes is not None else (int(out.shape[1]) if out is not None else self.state_row_bytes())
+        if out is None:
+            out = torch.empty((self.n_envs, rb), dtype=torch.uint8, device=self.device)
+        if out.dtype != torch.uint8 or not out.is_contiguous() or tuple(out.shape) != (self.n_envs, rb):
+            raise ValueError("out must be a contiguous uint8 [n_envs, row_bytes] tensor")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_pack_state(self._h, C.c_void_p(out.data_ptr()), rb, int(region_base), _stream_ptr(self.device)))
+        return out
+
+    def expand_state(self, rows: torch.Tensor, head_out: Optional[torch.Tensor] = None, nlegal_out: Optional[torch.Tensor] = None,
+                     region_out: Optional[torch.Tensor] = None):
+        """Learner side: packed rows (uint8 [n, row_bytes], e.g. the all_gather of every rank's `pack_state`) -> (head [n, stride] fp32 with
+        planes 0..1 of every env exactly as `step_compact` writes them, nlegal int32 [n], region int32 [n]).  This batch supplies the
+        region table (it must hold every region the rows name); rows that do not parse are flagged nlegal = region = -1."""
+        if rows.dtype != torch.uint8 or rows.dim() != 2 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous uint8 [n, row_bytes] tensor")
+        n = int(rows.shape[0])
+        if head_out is None:
+            head_out = torch.empty((n, 2 * self.n_max), dtype=torch.float32, device=self.device)
+        if nlegal_out is None:
+            nlegal_out = torch.empty(n, dtype=torch.int32, device=self.device)
+        if region_out is None:
+            region_out = torch.empty(n, dtype=torch.int32, device=self.device)
+        if head_out.dtype != torch.float32 or head_out.shape[0] != n or head_out.stride(1) != 1:
+            raise ValueError("head_out must be fp32 [n, stride] with unit inner stride")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_expand_state(self._h, C.c_void_p(rows.data_ptr()), int(rows.shape[1]), n, C.c_void_p(head_out.data_ptr()),
+                                                    int(head_out.stride(0)), C.c_void_p(nlegal_out.data_ptr()), C.c_void_p(region_out.data_ptr()),
+                                                    _stream_ptr(self.device)))
+        return head_out, nlegal_out, region_out
+
     def route_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the step kernel for the loaded regions."""
         n, lds = C.c_int32(0), C.c_int64(0)

@@ -33,6 +33,8 @@ hipError_t xr_launch_obs(const XrBatchDev*, float*, int64_t, int, int, int, int,
 hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*, int, float*, int, hipStream_t);
 hipError_t xr_launch_unit_helpers(const XrBatchDev*, int, hipStream_t);
 hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const int32_t*, int, float*, int64_t, int, hipStream_t);
+hipError_t xr_launch_pack_state(const XrBatchDev*, uint8_t*, int64_t, int, hipStream_t);
+hipError_t xr_launch_expand_state(const XrBatchDev*, const uint8_t*, int64_t, int, float*, int64_t, int32_t*, int32_t*, int, hipStream_t);
 }
 
 namespace {
@@ -1121,6 +1123,40 @@ int32_t xr_batch_net_planes(xr_batch* b, const int32_t* pair_region_dev, const i
     const bool aligned = (pair_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
     XR_HIP(xr_launch_netplanes_pairs(&b->dev, pair_region_dev, pair_net_dev, n_pairs, out_dev, pair_stride, aligned ? 1 : 0,
                                      static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_state_row_bytes(const xr_batch* b, int64_t* row_bytes) {
+    if (!b || !row_bytes) return fail(XR_ERR_INVALID, "xr_batch_state_row_bytes: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_state_row_bytes: load regions first");
+    *row_bytes = 16 + 8 * ((int64_t)b->legal_words + ((b->n_max + 63) >> 6));
+    return XR_OK;
+}
+
+int32_t xr_batch_pack_state(xr_batch* b, uint8_t* rows_dev, int64_t row_bytes, int32_t region_base, void* stream) {
+    if (!b || !rows_dev) return fail(XR_ERR_INVALID, "xr_batch_pack_state: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_pack_state: load regions first");
+    const int64_t need = 16 + 8 * ((int64_t)b->legal_words + ((b->n_max + 63) >> 6));
+    if (row_bytes < need || row_bytes % 8 != 0 || (reinterpret_cast<uintptr_t>(rows_dev) & 7) != 0 || region_base < 0)
+        return fail(XR_ERR_RANGE, "xr_batch_pack_state: row_bytes %lld (need >= %lld, a multiple of 8, 8-byte aligned rows), region_base %d",
+                    (long long)row_bytes, (long long)need, region_base);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    XR_HIP(xr_launch_pack_state(&b->dev, rows_dev, row_bytes, region_base, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_expand_state(xr_batch* b, const uint8_t* rows_dev, int64_t row_bytes, int32_t n_rows, float* head_out_dev, int64_t head_stride,
+                              int32_t* nlegal_out_dev, int32_t* region_out_dev, void* stream) {
+    if (!b || (n_rows > 0 && (!rows_dev || !head_out_dev || !nlegal_out_dev || !region_out_dev)))
+        return fail(XR_ERR_INVALID, "xr_batch_expand_state: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_expand_state: load regions first");
+    if (n_rows < 0 || row_bytes < 16 || row_bytes % 8 != 0 || (reinterpret_cast<uintptr_t>(rows_dev) & 7) != 0 || head_stride < (int64_t)2 * b->n_max_nodes)
+        return fail(XR_ERR_RANGE, "xr_batch_expand_state: n_rows %d, row_bytes %lld (a multiple of 8, 8-byte aligned rows), head_stride %lld < 2*n_max = %lld",
+                    n_rows, (long long)row_bytes, (long long)head_stride, (long long)2 * b->n_max_nodes);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    const bool aligned = (head_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(head_out_dev) & 15) == 0);
+    XR_HIP(xr_launch_expand_state(&b->dev, rows_dev, row_bytes, n_rows, head_out_dev, head_stride, nlegal_out_dev, region_out_dev, aligned ? 1 : 0,
+                                  static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 

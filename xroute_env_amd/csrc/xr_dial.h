@@ -40,6 +40,14 @@
 // Two placements: LDS_FIELD (field + bitmasks in LDS: 38.2 KB at 24x40x9, 4 workgroups per CU) and the HBM-scratch form
 // for large regions (see xr_dial_route_env_big below).
 #pragma once
+// XR-Maze v2's rip-up-and-reroute loop is computed as ONE attempt at the last attempt's penalty (proof: xr_dial3.h);
+// -DXR3_V2_ALL_ATTEMPTS keeps round 4's attempt-by-attempt form (same results)
+#ifdef XR3_V2_ALL_ATTEMPTS
+#define XR3_ALL_ATTEMPTS true
+#else
+#define XR3_ALL_ATTEMPTS false
+#endif
+
 
 #define XR_DIAL_INF 0xFFFFFFFFu
 #ifndef XR_DIAL_ASTAR
@@ -558,8 +566,13 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         return (guide4 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide4 : 0u;
     };
     // Rip-up and reroute: claims of an attempt are tentative (owner = -a) until the attempt stands
-    const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
+    const int16_t claim_val = (int16_t)(XR3_ALL_ATTEMPTS && V2 && b.maze_end_iter > 1 ? -a : a);      // (one attempt: its claims are final)
+#ifdef XR3_V2_ALL_ATTEMPTS
     int attempt = 0;
+#else           // the rip-up-and-reroute loop has one possible outcome: the last attempt's route (xr_dial3.h)
+    int attempt = V2 ? max(b.maze_end_iter, 1) - 1 : 0;
+    if (V2) pen4 <<= attempt;
+#endif
 
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     for (;;) {
@@ -1067,7 +1080,7 @@ __device__ __forceinline__ void xr_dial_route_env(const XrBatchDev& b, const int
         XR_LAP(4);
         // (the barrier at the top of the loop orders these writes before the next search / the exit test)
     }
-    if (!V2 || b.maze_end_iter <= 1) break;
+    if (!XR3_ALL_ATTEMPTS || !V2 || b.maze_end_iter <= 1) break;
     // ---- XR-Maze v2: does the attempt stand?  Its path uses a node held by another net and attempts are left: rip it up ----
     if (tid == 0) s_retry = (d_held > 0 && attempt + 1 < b.maze_end_iter) ? 1 : 0;
     __syncthreads();
@@ -1275,8 +1288,13 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
         if (!V2) return 0u;
         return (guide4 != 0u && !xr_guide_has(s_gbx, ngb, gb0, x, y, z)) ? guide4 : 0u;
     };
-    const int16_t claim_val = (int16_t)(V2 && b.maze_end_iter > 1 ? -a : a);
+    const int16_t claim_val = (int16_t)(XR3_ALL_ATTEMPTS && V2 && b.maze_end_iter > 1 ? -a : a);      // (one attempt: its claims are final)
+#ifdef XR3_V2_ALL_ATTEMPTS
     int attempt = 0;
+#else           // the rip-up-and-reroute loop has one possible outcome: the last attempt's route (xr_dial3.h)
+    int attempt = V2 ? max(b.maze_end_iter, 1) - 1 : 0;
+    if (V2) pen4 <<= attempt;
+#endif
 
     for (;;) {                                              // attempts (exactly one unless maze_end_iter > 1)
     for (;;) {
@@ -1678,7 +1696,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             xr_st(&wming[f >> 5], XR_DIAL_INF);
         }
     }
-    if (!V2 || b.maze_end_iter <= 1) break;
+    if (!XR3_ALL_ATTEMPTS || !V2 || b.maze_end_iter <= 1) break;
     // ---- XR-Maze v2: does the attempt stand?  Its path uses a node held by another net and attempts are left: rip it up ----
     if (tid == 0) s_retry = (d_held > 0 && attempt + 1 < b.maze_end_iter) ? 1 : 0;
     __syncthreads();

@@ -306,7 +306,19 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         __syncthreads();
     }
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
+    // XR-Maze v2's rip-up-and-reroute loop has ONE possible outcome: the LAST attempt's route (round 5; DESIGN.md §3.1 "the loop is one
+    // attempt").  If attempt t stands because its paths use no held node, attempt t + 1 would repeat it search by search: paths without a
+    // held node cost what they cost, every alternative through one only got dearer — same distances along them, same first tight
+    // predecessors, same targets (the argument behind round 4's "resume at the failed search", applied to a whole attempt) — and so would
+    // every later one, up to the last.  If no attempt stands, the last one is the result by definition.  So the route is computed once, at
+    // the penalty of the last attempt (pen << (maze_end_iter - 1)); the loop below never iterates.  -DXR3_V2_ALL_ATTEMPTS keeps the
+    // attempt-by-attempt form of round 4 (same results: the A/B and the proof by test).
+#ifdef XR3_V2_ALL_ATTEMPTS
     int attempt = 0;
+#else
+    int attempt = V2 ? max(b.maze_end_iter, 1) - 1 : 0;
+    if (V2) pen5 <<= attempt;
+#endif
 
     // per-lane constants of a quad: lane 4g + d relaxes direction d of quad g's node: 0 +planar, 1 -planar, 2 +z, 3 -z
     const int dir = lane & 3, qbase = lane & ~3;

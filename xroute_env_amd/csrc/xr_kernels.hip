@@ -1820,6 +1820,96 @@ __global__ void __launch_bounds__(256) xr_netplanes_pairs_kernel(XrBatchDev b, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compact state for a central learner (BASELINE config 4: "gather compact state and expand on the learner GPU").
+// The two planes of an observation that change per step are functions of very little: plane 0 ("blockage or used",
+// build_3Dgrid.py:19-36,94-103) is one BIT per node, plane 1 (the remaining nets' ids ascending at flat positions 0..K-1,
+// :144-161) IS the legal-net bitmask.  One row per env slot, fixed size, ready for ONE all_gather:
+//     int32 region (+ region_base: the sender's local region index as an index into the learner's region table)
+//     int32 nlegal | int32 legal_words | int32 occ_words
+//     uint64 legal[legal_words] | uint64 occ[occ_words]      bit f % 64 of word f / 64 = node f (flat observation order)
+// = 16 + 8·(legal_words + ceil(n_max / 64)) bytes: 1.1 KB for an ispd18_test1-sized region against 69 KB for the two fp32 planes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xr_pack_state_kernel(XrBatchDev b, uint8_t* __restrict__ rows, int64_t row_bytes, int region_base) {
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int r = b.env_region[e];
+    const XrRegionDev R = b.regions[r];
+    uint8_t* row = rows + (int64_t)e * row_bytes;
+    uint64_t* lg = reinterpret_cast<uint64_t*>(row + 16);
+    uint64_t* occ = lg + b.legal_words;
+    const int ow = (b.n_max + 63) >> 6;
+    if (tid == 0) {
+        int32_t* hdr = reinterpret_cast<int32_t*>(row);
+        hdr[0] = r + region_base; hdr[1] = b.nlegal[e]; hdr[2] = b.legal_words; hdr[3] = ow;
+    }
+    for (int w = tid; w < b.legal_words; w += 256) lg[w] = b.legal[(int64_t)e * b.legal_words + w];
+    // eight nodes per lane (two 16-byte loads), eight lanes per 64-bit word: a wave covers 512 nodes per pass
+    const int16_t* __restrict__ nn = b.rg_node_net + R.node_off;
+    const int16_t* __restrict__ own = b.owner + (int64_t)e * b.n_max;
+    const int nchunk = ow << 3;                       // chunks of 8 nodes in the row (the state rows are padded to multiples of 8)
+    const int cmax = (R.N + 7) >> 3;
+    for (int c = tid; c < ((nchunk + 255) & ~255); c += 256) {
+        uint32_t bits = 0;
+        if (c < cmax) {
+            const int4 vn = *reinterpret_cast<const int4*>(nn + (c << 3));
+            const int4 vo = *reinterpret_cast<const int4*>(own + (c << 3));
+            const uint32_t n4[4] = {(uint32_t)vn.x, (uint32_t)vn.y, (uint32_t)vn.z, (uint32_t)vn.w};
+            const uint32_t o4[4] = {(uint32_t)vo.x, (uint32_t)vo.y, (uint32_t)vo.z, (uint32_t)vo.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bits |= (uint32_t)(((n4[j] & 0xFFFFu) == 0xFFFFu) || (o4[j] & 0xFFFFu)) << (2 * j);
+                bits |= (uint32_t)(((n4[j] >> 16) == 0xFFFFu) || (o4[j] >> 16)) << (2 * j + 1);
+            }
+            const int left = R.N - (c << 3);
+            if (left < 8) bits &= (1u << left) - 1u;
+        }
+        uint64_t v = (uint64_t)bits << (8 * (lane & 7));
+        v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
+        if ((lane & 7) == 0 && (c >> 3) < ow) occ[c >> 3] = v;
+    }
+}
+
+// rows -> the fp32 head rows xr_batch_step_compact writes (planes 0..1, each env in its own region's layout), on the learner's device; `b` only
+// supplies the region table (the learner's batch holds every region of the job).  A row that does not parse (region index outside the table,
+// sizes that do not fit, a nets-left count that is not the popcount of its mask) is left unwritten and flagged nlegal = region = -1.
+__global__ void __launch_bounds__(256) xr_expand_state_kernel(XrBatchDev b, const uint8_t* __restrict__ rows, int64_t row_bytes, float* __restrict__ head,
+                                                            int64_t head_stride, int32_t* __restrict__ nlegal_out, int32_t* __restrict__ region_out, int vec4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_ids = reinterpret_cast<int*>(smem);
+    int* s_pref = s_ids + b.legal_words * 64;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* row = rows + (int64_t)i * row_bytes;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(row);
+    const int r = hdr[0], nl = hdr[1], lw = hdr[2], ow = hdr[3];
+    bool ok = r >= 0 && r < b.n_regions && lw >= 0 && lw <= b.legal_words && ow >= 0 && 16 + 8 * ((int64_t)lw + ow) <= row_bytes;
+    XrRegionDev R = b.regions[ok ? r : 0];
+    ok = ok && (int64_t)ow * 64 >= R.N && 2 * (int64_t)R.N <= head_stride;
+    const uint64_t* lg = reinterpret_cast<const uint64_t*>(row + 16);
+    const uint64_t* occ = lg + (ok ? lw : 0);
+    int K = 0;
+    if (ok) {                  // (uniform over the workgroup: every thread read the same header)
+        K = xr_legal_ids(lg, lw, s_ids, s_pref);
+        ok = K == nl && K <= R.n_nets && (K == 0 || s_ids[K - 1] <= R.n_nets);
+    }
+    if (tid == 0) { nlegal_out[i] = ok ? K : -1; region_out[i] = ok ? r : -1; }
+    if (!ok) return;
+    const int N = R.N;
+    float* __restrict__ o = head + (int64_t)i * head_stride;
+    if (vec4 && (N & 3) == 0) {
+        for (int f0 = tid * 4; f0 < N; f0 += 1024) {
+            const uint32_t m = (uint32_t)(occ[f0 >> 6] >> (f0 & 63)) & 15u;
+            XR_ST4(o + f0, make_float4((m & 1u) ? 1.f : 0.f, (m & 2u) ? 1.f : 0.f, (m & 4u) ? 1.f : 0.f, (m & 8u) ? 1.f : 0.f));
+            XR_ST4(o + N + f0, make_float4(f0 < K ? (float)s_ids[f0] : 0.f, f0 + 1 < K ? (float)s_ids[f0 + 1] : 0.f,
+                                           f0 + 2 < K ? (float)s_ids[f0 + 2] : 0.f, f0 + 3 < K ? (float)s_ids[f0 + 3] : 0.f));
+        }
+    } else {
+        for (int f = tid; f < N; f += 256) {
+            o[f] = ((occ[f >> 6] >> (f & 63)) & 1ull) ? 1.f : 0.f;
+            o[N + f] = f < K ? (float)s_ids[f] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers (kept here so that only this TU needs the <<<>>> syntax)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -2047,6 +2137,20 @@ hipError_t xr_launch_netplanes_pairs(const XrBatchDev* b, const int32_t* pair_re
                                      float* out, int64_t pair_stride, int vec4, hipStream_t st) {
     if (n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(xr_netplanes_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, *b, pair_region, pair_net, out, pair_stride, vec4);
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_pack_state(const XrBatchDev* b, uint8_t* rows, int64_t row_bytes, int region_base, hipStream_t st) {
+    if (b->n_envs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xr_pack_state_kernel, dim3(b->n_envs), dim3(256), 0, st, *b, rows, row_bytes, region_base);
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_expand_state(const XrBatchDev* b, const uint8_t* rows, int64_t row_bytes, int n_rows, float* head, int64_t head_stride,
+                                  int32_t* nlegal_out, int32_t* region_out, int vec4, hipStream_t st) {
+    if (n_rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)(b->legal_words * 64 + b->legal_words + 1) * sizeof(int);
+    hipLaunchKernelGGL(xr_expand_state_kernel, dim3(n_rows), dim3(256), lds, st, *b, rows, row_bytes, head, head_stride, nlegal_out, region_out, vec4);
     return hipGetLastError();
 }
 
