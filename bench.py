@@ -1050,21 +1050,26 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     if not learner:
         _head_of(batch, head)
 
-    # ---- stagger: every env to a uniform phase of its episode (untimed, random actions, route-only) ---------------------------------
-    stagger = None
+    # ---- stagger: every env to a uniform phase of its episode (untimed, random actions, route-only).  The random net-order policy is keyed
+    # by the GLOBAL env id (dist.random_legal_policy), so the state every env starts the measured steps from does not depend on the sharding;
+    # the pre-roll's actions are part of the log the oracle replays
+    n_pre = 0
+    pre_log = None
     if not args.no_stagger:
+        from xroute_env_amd.dist import random_legal_policy, unpack_records
         off = stagger_offsets(batch.fetch("nlegal").cpu().numpy(), first_env)
         off_d = torch.from_numpy(off).to(dev)
         mx = torch.tensor([int(off.max()) if B else 0], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        pre_seeds = [args.seed ^ 0xA6E7 ^ i for i in range(int(mx.item()))]          # (the same list on every rank: one oracle replay recipe)
+        n_pre = int(mx.item())
+        pre_log = torch.zeros((max(n_pre, 1), B), dtype=torch.int32, device=dev)
         zero = torch.zeros_like(acts)
-        for i, sd in enumerate(pre_seeds):
-            batch.random_actions(sd, acts)
-            torch.where(off_d > i, acts, zero, out=acts)
+        for i in range(n_pre):
+            a_ = random_legal_policy(unpack_records(batch.fetch("record")), batch.fetch("legal"), args.seed ^ 0xA6E7 ^ i, env_ids=env_ids)
+            torch.where(off_d > i, a_, zero, out=acts)
+            pre_log[i].copy_(acts)
             batch.step(acts)
-        stagger = (off, pre_seeds)
         if not learner:
             _head_of(batch, head)
 
@@ -1182,9 +1187,9 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     actions_sha = hashlib.sha256(al.cpu().numpy().tobytes()).hexdigest()
     chains_sha = hashlib.sha256(hs.cpu().numpy().tobytes()).hexdigest()
     try:
-        seeds = list(range(nsteps_total))
-        parity = parity_check(slot_regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
-                              actions_log=acts_log.cpu().numpy(), v2=v2 or None, head_only=True)
+        full_log = torch.cat([pre_log[:n_pre], acts_log]) if n_pre else acts_log
+        parity = parity_check(slot_regions, list(range(full_log.shape[0])), None, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
+                              actions_log=full_log.cpu().numpy(), v2=v2 or None, head_only=True)
         parity["what"] = ("CPU oracle replay of the actions the POLICY chose (stagger pre-roll + warm-up + timed steps) on the first envs of the rank: "
                           "hash chains, cumulative metrics" + ("" if learner else ", sha256 of planes 0..1 the last compact step wrote vs the oracle's build_3Dgrid restatement"))
     except Exception as ex:

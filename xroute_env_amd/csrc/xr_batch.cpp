@@ -34,6 +34,7 @@ hipError_t xr_launch_obs_records(const uint32_t*, int, int, int, const int32_t*,
 hipError_t xr_launch_unit_helpers(const XrBatchDev*, int, hipStream_t);
 hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const int32_t*, int, float*, int64_t, int, hipStream_t);
 hipError_t xr_launch_pack_state(const XrBatchDev*, uint8_t*, int64_t, int, hipStream_t);
+hipError_t xr_launch_guide_masks(const XrBatchDev*, uint8_t*, int, hipStream_t);
 hipError_t xr_launch_expand_state(const XrBatchDev*, const uint8_t*, int64_t, int, float*, int64_t, int32_t*, int32_t*, int, hipStream_t);
 }
 
@@ -111,6 +112,8 @@ struct xr_batch {
     DevBuf<int16_t> ap_pin;
     DevBuf<int32_t> guide_csr;            // XR-Maze v2, optional (xr_batch_load_guides): boxes of (region, net), indexed like net_csr
     DevBuf<int16_t> guide_box;
+    DevBuf<uint8_t> guide_mask;           // XR-Maze v2 with guide_cost > 0: static "outside the guide" bitmasks of every (region, net) (build_guide_masks)
+    size_t guide_mask_bytes = 0;
     std::vector<int32_t> h_net_off, h_n_nets, h_dims;   // per region: R.net_off, n_nets, (X, Y, Z) — what xr_batch_load_guides validates against
     size_t h_csr_size = 0;
     DevBuf<uint64_t> legal0;
@@ -248,6 +251,8 @@ int32_t xr_batch_destroy(xr_batch* b) {
     return XR_OK;
 }
 
+static int32_t build_guide_masks(xr_batch* b, hipStream_t st);
+
 int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n_regions, void* stream) {
     if (!b || !regs || n_regions < 1) return fail(XR_ERR_INVALID, "xr_batch_load_regions: bad argument");
     XR_HIP(hipSetDevice(b->cfg.device));
@@ -259,7 +264,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     b->obs_valid_ptr = nullptr;
     b->n_cus = 0;
     b->route_slots = 0;
-    b->guide_csr.release(); b->guide_box.release();        // guides belong to the regions they were loaded for
+    b->guide_csr.release(); b->guide_box.release(); b->guide_mask.release(); b->guide_mask_bytes = 0;        // guides belong to the regions they were loaded for
     memset(&b->dev, 0, sizeof(b->dev));
 
     std::vector<XrRegionDev> hreg(n_regions);
@@ -291,6 +296,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         return found;
     };
     int n_max_nodes = 0, k_max = 0, x_max = 0, y_max = 0, n_lds = 0, tracks_max = 0, lines_max = 0, bits_max = 0, z_min = 1 << 30, z_max = 0, ncol_max = 0;
+    size_t gmask_bytes = 0;        // XR-Maze v2: bytes of the static guide masks of every (region, net) (XrRegionDev::gmask_off)
     bool mult4 = true;
     for (int r = 0; r < n_regions; r++) {
         const xr_region_desc& d = regs[r];
@@ -335,6 +341,10 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         R.ys_off = (int32_t)hcoords.size();
         hcoords.insert(hcoords.end(), d.ys_host, d.ys_host + d.dim_y);
         // node records, padded to a multiple of 8 elements so that int16 planes stay 16-byte aligned
+        R.gmask_off = (int64_t)gmask_bytes;
+        R.gmask_stride = (int32_t)((((size_t)N + 7) / 8 + 15) & ~(size_t)15);
+        R.pad0 = 0;
+        gmask_bytes += (size_t)R.gmask_stride * (size_t)std::max(d.n_nets, 0);
         R.node_off = (int64_t)hrec.size();
         hrec.insert(hrec.end(), d.nodes_host, d.nodes_host + N);
         while (hrec.size() % 8) hrec.push_back(XR_TYPE_NORMAL);
@@ -809,6 +819,28 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     }
     b->h_csr_size = hcsr.size();
     b->loaded = true;
+    b->guide_mask_bytes = gmask_bytes;
+    d.guide_csr = nullptr; d.guide_box = nullptr;
+    return build_guide_masks(b, st);          // (the default guides: bounding box of every net's access points)
+}
+
+// XR-Maze v2 with guide_cost > 0 and the round-3 LDS router: the guide of every (region, net) as a static bitmask (xr_guide_mask_kernel) — from the
+// boxes loaded last (xr_batch_load_guides) or the default guides.  Without it (no guide cost, another router form, or more than 2 GiB of masks)
+// dev.guide_mask stays null and the router decides membership per route as before.
+static int32_t build_guide_masks(xr_batch* b, hipStream_t st) {
+    b->dev.guide_mask = nullptr;
+    const char* off = getenv("XR_NO_GUIDE_MASK");       // (A/B switch: membership per route, round 4's form; results are the same)
+    if (b->cfg.guide_cost <= 0 || b->kzch != -4 || b->guide_mask_bytes == 0 || b->guide_mask_bytes > ((size_t)1 << 31) || (off && off[0] == '1')) {
+        b->guide_mask.release();
+        return XR_OK;
+    }
+    if (b->guide_mask.n != b->guide_mask_bytes && b->guide_mask.alloc(b->guide_mask_bytes) != hipSuccess) {
+        b->guide_mask.release();
+        return XR_OK;                    // (no memory for the masks: the per-route form still applies)
+    }
+    XR_HIP(xr_launch_guide_masks(&b->dev, b->guide_mask.p, b->k_max, st));
+    XR_HIP(hipStreamSynchronize(st));
+    b->dev.guide_mask = b->guide_mask.p;
     return XR_OK;
 }
 
@@ -821,7 +853,7 @@ int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, co
     XR_HIP(hipSetDevice(b->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     b->dev.guide_csr = nullptr; b->dev.guide_box = nullptr;
-    if (!box_off_host) { b->guide_csr.release(); b->guide_box.release(); return XR_OK; }      // back to the default guides
+    if (!box_off_host) { b->guide_csr.release(); b->guide_box.release(); return build_guide_masks(b, st); }      // back to the default guides
     std::vector<int32_t> csr(b->h_csr_size, 0);
     std::vector<int16_t> box;
     for (int r = 0; r < b->n_regions; r++) {
@@ -851,7 +883,7 @@ int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, co
     if (!box.empty()) XR_HIP(hipMemcpyAsync(b->guide_box.p, box.data(), box.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
     XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here
     b->dev.guide_csr = b->guide_csr.p; b->dev.guide_box = b->guide_box.p;
-    return XR_OK;
+    return build_guide_masks(b, st);
 }
 
 int32_t xr_batch_assign(xr_batch* b, const int32_t* env_region_host) {

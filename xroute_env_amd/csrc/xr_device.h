@@ -51,6 +51,11 @@ struct XrRegionDev {
     // keeps round 2's form)
     uint32_t m24_yz, m24_z, m24_mw;
     uint32_t s24;          // shift of yz | z << 8 | mw << 16 | div24_ok << 24
+    // XR-Maze v2: static guide masks (XrBatchDev::guide_mask, round 5): net n (1-based) of this region at byte gmask_off + (n - 1) * gmask_stride,
+    // bit j of byte c = node 8 c + j lies OUTSIDE the net's guide
+    int64_t gmask_off;
+    int32_t gmask_stride;  // ((N + 7) / 8 rounded up to 16 bytes)
+    int32_t pad0;
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over global memory too: the wave first waits for
@@ -97,6 +102,9 @@ struct XrBatchDev {
                              // pin boxes of the search heuristic the access point's pin belongs to (xr_dial3.h)
     const int32_t* guide_csr; // [like net_csr] XR-Maze v2, optional (null: none): boxes of net n are [guide_csr[n], guide_csr[n + 1]) of guide_box
     const int16_t* guide_box; // [boxes][6] x0, y0, x1, y1, z0, z1 (track / layer indices, inclusive)
+    const uint8_t* guide_mask; // XR-Maze v2 with guide_cost > 0 (null: none): "outside the guide" of every (region, net) as a bitmask over the nodes, built
+                              // once per guide load (xr_guide_mask_kernel) — guide membership is static, so a route reads 1 bit per node with its grid
+                              // build instead of testing up to 8 boxes per node in a pass of its own (XrRegionDev::gmask_off)
     int32_t n_regions;
     // envs (mutable)
     int32_t n_envs;

@@ -183,11 +183,16 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
     const int first_pin = ninfo & 0x3FFF, npins = (ninfo >> 14) & 0xFF;
     const int n_isolated = (ninfo >> 30) & 1 ? npins - 1 : (ninfo >> 22) & 0xFF;      // unreachable pins known up front
 
+    // XR-Maze v2, guide membership (round 5): a static bit per node of this (region, net) — "outside the guide" — read with the grid build:
+    // one byte per chunk of 8 nodes, in flight with the chunk's state loads (round 4: the net's boxes fetched per route by two dependent
+    // global loads and tested in a pass of their own).  Null: no static masks (xr_batch.cpp build_guide_masks) -> the pass below.
+    const uint8_t* __restrict__ gmrow = (V2 && b.guide_cost && b.guide_mask) ? b.guide_mask + R.gmask_off + (int64_t)(a - 1) * R.gmask_stride : nullptr;
     // ---- grid build: field word of every node for THIS net (16-byte loads of node_net / owner, four chunks in flight) ----
     auto build_field = [&]() __attribute__((always_inline)) {
         const int nchunk = (N + 7) >> 3;
         for (int c0 = tid; c0 < nchunk; c0 += 4 * nthr) {
             int4 vn[4], vo[4];
+            uint32_t gm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int ci = c0 + u * nthr;
@@ -196,6 +201,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
                                                               //  starts on a 16-byte boundary of the rows: wy0 is a multiple of win_ystep)
                     vn[u] = *reinterpret_cast<const int4*>(node_net + g0);
                     vo[u] = *reinterpret_cast<const int4*>(owner + g0);
+                    if (V2 && gmrow) gm[u] = gmrow[ci];
                 }
             }
 #pragma unroll
@@ -209,7 +215,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
                 for (int j = 0; j < 8; j++) {
                     const int nn = (int)(short)((j & 1) ? (pn[j >> 1] >> 16) : (pn[j >> 1] & 0xFFFF));
                     const int ow = (int)(short)((j & 1) ? (po[j >> 1] >> 16) : (po[j >> 1] & 0xFFFF));
-                    const uint32_t ww = (V2 ? XR3_UNREACHED_V2 : XR3_UNREACHED) | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
+                    const uint32_t ww = (V2 ? (XR3_UNREACHED_V2 | ((gm[u] >> j) & 1u)) : XR3_UNREACHED) | (((ow != 0 && ow != a) || (nn > 0 && nn != a)) ? 2u : 0u);
                     w[j] = (nn == -1 || f0 + j >= N) ? 0u : ww;
                 }
                 uint4* dst = reinterpret_cast<uint4*>(field + f0);
@@ -231,7 +237,8 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
     for (int i = tid + nthr; i <= Y + 1; i += nthr)
         s_tab[XO + i] = (uint32_t)(b.coords[R.ys_off + min(wy0 + i - 1, RY - 1)] - cby) << 5;
     if (tid == 0) { s_gb[0] = 0x7FFFFFFF; s_gb[1] = -1; s_gb[2] = 0x7FFFFFFF; s_gb[3] = -1; }
-    if (V2 && b.guide_cost) __syncthreads();
+    const bool guide_pass = V2 && b.guide_cost && !gmrow;        // (uniform) membership decided per route: only without the static masks
+    if (guide_pass) __syncthreads();
     for (int i = tid; i < nap; i += nthr) {
         const int pin = i < nthr ? my_ap_pin : (int)b.ap_pin[R.ap_off + ap_lo + i];
         const int apf = i < nthr ? my_ap_f : b.ap_node[R.ap_off + ap_lo + i];
@@ -241,7 +248,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         s_ap_conn[i] = (unsigned char)((iso & 1) ? 2 : (pin == first_pin ? 1 : 0));
         s_ap_slot[i] = (unsigned char)((iso >> 1) & 3);
         s_ap_own[i] = (unsigned char)((i < nthr ? my_ap_own : (int)owner[apf]) != 0);
-        if (V2 && b.guide_cost) {                // XR-Maze v2: the net's guide = bounding box of all its access points (+ margin)
+        if (guide_pass) {                        // XR-Maze v2: the net's default guide = bounding box of all its access points (+ margin)
             const int gy = (apf / Z) % Y, gx = apf / YZ;
             atomicMin(&s_gb[0], gx); atomicMax(&s_gb[1], gx); atomicMin(&s_gb[2], gy); atomicMax(&s_gb[3], gy);
         }
@@ -270,7 +277,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         xr3_divmod(ur, uZ, m24_z, sh_z, uy, uz);
         x = (int)ux; y = (int)uy; z = (int)uz;
     };
-    if (V2 && b.guide_cost) {
+    if (guide_pass) {
         // ---- guide membership as data (round 4): ONE pass over the nodes sets bit 0 of every word outside the net's guide (<= 8 box
         // tests per node, boxes unpacked once per 8-node chunk); a hop and a trace step then test a bit of a word they load anyway.
         xr_guide_load(b, R, a, s_gb, Z, s_gbx, &s_ngb, tid);

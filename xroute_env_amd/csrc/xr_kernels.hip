@@ -1820,6 +1820,47 @@ __global__ void __launch_bounds__(256) xr_netplanes_pairs_kernel(XrBatchDev b, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// XR-Maze v2: the guide of every (region, net) as a static bitmask (round 5).  Whether a node lies inside a net's guide — the boxes
+// xr_batch_load_guides handed over, inflated by guide_margin, or the bounding box of the net's access points when it has none
+// (xr_guide_load) — never changes while the regions are loaded, yet round 4's router decided it per ROUTE: two dependent
+// global loads for the boxes and a pass over the nodes with up to 8 box tests each (~13 % of a route on the design-derived pack).  One
+// workgroup per (region, net), once per guide load: bit j of byte c = node 8 c + j is OUTSIDE the guide.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xr_guide_mask_kernel(XrBatchDev b, uint8_t* __restrict__ masks) {
+    __shared__ int s_bb[4], s_ngb;
+    __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];
+    const int r = blockIdx.y, a = blockIdx.x + 1, tid = threadIdx.x;
+    const XrRegionDev R = b.regions[r];
+    if (a > R.n_nets) return;
+    const int Y = R.Y, Z = R.Z, YZ = Y * Z, N = R.N;
+    if (tid == 0) { s_bb[0] = 0x7FFFFFFF; s_bb[1] = -1; s_bb[2] = 0x7FFFFFFF; s_bb[3] = -1; }
+    __syncthreads();
+    const int lo = b.net_csr[R.net_off + a], hi = b.net_csr[R.net_off + a + 1];
+    for (int i = lo + tid; i < hi; i += 256) {
+        const int apf = b.ap_node[R.ap_off + i];
+        const int gy = (apf / Z) % Y, gx = apf / YZ;
+        atomicMin(&s_bb[0], gx); atomicMax(&s_bb[1], gx); atomicMin(&s_bb[2], gy); atomicMax(&s_bb[3], gy);
+    }
+    __syncthreads();
+    xr_guide_load(b, R, a, s_bb, Z, s_gbx, &s_ngb, tid);
+    __syncthreads();
+    const int ngb = s_ngb;
+    const int4 g0 = s_gbx[0];
+    uint8_t* __restrict__ row = masks + R.gmask_off + (int64_t)(a - 1) * R.gmask_stride;
+    for (int c = tid; c < R.gmask_stride; c += 256) {
+        uint32_t out = 0;
+        for (int j = 0; j < 8; j++) {
+            const int f = (c << 3) + j;
+            if (f < N) {
+                const int z = f % Z, y = (f / Z) % Y, x = f / YZ;
+                out |= (uint32_t)(!xr_guide_has(s_gbx, ngb, g0, x, y, z)) << j;
+            }
+        }
+        row[c] = (uint8_t)out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compact state for a central learner (BASELINE config 4: "gather compact state and expand on the learner GPU").
 // The two planes of an observation that change per step are functions of very little: plane 0 ("blockage or used",
 // build_3Dgrid.py:19-36,94-103) is one BIT per node, plane 1 (the remaining nets' ids ascending at flat positions 0..K-1,
@@ -2137,6 +2178,12 @@ hipError_t xr_launch_netplanes_pairs(const XrBatchDev* b, const int32_t* pair_re
                                      float* out, int64_t pair_stride, int vec4, hipStream_t st) {
     if (n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(xr_netplanes_pairs_kernel, dim3(n_pairs), dim3(256), 0, st, *b, pair_region, pair_net, out, pair_stride, vec4);
+    return hipGetLastError();
+}
+
+hipError_t xr_launch_guide_masks(const XrBatchDev* b, uint8_t* masks, int k_max, hipStream_t st) {
+    if (b->n_regions <= 0 || k_max <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xr_guide_mask_kernel, dim3(k_max, b->n_regions), dim3(256), 0, st, *b, masks);
     return hipGetLastError();
 }
 

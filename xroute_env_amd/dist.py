@@ -150,15 +150,18 @@ def first_legal_policy(records: dict, legal: torch.Tensor) -> torch.Tensor:
     return torch.where(has, first, torch.zeros_like(first))
 
 
-def random_legal_policy(records: dict, legal: torch.Tensor, seed: int) -> torch.Tensor:
+def random_legal_policy(records: dict, legal: torch.Tensor, seed: int, env_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Random net-order policy over gathered state, in torch ops on the learner's device: a uniformly chosen legal net
-    of every env (0 when none) from a counter-based hash of (seed, env, env_steps) — reproducible, no host sync."""
+    of every env (0 when none) from a counter-based hash of (seed, env, env_steps) — reproducible, no host sync.
+    `env_ids` (int64 [n]): the GLOBAL id of every row (default: its index) — a rank that evaluates this on its own shard then chooses
+    what a one-process run chooses for the same env."""
     n, words = legal.shape
     dev = legal.device
     bits = torch.arange(64, device=dev, dtype=torch.int64)
     m = ((legal.unsqueeze(-1) >> bits) & 1).reshape(n, words * 64)            # [n, 64*words] 0/1
     k = m.sum(dim=1)
-    x = (torch.arange(n, device=dev, dtype=torch.int64) * 0x100000001B3 + records["env_steps"].to(torch.int64)) ^ int(seed)
+    ids = torch.arange(n, device=dev, dtype=torch.int64) if env_ids is None else env_ids.to(device=dev, dtype=torch.int64)
+    x = (ids * 0x100000001B3 + records["env_steps"].to(torch.int64)) ^ int(seed)
     x = (x ^ (x >> 30) & 0x3FFFFFFFF) * 0x3F58476D1CE4E5B9
     x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * 0x14D049BB133111EB
     j = (x & 0x7FFFFFFF) % torch.clamp(k, min=1)
