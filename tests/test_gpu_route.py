@@ -528,3 +528,45 @@ def test_router_fuzz_against_the_oracle():
     spec.loader.exec_module(mod)
     steps, tally = mod.run(40, 5)
     assert steps > 1500 and len(tally) >= 6, (steps, tally)
+
+
+def test_measured_launch_order_and_static_guide_masks_never_change_results():
+    """Round 5: (i) launch orders use the MEASURED cost of a (region, net) — written by every route's epilogue — in place of the geometric guess
+    once there is one; (ii) XR-Maze v2 reads guide membership from static per-(region, net) bitmasks built at load.  Both are performance
+    devices: twins with the switches off (XR_NO_MEASURED_ORDER / XR_NO_GUIDE_MASK, read when the regions are loaded) produce the same records,
+    owners and hash chains over episodes that replay their regions — and the measured order really is another order than the guess."""
+    import os
+    from tests.helpers import GOLDEN
+    from xroute_env_amd import lefdef
+    from xroute_env_amd.batch import RegionBatch
+    pack = lefdef.load_region_pack(os.path.join(GOLDEN, "ispd18_test1_regions.npz"))[:24]
+    B = 96
+    kw = dict(n_envs=B, device="cuda:0", auto_reset=True, max_route_count=1 << 30, launch_order=2, guide_cost=800, guide_margin=1, maze_end_iter=3)
+
+    def make(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            b = RegionBatch(pack, **kw)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        b.reset()
+        return b
+    a, plain, nomask = make(), make(XR_NO_MEASURED_ORDER="1"), make(XR_NO_GUIDE_MASK="1")
+    acts = torch.empty(B, dtype=torch.int32, device="cuda:0")
+    differs = 0
+    for it in range(40):                       # ~3 episodes per slot: every (region, net) is routed, measured, and asked for again
+        a.random_actions(400 + it, acts)
+        for b in (a, plain, nomask):
+            b.step(acts)
+        assert torch.equal(a.fetch("record"), plain.fetch("record")) and torch.equal(a.fetch("record"), nomask.fetch("record")), it
+        oa, op = a.fetch("route_order").cpu().numpy(), plain.fetch("route_order").cpu().numpy()
+        assert sorted(oa.tolist()) == list(range(B)) and sorted(op.tolist()) == list(range(B))
+        differs += int(not np.array_equal(oa, op))
+    for b in (plain, nomask):
+        assert torch.equal(a.fetch("hash"), b.fetch("hash")) and torch.equal(a.fetch("owner"), b.fetch("owner")) and torch.equal(a.fetch("cum"), b.fetch("cum"))
+    assert differs >= 20, differs

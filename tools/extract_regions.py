@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extract per-GCell regions from a LEF/DEF/guide triple (xroute_env_amd/lefdef.py) into a compact region pack.
 
-    python tools/extract_regions.py --out tests/golden/ispd18_test1_regions.npz --count 256 --stride 16
+    python tools/extract_regions.py --out tests/golden/ispd18_test1_regions.npz --count 256 --stride 12     # (the committed pack: --stride 16 yields 206 regions)
 
 Default inputs are the reference's ispd18_test1 files (build container only).  The pack is DATA derived from the
 reference's benchmark input files (tracks, placed pin / obstruction shapes, guides), not source."""

@@ -119,7 +119,7 @@ struct xr_batch {
     DevBuf<uint64_t> legal0;
     // envs
     DevBuf<int32_t> env_region, env_replay, nlegal, cum, delta, status, path, path_len, sweeps, touched, route_order;
-    DevBuf<uint8_t> net_work;
+    DevBuf<uint8_t> net_work, net_meas;
     int route_slots = 0;         // workgroups of the route kernel the chip holds at once (0: not asked yet)
     DevBuf<int16_t> owner;
     DevBuf<uint64_t> legal, hash;
@@ -701,6 +701,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     XR_ALLOC(b->touched, B);
     XR_ALLOC(b->route_order, B);
     XR_ALLOC(b->net_work, hcsr.size());
+    XR_ALLOC(b->net_meas, hcsr.size());
     XR_ALLOC(b->net_info, hcsr.size());
     XR_ALLOC(b->ap_flags, std::max<size_t>(1, hap_flags.size()));
     XR_ALLOC(b->owner, (size_t)B * b->n_max);
@@ -741,6 +742,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
             if (hwork[i] > 0.0f) hclass[i] = (uint8_t)(1 + std::min(254, (int)(254.0f * hwork[i] / wmax)));
     }
     XR_HIP(hipMemcpyAsync(b->net_work.p, hclass.data(), hclass.size(), hipMemcpyHostToDevice, st));
+    XR_HIP(hipMemsetAsync(b->net_meas.p, 0, hcsr.size(), st));                  // nothing measured yet: the launch orders use the geometric guess
     hinfo.resize(hcsr.size(), 0);
     XR_HIP(hipMemcpyAsync(b->net_info.p, hinfo.data(), hinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (!hap_flags.empty()) XR_HIP(hipMemcpyAsync(b->ap_flags.p, hap_flags.data(), hap_flags.size(), hipMemcpyHostToDevice, st));
@@ -781,7 +783,12 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
 
     XrBatchDev& d = b->dev;
     d.regions = b->regions.p; d.rg_rec = b->rg_rec.p; d.rg_node_net = b->rg_node_net.p; d.rg_owner0 = b->rg_owner0.p;
-    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p; d.net_work = b->net_work.p; d.net_info = b->net_info.p; d.ap_flags = b->ap_flags.p;
+    d.coords = b->coords.p; d.net_csr = b->net_csr.p; d.ap_node = b->ap_node.p; d.ap_pin = b->ap_pin.p; d.ap_feat = b->ap_feat.p; d.net_work = b->net_work.p; d.net_info = b->net_info.p;
+    {   // measured launch order (round 5): on unless XR_NO_MEASURED_ORDER=1 (A/B switch; results never depend on the order)
+        const char* off = getenv("XR_NO_MEASURED_ORDER");
+        d.net_meas = (off && off[0] == '1') ? nullptr : b->net_meas.p;
+        d.meas_shift = b->lds_dist ? 13 : 15;       // class unit: 8 k cycles (LDS form: a route is 0.1-1.5 M cycles), 32 k (HBM-scratch form: up to 6 M)
+    } d.ap_flags = b->ap_flags.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
     d.n_envs = B; d.n_max = b->n_max; d.n_lds = b->n_lds; d.lw_max = (int)lw_max; d.lines_max = lines_max; d.x_max = x_max; d.y_max = y_max; d.legal_words = legal_words; d.path_cap = b->path_cap;
     d.env_region = b->env_region.p; d.env_replay = b->env_replay.p; d.owner = b->owner.p; d.legal = b->legal.p;

@@ -96,6 +96,11 @@ struct XrBatchDev {
     const int32_t* ap_feat;  // node index | (the access point has an axis neighbour that is an access point of the same net) << 31
     const uint64_t* legal0;
     const uint8_t* net_work; // [like net_csr] predicted route work class of net n of a region (1..255; 0 = no access points), static
+    uint8_t* net_meas;       // [like net_csr] MEASURED route work class of net n of a region (0 = never routed yet): written by every route's epilogue
+                             // (cycles of the route >> meas_shift, clamped to 1..255), read by the launch orders in place of the geometric guess
+                             // net_work — regions replay (10 episodes each, then they come round again), so after one episode every heavy net
+                             // is known for what it costs, whatever made it heavy (null: off)
+    int32_t meas_shift;
     const int32_t* net_info; // [like net_csr] static facts of net n: lowest pin id (pin + 1, 14 bits) | distinct pins << 14 | pins in closed
                              // pockets (never reachable) << 22 | the lowest pin itself is in one << 30   (xr_dial3.h)
     const uint8_t* ap_flags; // [like ap_node] bit 0: the access point's pin sits in a closed pocket (isolated); bits 1..2: which of the three

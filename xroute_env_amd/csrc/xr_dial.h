@@ -103,6 +103,10 @@ __device__ __forceinline__ uint32_t xr_wave_min_u32(uint32_t v) {
 
 // Prologue shared by both routers: auto-reset of a finished env, action validity (uniform over the workgroup).
 // Returns true when net `a` is to be routed.
+// (measured launch order, round 5) when the route began and which (region, net) it is: written by thread 0 of the prologue, read by the one
+// thread that runs the epilogue — every router form has workgroup barriers in between
+__shared__ long long xr_s_route_t0;
+__shared__ int xr_s_route_net;
 __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int e, const int a) {
     const int tid = threadIdx.x;
     // the three loads that depend on (e, a) only are issued together: a route is ~70 us and every dependent global round trip
@@ -123,6 +127,7 @@ __device__ __forceinline__ bool xr_step_prologue(const XrBatchDev& b, const int 
         return false;
     }
     const bool valid = a_in_words && a <= b.regions[r0].n_nets && ((lw0 >> ((a - 1) & 63)) & 1ULL);
+    if (valid && tid == 0 && b.net_meas) { xr_s_route_t0 = (long long)__builtin_readcyclecounter(); xr_s_route_net = b.regions[r0].net_off + a; }
     if (!valid) {   // the reference never checks this client-side; here: flagged no-op
         if (tid == 0) {
             b.status[e] = XR_ENV_BAD_ACTION;
@@ -158,6 +163,11 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
     b.path_len[e] = plen;
     b.sweeps[e] = nrounds;
     b.touched[e] = ntouched;
+    if (b.net_meas) {          // what this route cost, for the launch orders of the next time this (region, net) is asked for
+        const long long dt = (long long)__builtin_readcyclecounter() - xr_s_route_t0;
+        const int cls = (int)min((dt >> b.meas_shift) + 1ll, 255ll);
+        b.net_meas[xr_s_route_net] = (uint8_t)max(cls, 1);
+    }
     fnv_mix(h, (uint32_t)a);
     fnv_mix(h, (uint32_t)d_vio); fnv_mix(h, (uint32_t)d_wl); fnv_mix(h, (uint32_t)d_via);
     fnv_mix(h, (uint32_t)plen);

@@ -1218,7 +1218,8 @@ __device__ __forceinline__ int xr_route_work_class(const XrBatchDev& b, const in
     const XrRegionDev& R = b.regions[b.env_region[e]];
     if (a < 1 || a > R.n_nets || b.done[e]) return 0;
     if (!((b.legal[(int64_t)e * b.legal_words + ((a - 1) >> 6)] >> ((a - 1) & 63)) & 1ull)) return 0;
-    return b.net_work[R.net_off + a];
+    if (b.net_meas) { const int m = b.net_meas[R.net_off + a]; if (m) return m; }          // measured the last time this (region, net) was routed
+    return b.net_work[R.net_off + a];                                                          // the geometric guess (extent x (6 + pins))
 }
 
 __global__ void __launch_bounds__(1024) xr_route_order_kernel(XrBatchDev b, const int32_t* __restrict__ actions, int32_t* __restrict__ order) {
