@@ -1012,11 +1012,11 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
             pol_batch = RegionBatch(pol_regions, n_envs=1, device=dev)
     evaluates = (not learner) or rank == 0
     n_rows = Bg if learner else B
-    rb = batch.state_row_bytes()
-    if learner and world > 1:
-        t_rb = torch.tensor([max(rb, pol_batch.state_row_bytes())], dtype=torch.int64, device=dev)
-        dist.all_reduce(t_rb, op=dist.ReduceOp.MAX)
-        rb = int(t_rb.item())
+    xch = None
+    if learner:
+        from xroute_env_amd.dist import CompactStateExchange
+        xch = CompactStateExchange(batch, Bg, first_env, region_base=region_base, learner_batch=pol_batch)
+    rb = xch.row_bytes if learner else 0
     head = nl = reg = None
     grouped = cache = tower = head_k = None
     if evaluates:
@@ -1033,8 +1033,6 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
             head_k = agents.FusedActorHead(model.actor, dev)
             cache.prefill(model.representation_network, [r.n_nets for r in pol_regions], pol_batch.net_planes, dims)
     row_ids = torch.arange(Bg, dtype=torch.int64, device=dev) if learner else env_ids
-    rows_local = torch.empty((B, rb), dtype=torch.uint8, device=dev) if learner else None
-    rows_all = torch.empty((Bg, rb), dtype=torch.uint8, device=dev) if learner and world > 1 and Bg % world == 0 else None
     acts_all = torch.zeros(Bg, dtype=torch.int32, device=dev) if learner else None
 
     def policy(i):
@@ -1085,18 +1083,10 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
         mark = (lambda j: ev[j].record()) if ev else (lambda j: None)
         mark(0)
         if learner:
-            batch.pack_state(rows_local, region_base=region_base)
-            if world > 1:
-                rows = rows_all if rows_all is not None else None
-                if rows is not None:
-                    dist.all_gather_into_tensor(rows, rows_local)          # the compact-state gather: Bg x row_bytes per step
-                else:
-                    rows = gather_rows(rows_local)
-            else:
-                rows = rows_local
+            rows = xch.gather()                                             # pack + the compact-state gather: Bg x row_bytes per step
             mark(1)
             if rank == 0:
-                pol_batch.expand_state(rows, head, nl, reg)
+                xch.expand(rows, head, nl, reg)
                 mark(2)
                 acts_all.copy_(policy(i))
             else:

@@ -185,3 +185,50 @@ print("tinylists lds ok", real)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, XR_LIB="libxroute_hip_tinylists.so"))
     assert out.returncode == 0 and "tinylists lds ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_seven_by_seven_gcell_region_size_matches_oracle():
+    """The only region size the reference actually ships as dumps is the 7x7-GCell worker (ispd/ispd18_test1/dump/workerx39900_y79800/worker.bin:
+    110 x 200 x 9 tracks) — 198 k nodes: too large for LDS, far smaller than config 5.  Not a BASELINE config; the HBM-scratch
+    form takes it like any other size.  Whole episodes of two such regions (K = 14, nets spanning up to 60 tracks) against the oracle: paths,
+    deltas, owners, hash chains — v1 and the reference's knobs (XR-Maze v2, default guides) — plus the compact state round trip at that size."""
+    from xroute_env_amd.batch import RegionBatch
+    from xroute_env_amd.regions import generate_region
+    regions = [generate_region(7700 + i, dims=(110, 200, 9), k_range=(14, 14), net_span=60, blockage=(0.1, 0.2)) for i in range(2)]
+    assert regions[0].n_nodes == 198000
+    for kw in (dict(), dict(guide_cost=800, guide_margin=2, maze_end_iter=3)):
+        batch = RegionBatch(regions, device="cuda:0", **kw)
+        batch.reset()
+        envs = [orc.OracleEnv(r, **kw) for r in regions]
+        rng = np.random.default_rng(77)
+        steps = 0
+        while True:
+            legal = batch.legal_sets()
+            if not any(legal):
+                break
+            acts = [int(rng.choice(sorted(s))) if s else 0 for s in legal]
+            batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+            delta = batch.fetch("delta").cpu().numpy()
+            plen = batch.fetch("path_len").cpu().numpy()
+            path = batch.fetch("path").cpu().numpy()
+            for e, env in enumerate(envs):
+                if not acts[e]:
+                    continue
+                res = env.step(acts[e], path_cap=batch.path_cap)
+                assert delta[e].tolist() == res["delta"].tolist(), (kw, steps, e)
+                n = min(res["path_len"], batch.path_cap)
+                assert int(plen[e]) == res["path_len"] and np.array_equal(path[e, :n], res["path"][:n])
+                steps += 1
+        owner = batch.fetch("owner").cpu().numpy()
+        hashes = batch.fetch("hash").cpu().numpy()
+        for e, env in enumerate(envs):
+            assert np.array_equal(owner[e, : regions[e].n_nodes], env.owner())
+            assert int(hashes[e]) & 0xFFFFFFFFFFFFFFFF == env.hash() & 0xFFFFFFFFFFFFFFFF
+        assert steps == 28
+    # compact state of a region this size: 24.8 KB per env (198 k occupancy bits) against 1.58 MB for its two fp32 planes
+    rows = batch.pack_state()
+    assert rows.shape[1] == 16 + 8 * (1 + (batch.n_max + 63) // 64)
+    head, nl, rg = batch.expand_state(rows)
+    ob = batch.observation()
+    N = regions[0].n_nodes
+    assert torch.equal(head[:, :2 * N], ob[:, :2 * N]) and nl.tolist() == [0, 0]

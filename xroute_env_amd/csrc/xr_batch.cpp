@@ -787,6 +787,8 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
     {   // measured launch order (round 5): on unless XR_NO_MEASURED_ORDER=1 (A/B switch; results never depend on the order)
         const char* off = getenv("XR_NO_MEASURED_ORDER");
         d.net_meas = (off && off[0] == '1') ? nullptr : b->net_meas.p;
+        const char* ht = getenv("XR_HEAVY_CLASS"); const char* hm = getenv("XR_HEAVY_MULT");       // (experiment switches)
+        d.heavy_class = ht ? atoi(ht) : 0; d.heavy_mult = hm ? atoi(hm) : 2;
         d.meas_shift = b->lds_dist ? 13 : 15;       // class unit: 8 k cycles (LDS form: a route is 0.1-1.5 M cycles), 32 k (HBM-scratch form: up to 6 M)
     } d.ap_flags = b->ap_flags.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;

@@ -101,6 +101,8 @@ struct XrBatchDev {
                              // net_work — regions replay (10 episodes each, then they come round again), so after one episode every heavy net
                              // is known for what it costs, whatever made it heavy (null: off)
     int32_t meas_shift;
+    int32_t heavy_class, heavy_mult;   // LDS router: a net whose measured class is >= heavy_class searches with buckets heavy_mult x as wide (0: off).  Bucket
+                                       // widths never change results; a route with many rounds pays per round, one with few pays per re-expansion
     const int32_t* net_info; // [like net_csr] static facts of net n: lowest pin id (pin + 1, 14 bits) | distinct pins << 14 | pins in closed
                              // pockets (never reachable) << 22 | the lowest pin itself is in one << 30   (xr_dial3.h)
     const uint8_t* ap_flags; // [like ap_node] bit 0: the access point's pin sits in a closed pocket (isolated); bits 1..2: which of the three

@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     __shared__ int s_nhb;
     __shared__ int s_remaining, s_target_i, s_first_pin, s_npins, s_niso, s_src_iso;
     __shared__ int s_pocket[4][XR_POCKET_CAP + 8];
-    __shared__ int s_nG, s_nN, s_nE[2], s_ntouched, s_plen, s_ndefer;
+    __shared__ int s_nG, s_nN, s_nE[3], s_ntouched, s_plen, s_ndefer;       // s_nE: three counters taking turns over the two E lists (one barrier per run-ahead pass)
     __shared__ int s_gb[4], s_retry, s_ngb;                   // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
     __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];                // ... and its guide (xr_guide_load)
 
@@ -1274,6 +1274,10 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     uint64_t h = h0;
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
 
+#ifndef XR_BIG_PREFETCH
+#define XR_BIG_PREFETCH 0         // (A/B, round 5: look-ahead loads by the idle half of the workgroup — measured 12 % SLOWER, profiles/r05_g_ab_config5_lookahead_loads.txt)
+#endif
+    [[maybe_unused]] uint32_t pf_acc = 0u, pf_v[4] = {0u, 0u, 0u, 0u};      // look-ahead loads of the run-ahead passes (stage D)
     // put a node (back) into the open structure with distance d
     auto open_insert = [&](uint32_t f, uint32_t d) {
         atomicOr(&openg[f >> 5], 1u << (f & 31));
@@ -1398,7 +1402,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
             const int nG = s_nG;
             // chunks of the active groups: 8 groups (= 256 words = one A list) at a time
             for (int g0 = 0; g0 < nG; g0 += XR_BIG_CA / 32) {
-                if (tid == 0) { s_nN = 0; s_nE[0] = 0; s_nE[1] = 0; }
+                if (tid == 0) { s_nN = 0; s_nE[0] = 0; s_nE[1] = 0; s_nE[2] = 0; }
                 __syncthreads();
                 // ---- A2 + B (fused, round 4): active words of these groups, and their open bits -> node list.  The cached minimum is
                 // read AND reset by ONE atomic exchange (a word that turns out inactive gets its bound back by an atomicMin — nobody reads
@@ -1470,21 +1474,60 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                 }
                 __syncthreads();
                 // ---- D: relax, one lane per (node, direction); run ahead inside the bucket -----------------------
-                int eb = 0;
+                // (round 5) the counters rotate over THREE slots — this pass reads ec, appends to ec1, and clears ec2 for the pass after next —
+                // so a pass ends with ONE workgroup barrier (round 4: barrier, thread 0 clears the consumed counter, barrier); the two E lists
+                // still take turns (the list pass k + 1 appends to is the one pass k read)
+                int eb = 0, ec = 0;
                 for (int npass = 0;; npass++) {
-                    const int nE = min(s_nE[eb], XR_BIG_CE);
+                    const int nE = min(s_nE[ec], XR_BIG_CE);
                     if (nE == 0) break;                                  // uniform
+                    const int ec1 = ec == 2 ? 0 : ec + 1, ec2 = ec1 == 2 ? 0 : ec1 + 1;
+                    if (tid == 0) s_nE[ec2] = 0;
                     if (npass >= round_cap) {            // hang guard (every pass lowers field words: finite anyway): what is left stays open
                         uint2* El = eb ? s_E1 : s_E0;
                         for (int it = tid; it < nE; it += nthr) { open_insert(El[it].x, m); }
                         lmin = m < lmin ? m : lmin;
                         __syncthreads();
-                        if (tid == 0) s_nE[eb] = 0;
+                        if (tid == 0) s_nE[ec] = 0;
                         __syncthreads();
                         break;
                     }
                     uint2* Ecur = eb ? s_E1 : s_E0;
                     uint2* Enxt = eb ? s_E0 : s_E1;
+#if XR_BIG_PREFETCH
+                    // ---- A/B only (round 5, off): look-ahead by the idle half of the workgroup.  The theory: a run-ahead pass is a chain of
+                    // dependent round trips and a moving frontier touches a new 128-byte line of each of three arrays almost every hop, so while the
+                    // first half of the workgroup relaxes (f -> nf), thread nthr / 2 + it loads what the next pass will ask for if nf is lowered
+                    // (the words of nf's four neighbours; values consumed a pass later, nobody waits).  Measured on config 5, 1024 slots: 2.07 ms
+                    // against 1.84 ms without — the passes are not waiting on HBM misses that a one-pass lead can hide.  Same results.
+                    pf_acc ^= pf_v[0] ^ pf_v[1] ^ pf_v[2] ^ pf_v[3];
+                    pf_v[0] = pf_v[1] = pf_v[2] = pf_v[3] = 0u;
+                    if (4 * nE <= (nthr >> 1) && tid >= (nthr >> 1) && tid - (nthr >> 1) < 4 * nE) {
+                        const int pit = tid - (nthr >> 1);
+                        const uint2 en = Ecur[pit >> 2];
+                        const int dir = pit & 3;
+                        uint32_t x, r, y, z;
+                        xr_divmod(en.x, uYZ, R.magic_yz, x, r);
+                        xr_divmod(r, uZ, R.magic_z, y, z);
+                        const bool vert = (ldir >> z) & 1u;
+                        const int sgn = (dir & 1) ? -1 : 1;
+                        const bool planar = dir < 2;
+                        const int nx = (int)x + ((planar && !vert) ? sgn : 0), ny = (int)y + ((planar && vert) ? sgn : 0), nz = (int)z + (planar ? 0 : sgn);
+                        if ((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z) {
+                            const int nf = (nx * Y + ny) * Z + nz;
+                            const bool nvert = (ldir >> nz) & 1u;
+#pragma unroll
+                            for (int d2 = 0; d2 < 4; d2++) {
+                                const int s2 = (d2 & 1) ? -1 : 1;
+                                const bool p2 = d2 < 2;
+                                const int mx = nx + ((p2 && !nvert) ? s2 : 0), my = ny + ((p2 && nvert) ? s2 : 0), mz = nz + (p2 ? 0 : s2);
+                                const bool in2 = (unsigned)mx < (unsigned)X && (unsigned)my < (unsigned)Y && (unsigned)mz < (unsigned)Z;
+                                const int mf = in2 ? (mx * Y + my) * Z + mz : nf;
+                                pf_v[d2] = xr_ld(&fieldg[mf]) ^ (uint32_t)(uint16_t)node_net[mf] ^ ((uint32_t)(uint16_t)owner[mf] << 16);
+                            }
+                        }
+                    }
+#endif
                     for (int it = tid; it < 4 * nE; it += nthr) {
                         const uint2 en = Ecur[it >> 2];
                         const int dir = it & 3;
@@ -1534,7 +1577,7 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                         if (cw < old) {
                             bool chained = false;
                             if (key < hi) {                             // lowered INTO the bucket: expand it in the next D pass
-                                const int pos = atomicAdd(&s_nE[eb ^ 1], 1);
+                                const int pos = atomicAdd(&s_nE[ec1], 1);
                                 if (pos < XR_BIG_CE) { Enxt[pos] = make_uint2((uint32_t)nf, cand4); chained = true; }
                             }
                             if (!chained) { open_insert((uint32_t)nf, key); lmin = key < lmin ? key : lmin; }
@@ -1545,9 +1588,10 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     //  L2 round trip per pass on the critical chain.  A later pass that reads a word an unacknowledged atomic is about to
                     //  lower sees the older, HIGHER value: it may issue an atomicMin that loses, never skip one that would win.)
                     xr_lds_barrier();
-                    if (tid == 0) s_nE[eb] = 0;
-                    eb ^= 1;
+#ifdef XR_BIG_TWO_BARRIERS          // A/B: round 4's second barrier per pass (the counters need none)
                     xr_lds_barrier();
+#endif
+                    eb ^= 1; ec = ec1;
                 }
             }
             lmin = xr_wave_min_u32(lmin);
@@ -1728,6 +1772,10 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
     // (the barriers at the top of the search loop order all of this)
     }
+#if XR_BIG_PREFETCH
+    pf_acc ^= pf_v[0] ^ pf_v[1] ^ pf_v[2] ^ pf_v[3];
+    if (pf_acc == 0x5EED5EEDu && nrounds < 0) touchg[0] = pf_acc;          // (never: the look-ahead loads must not be optimised away)
+#endif
     if (tid == 0) {
         if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
         xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h, s_ntouched);

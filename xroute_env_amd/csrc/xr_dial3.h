@@ -41,6 +41,18 @@
 #define XR3_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+// Solo rounds (round 5): a round whose predecessor took at most XR3_SOLO_ENTER nodes from the mask is run by ONE wave (the tracing wave) on its
+// own — scan, quads, next minimum — and so are the rounds after it, with wave-level synchronisation only, until a round takes more than
+// XR3_SOLO_EXIT nodes or the search ends; the other waves of the workgroup are parked at one barrier meanwhile.  A narrow frontier has work for
+// a few quads: four waves then mostly pay for each other's barrier skew (26 % of a route).  Same results (rounds are rounds, whoever runs them).
+// XR3_SOLO_ENTER < 0: off.
+#ifndef XR3_SOLO_ENTER
+#define XR3_SOLO_ENTER (-1)
+#endif
+#ifndef XR3_SOLO_EXIT
+#define XR3_SOLO_EXIT 24
+#endif
+
 #ifndef XR3_WAVE_MIN_SHFL
 // wave-wide min by DPP (row_shr 1,2,4,8 -> lane 15 of every row; row_bcast:15, row_bcast:31 -> lane 63), ~12 VALU ops, no LDS
 __device__ __forceinline__ uint32_t xr3_wave_min(uint32_t v) {
@@ -94,6 +106,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
     __shared__ int s_cnt[3];                                    // ... and the nodes the round took from the mask (XR3_ADAPT: sparse rounds widen the bucket)
     __shared__ int s_hb[3][6];                                  // heuristic: three boxes over the unconnected pins (x, y: coordinates x32; z), see the search start
     __shared__ int s_qcnt[16];                                  // per wave: nodes of the bucket queued for its quads
+    __shared__ int s_hand[2];                                   // solo rounds: where the solo wave left the search (cur | rounds so far << 2), two slots taking turns
     __shared__ unsigned short s_qn[XR_QUAD_POOL];
     __shared__ int s_remaining, s_abort;
     __shared__ int s_gb[4], s_retry, s_ngb;                     // XR-Maze v2: bounding box of the net's access points (track indices), rip-up decision
@@ -169,6 +182,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
     const int ap_lo = b.net_csr[R.net_off + a], ap_hi = b.net_csr[R.net_off + a + 1];
     const int nap = ap_hi - ap_lo;    // 1 <= nap <= XR_MAX_AP_PER_NET (checked at load)
     const int ninfo = b.net_info[R.net_off + a];               // first pin | pins << 14 | isolated pins << 22 | first pin isolated << 30
+    const int meas_cls = (b.heavy_class > 0 && b.net_meas) ? (int)b.net_meas[R.net_off + a] : 0;      // what this net cost the last time it was routed
     int my_ap_f = 0, my_ap_pin = 0, my_ap_iso = 0;
     if (tid < nap) {
         my_ap_f = b.ap_node[R.ap_off + ap_lo + tid]; my_ap_pin = b.ap_pin[R.ap_off + ap_lo + tid];
@@ -268,7 +282,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
 
     const uint32_t via5 = (uint32_t)b.via_cost << 5;
     uint32_t pen5 = (uint32_t)b.pen_cost << 5;              // (XR-Maze v2: doubled by every rip-up-and-reroute attempt)
-    const uint32_t delta = R.w_min * (uint32_t)b.dial_mult;  // bucket width (keys f = d + h, DBU)
+    const uint32_t delta = R.w_min * (uint32_t)b.dial_mult * (uint32_t)(meas_cls >= b.heavy_class && b.heavy_class > 0 ? b.heavy_mult : 1);  // bucket width (keys f = d + h, DBU)
     const uint32_t guide5 = V2 ? (uint32_t)b.guide_cost << 5 : 0u;
     const uint32_t sh_yz = s24w & 31u, sh_z = (s24w >> 8) & 31u, sh_mw = (s24w >> 16) & 31u;       // (window form: its own magics)
     auto node_xyz = [&](uint32_t f, int& x, int& y, int& z) __attribute__((always_inline)) {
@@ -424,11 +438,36 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
         int cur = 0;
         [[maybe_unused]] int bscale = 1;      // (XR3_ADAPT_LO builds: bucket width of the round, in units of delta)
         bool aborted = false;                 // (round cap: xr_dial.h)
+        bool soloing = false;                 // this wave runs the rounds on its own (the tracing wave only; the others wait at a barrier)
+        int hpar = 0;                         // which hand-off slot the next solo episode uses (every wave counts the episodes)
         for (int nsr = 0;; nsr++) {
-            const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
+            int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
             const uint32_t m = s_min[cur], best = s_bst[cur];
-            if (m == XR_DIAL_INF || m > best) break;                 // uniform
-            if (nsr >= round_cap || s_abort) { aborted = true; break; }   // uniform (s_abort: written before the last barrier)
+            const bool sdone = m == XR_DIAL_INF || m > best;
+            const bool scap = nsr >= round_cap || s_abort;
+            if (XR3_SOLO_ENTER >= 0) {
+                const int pc = s_cnt[cur];                        // nodes the round before this one took from the mask (search start: 1 << 20)
+                if (soloing && (sdone || scap || pc > XR3_SOLO_EXIT)) {      // leave the episode: publish where the search stands, release the others
+                    if (lane == 0) s_hand[hpar] = cur | (nsr << 2);
+                    hpar ^= 1;
+                    xr_lds_barrier();
+                    soloing = false;
+                }
+                if (!soloing && !sdone && !scap && pc <= XR3_SOLO_ENTER) {   // (uniform over the workgroup: everybody read the same pc)
+                    if (wv != sw) {                               // parked until the solo wave leaves its episode
+                        xr_lds_barrier();
+                        const int hv = s_hand[hpar];
+                        hpar ^= 1;
+                        cur = hv & 3; nsr = (hv >> 2) - 1;
+                        continue;
+                    }
+                    soloing = true;
+                }
+            }
+            if (sdone) break;                                                // uniform
+            if (scap) { aborted = true; break; }                             // uniform (s_abort: written before the last barrier)
+            // the team of this round: the whole workgroup, or the solo wave
+            const int tE = soloing ? lane : tid, nE = soloing ? 64 : nthr;
 #ifdef XR3_GROW_AFTER        // A/B only (profiles/r03_q_ab_growing_bucket_width.txt: wider late buckets cost 3-18 % --
                              // the extra re-expansions outweigh the rounds saved); off in the shipped build
             const uint32_t hi = m + (nsr >= XR3_GROW_AFTER ? delta * XR3_GROW_BY : delta);
@@ -440,16 +479,16 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
             const uint32_t hi = m + delta;
 #endif
             uint32_t lmin = XR_DIAL_INF;
-            if (tid == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; s_cnt[nx2] = 0; }
+            if (tE == 0) { s_min[nx2] = XR_DIAL_INF; s_bst[nx2] = XR_DIAL_INF; s_cnt[nx2] = 0; }
             // bound for the next round: smallest tentative distance of an unconnected target
             // (by the threads at the END of the workgroup: the first wave carries the words beyond one per thread)
-            for (int i = nthr - 1 - tid; i < nap; i += nthr)
+            for (int i = nE - 1 - tE; i < nap; i += nE)
                 if (!s_ap_conn[i]) { const uint32_t d = field[s_ap_f[i]] >> 5; if (d != XR3_DMAX) atomicMin(&s_bst[nx1], d); }
             // A lane scans word wi and — where the mask has more words than the workgroup has threads — word wi + nthr in the
             // SAME pass (one 64-bit bit set).  The nodes of this bucket are then expanded by QUADS of lanes, one lane per direction.
-            for (int wbase = 0; wbase < mw; wbase += 2 * nthr) {          // (uniform trip count: the expansion is wave-cooperative)
-                const int wi = wbase + tid;
-                const int wi2 = wi + nthr;
+            for (int wbase = 0; wbase < mw; wbase += 2 * nE) {            // (uniform trip count: the expansion is wave-cooperative)
+                const int wi = wbase + tE;
+                const int wi2 = wi + nE;
                 unsigned long long expd = 0;
                 if (wi < mw) {
                     const bool has2 = wi2 < mw;
@@ -504,9 +543,9 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
                 XR_LAP(1);
                 // ---- the wave's nodes of this bucket go into its slice of a small LDS queue (no room: back into the mask)
                 {
-                    const int qcap = XR_QUAD_POOL / ((nthr + 63) >> 6);
+                    const int qcap = soloing ? XR_QUAD_POOL : XR_QUAD_POOL / ((nthr + 63) >> 6);      // (alone: the whole pool)
                     int* qcnt = &s_qcnt[wv];
-                    unsigned short* qn = s_qn + wv * qcap;
+                    unsigned short* qn = soloing ? s_qn : s_qn + wv * qcap;
                     if (lane == 0) *qcnt = 0;
                     __builtin_amdgcn_wave_barrier();
                     while (expd) {
@@ -520,8 +559,10 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
                     }
                     __builtin_amdgcn_wave_barrier();
                     const int nq = min(__builtin_amdgcn_readfirstlane(*qcnt), qcap);
-#ifdef XR3_ADAPT_LO
+#if defined(XR3_ADAPT_LO)
                     if (lane == 0 && nq) atomicAdd(&s_cnt[nx1], nq);
+#else
+                    if (XR3_SOLO_ENTER >= 0 && lane == 0 && nq) atomicAdd(&s_cnt[nx1], nq);
 #endif
                     // ---- quads: lanes 4g .. 4g+3 follow ONE chain, lane 4g+d relaxes direction d of the chain's current node
                     int gf = -1, gx = 0, gy = 0, gz = 0, qh = 0;
@@ -591,7 +632,7 @@ __device__ __forceinline__ bool xr_dial3_route_env(const XrBatchDev& b, const in
             lmin = xr3_wave_min(lmin);
             if (lane == 0 && lmin != XR_DIAL_INF) atomicMin(&s_min[nx1], lmin);
             if (wv == sw) nrounds++;
-            xr_lds_barrier();
+            if (soloing) XR3_WSYNC(); else xr_lds_barrier();
             XR_LAP(6);
             cur = nx1;
         }

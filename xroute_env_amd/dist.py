@@ -238,3 +238,47 @@ class ShardedVectorEnv:
         if self.world > 1:
             dist.broadcast(self._actions_all, src=0, group=self.group)      # actions travel the other way
         return self._actions_all[self.lo:self.hi].contiguous()
+
+
+class CompactStateExchange:
+    """The compact-state gather of a CENTRAL learner (BASELINE config 4's `--learner` placement): every rank packs what planes 0..1
+    of its envs' observations are functions of (`RegionBatch.pack_state`: region, nets left, legal bitmask, one occupancy bit per node), ONE
+    all_gather carries the rows, the learner expands them to the fp32 head rows its policy reads (`RegionBatch.expand_state`, byte-identical to
+    what `step_compact` writes).  fp32 planes are never gathered.
+
+    batch          the rank's RegionBatch (its shard)
+    n_total        env slots over all ranks; `lo` = global id of this rank's first env (contiguous shards, `shard_range`)
+    region_base    what turns the shard's local region index into an index of the learner's region table (0 when every rank loaded the same regions)
+    learner_batch  on the learner rank: a RegionBatch whose region table holds every region of the job (default: `batch`)"""
+
+    def __init__(self, batch, n_total: int, lo: int, region_base: int = 0, learner_batch=None, group=None):
+        self.batch, self.learner = batch, (learner_batch if learner_batch is not None else batch)
+        self.n_total, self.lo, self.region_base, self.group = int(n_total), int(lo), int(region_base), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rb = max(batch.state_row_bytes(), self.learner.state_row_bytes())
+        if self.world > 1:                       # one row size for everybody (ranks may hold regions with different net counts)
+            t = torch.tensor([rb], dtype=torch.int64, device=batch.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            rb = int(t.item())
+        self.row_bytes = rb
+        self.rows_local = torch.empty((batch.n_envs, rb), dtype=torch.uint8, device=batch.device)
+        self.equal = self.world > 1 and self.n_total == self.world * batch.n_envs
+        self.rows_all = torch.empty((self.n_total, rb), dtype=torch.uint8, device=batch.device) if self.equal else None
+
+    @property
+    def bytes_per_step(self) -> int:
+        return self.n_total * self.row_bytes
+
+    def gather(self) -> torch.Tensor:
+        """pack this rank's envs and all-gather the rows: uint8 [n_total, row_bytes] in global env order (on every rank)"""
+        self.batch.pack_state(self.rows_local, region_base=self.region_base)
+        if self.world == 1:
+            return self.rows_local
+        if self.equal:
+            dist.all_gather_into_tensor(self.rows_all, self.rows_local, group=self.group)
+            return self.rows_all
+        return gather_rows(self.rows_local, group=self.group)
+
+    def expand(self, rows: torch.Tensor, head_out=None, nlegal_out=None, region_out=None):
+        """learner rank: rows -> (head fp32 [n, 2 * n_max], nlegal int32 [n], region int32 [n]); rows that do not parse are flagged -1"""
+        return self.learner.expand_state(rows, head_out, nlegal_out, region_out)
