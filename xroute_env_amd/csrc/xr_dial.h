@@ -1494,6 +1494,10 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     }
                     uint2* Ecur = eb ? s_E1 : s_E0;
                     uint2* Enxt = eb ? s_E0 : s_E1;
+#ifdef XR_BIG_PASS_PROBE       // (tools/config5_pass_split.py: where a run-ahead pass spends its time, as thread 0 sees it)
+                    const long long pp0 = clock64();
+                    long long pp1 = 0, pp2 = 0, pp3 = 0;
+#endif
 #if XR_BIG_PREFETCH
                     // ---- A/B only (round 5, off): look-ahead by the idle half of the workgroup.  The theory: a run-ahead pass is a chain of
                     // dependent round trips and a moving frontier touches a new 128-byte line of each of three arrays almost every hop, so while the
@@ -1552,6 +1556,14 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                         const uint32_t cb = (vert ? s_yc : s_xc)[(vert ? (int)y : (int)x) + 1 + (planar ? sgn : 0)];
                         const uint32_t ca = vert ? yq : xq;
                         const uint32_t len4 = planar ? (sgn > 0 ? cb - ca : ca - cb) : via4;
+                        // (round 5) what does NOT depend on the words in flight — the neighbour's heuristic (a loop over the pin boxes in LDS), its
+                        // guide cost — is computed here, in the shadow of the loads; it used to sit between the load and the atomic, on the chain
+                        // (tools/config5_pass_split.py: 1.5 k cycles from "loads returned" to "atomic returned" for an L2 atomic of ~1 k)
+                        const uint32_t hq = heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);
+                        const uint32_t gq = guide_of(nx, ny, nz);
+#ifdef XR_BIG_PASS_PROBE
+                        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pp1 = clock64(); }
+#endif
                         if (!inb) continue;
                         uint32_t fl;
                         if (wn == XR_BIG_CLEAN) {                                 // first touch: derive the flags
@@ -1562,26 +1574,35 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
 #endif
                             if (fl == 0u) continue;
                         } else fl = wn & 3u;
-                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + guide_of(nx, ny, nz);
+                        const uint32_t cand4 = d4 + len4 + ((fl & 2u) ? pen4 : 0u) + gq;
                         if (cand4 >= XR_W_USABLE_END) continue;
                         const uint32_t cw = cand4 | fl;
                         if (cw >= wn) continue;
-                        const uint32_t key = (cand4 >> 2) + heur_c((int)((planar && !vert) ? cb : xq), (int)((planar && vert) ? cb : yq), nz);   // f = d + h
+                        const uint32_t key = (cand4 >> 2) + hq;   // f = d + h
                         if (key > best) {                              // bound pruning: f is looked at again by the next search
                             const int k = atomicAdd(&s_ndefer, 1);
                             if (k < defer_cap) deferl[k] = f;
                             continue;
                         }
                         const uint32_t old = atomicMin(&fieldg[nf], cw);
-                        if (old == XR_BIG_CLEAN) touch((uint32_t)nf);
+#ifdef XR_BIG_PASS_PROBE
+                        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pp2 = clock64(); }
+#endif
+                        // (round 5) both list positions are asked for before either is used: two LDS atomics in flight together instead of
+                        // one after the other (the touched-list slot, then the E-list slot: 650 cycles behind the atomic, tools/config5_pass_split.py)
+                        const bool first = old == XR_BIG_CLEAN, chain_try = cw < old && key < hi;
+                        int tk = 0, pos = XR_BIG_CE;
+                        if (first) tk = atomicAdd(&s_ntouched, 1);
+                        if (chain_try) pos = atomicAdd(&s_nE[ec1], 1);
+                        if (first) touchg[tk] = (uint32_t)nf;
                         if (cw < old) {
-                            bool chained = false;
-                            if (key < hi) {                             // lowered INTO the bucket: expand it in the next D pass
-                                const int pos = atomicAdd(&s_nE[ec1], 1);
-                                if (pos < XR_BIG_CE) { Enxt[pos] = make_uint2((uint32_t)nf, cand4); chained = true; }
-                            }
-                            if (!chained) { open_insert((uint32_t)nf, key); lmin = key < lmin ? key : lmin; }
+                            const bool chained = pos < XR_BIG_CE;
+                            if (chained) Enxt[pos] = make_uint2((uint32_t)nf, cand4);
+                            else { open_insert((uint32_t)nf, key); lmin = key < lmin ? key : lmin; }
                         }
+#ifdef XR_BIG_PASS_PROBE
+                        if (tid == 0 && it == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pp3 = clock64(); }
+#endif
                     }
                     // (LDS-only barrier, round 4: the next pass is handed the E list, nothing else.  __syncthreads() would also wait for the
                     //  acknowledgement of this pass's fire-and-forget traffic — touched / deferred list stores, open-mask atomics: one more
@@ -1590,6 +1611,14 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     xr_lds_barrier();
 #ifdef XR_BIG_TWO_BARRIERS          // A/B: round 4's second barrier per pass (the counters need none)
                     xr_lds_barrier();
+#endif
+#ifdef XR_BIG_PASS_PROBE
+                    if (tid == 0) {
+                        const long long pp4 = clock64();
+                        long long* pc = b.phase_cycles + (int64_t)e * 8;
+                        pc[5] += pp4 - pp0; pc[6] += 1; pc[7] += nE;
+                        if (pp1 && pp2 && pp3) { pc[0] += pp1 - pp0; pc[1] += pp2 - pp1; pc[2] += pp3 - pp2; pc[3] += pp4 - pp3; pc[4] += 1; }
+                    }
 #endif
                     eb ^= 1; ec = ec1;
                 }
