@@ -4,7 +4,7 @@ look-ahead: libxroute_hip_twobarriers.so built from the tree before the look-ahe
     python tools/ab_c5_barriers.py [libs...]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [a for a in sys.argv[1:]] or ["libxroute_hip.so", "libxroute_hip_prefetch.so", "libxroute_hip_twobarriers.so"]
+libs = [a for a in sys.argv[1:]] or ["libxroute_hip.so", "libxroute_hip_nofwd.so", "libxroute_hip_twobarriers.so"]
 for envs in (os.environ.get("XR_AB_ENVS", "1024,4096")).split(","):
     res = {l: [] for l in libs}
     for rep in range(int(os.environ.get("XR_AB_REPS", "3"))):

@@ -1274,10 +1274,6 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     uint64_t h = h0;
     int32_t* __restrict__ path = b.path + (int64_t)e * b.path_cap;
 
-#ifndef XR_BIG_PREFETCH
-#define XR_BIG_PREFETCH 0         // (A/B, round 5: look-ahead loads by the idle half of the workgroup — measured 12 % SLOWER, profiles/r05_g_ab_config5_lookahead_loads.txt)
-#endif
-    [[maybe_unused]] uint32_t pf_acc = 0u, pf_v[4] = {0u, 0u, 0u, 0u};      // look-ahead loads of the run-ahead passes (stage D)
     // put a node (back) into the open structure with distance d
     auto open_insert = [&](uint32_t f, uint32_t d) {
         atomicOr(&openg[f >> 5], 1u << (f & 31));
@@ -1498,40 +1494,12 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
                     const long long pp0 = clock64();
                     long long pp1 = 0, pp2 = 0, pp3 = 0;
 #endif
-#if XR_BIG_PREFETCH
-                    // ---- A/B only (round 5, off): look-ahead by the idle half of the workgroup.  The theory: a run-ahead pass is a chain of
-                    // dependent round trips and a moving frontier touches a new 128-byte line of each of three arrays almost every hop, so while the
-                    // first half of the workgroup relaxes (f -> nf), thread nthr / 2 + it loads what the next pass will ask for if nf is lowered
-                    // (the words of nf's four neighbours; values consumed a pass later, nobody waits).  Measured on config 5, 1024 slots: 2.07 ms
-                    // against 1.84 ms without — the passes are not waiting on HBM misses that a one-pass lead can hide.  Same results.
-                    pf_acc ^= pf_v[0] ^ pf_v[1] ^ pf_v[2] ^ pf_v[3];
-                    pf_v[0] = pf_v[1] = pf_v[2] = pf_v[3] = 0u;
-                    if (4 * nE <= (nthr >> 1) && tid >= (nthr >> 1) && tid - (nthr >> 1) < 4 * nE) {
-                        const int pit = tid - (nthr >> 1);
-                        const uint2 en = Ecur[pit >> 2];
-                        const int dir = pit & 3;
-                        uint32_t x, r, y, z;
-                        xr_divmod(en.x, uYZ, R.magic_yz, x, r);
-                        xr_divmod(r, uZ, R.magic_z, y, z);
-                        const bool vert = (ldir >> z) & 1u;
-                        const int sgn = (dir & 1) ? -1 : 1;
-                        const bool planar = dir < 2;
-                        const int nx = (int)x + ((planar && !vert) ? sgn : 0), ny = (int)y + ((planar && vert) ? sgn : 0), nz = (int)z + (planar ? 0 : sgn);
-                        if ((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y && (unsigned)nz < (unsigned)Z) {
-                            const int nf = (nx * Y + ny) * Z + nz;
-                            const bool nvert = (ldir >> nz) & 1u;
-#pragma unroll
-                            for (int d2 = 0; d2 < 4; d2++) {
-                                const int s2 = (d2 & 1) ? -1 : 1;
-                                const bool p2 = d2 < 2;
-                                const int mx = nx + ((p2 && !nvert) ? s2 : 0), my = ny + ((p2 && nvert) ? s2 : 0), mz = nz + (p2 ? 0 : s2);
-                                const bool in2 = (unsigned)mx < (unsigned)X && (unsigned)my < (unsigned)Y && (unsigned)mz < (unsigned)Z;
-                                const int mf = in2 ? (mx * Y + my) * Z + mz : nf;
-                                pf_v[d2] = xr_ld(&fieldg[mf]) ^ (uint32_t)(uint16_t)node_net[mf] ^ ((uint32_t)(uint16_t)owner[mf] << 16);
-                            }
-                        }
-                    }
-#endif
+                    // (Round 5, measured and NOT adopted — both bit-exact: look-ahead loads of the next pass's words by the idle half of the
+                    //  workgroup, +12 % (profiles/r05_g_*); "flags forward": the pass that lowers a node fetches the flags of ITS neighbours beside
+                    //  its atomic and hands them on in the E entry, so the next pass goes straight to its atomics — one L2 round trip per pass
+                    //  instead of two, yet +17 % (profiles/r05_j_*, tools/archive/xr_big_flags_forward.patch): the pass-split probe shows why —
+                    //  ~1.1 k of a pass's ~3.5 k cycles are the index / heuristic arithmetic in front of the atomic, the word load hides
+                    //  behind it, and six more loads per lane queue up behind the atomic whose result the pass waits for.)
                     for (int it = tid; it < 4 * nE; it += nthr) {
                         const uint2 en = Ecur[it >> 2];
                         const int dir = it & 3;
@@ -1801,10 +1769,6 @@ __device__ __forceinline__ void xr_dial_route_env_big(const XrBatchDev& b, const
     if (tid == 0) s_remaining = s_npins - 1 - n_isolated;
     // (the barriers at the top of the search loop order all of this)
     }
-#if XR_BIG_PREFETCH
-    pf_acc ^= pf_v[0] ^ pf_v[1] ^ pf_v[2] ^ pf_v[3];
-    if (pf_acc == 0x5EED5EEDu && nrounds < 0) touchg[0] = pf_acc;          // (never: the look-ahead loads must not be optimised away)
-#endif
     if (tid == 0) {
         if (n_isolated > 0) { d_vio += n_isolated; status |= XR_ENV_UNREACHABLE; }
         xr_step_epilogue(b, e, a, d_vio, d_wl, d_via, plen, status, nrounds, h, s_ntouched);
