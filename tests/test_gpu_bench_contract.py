@@ -230,7 +230,7 @@ def test_bench_value_is_stationary_in_warmup():
 
 def test_bench_region_pack_with_the_reference_configuration():
     """`bench.py --region-pack <the design-derived pack> --maze-v2`: the main batch itself routes with the reference's simulator
-    configuration (XR-Maze v2: maze_end_iter 3, guide cost over the design's guide rectangles) — the command `tools/final_round4.sh`
+    configuration (XR-Maze v2: maze_end_iter 3, guide cost over the design's guide rectangles) — the command `tools/final_round5.sh`
     profiles under rocprofv3.  One JSON line, the queue form, the workload text says what ran."""
     pack = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--envs", "512",

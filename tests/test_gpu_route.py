@@ -521,7 +521,7 @@ def test_window_form_of_the_lds_router_matches_the_oracle(window, forms):
 def test_router_fuzz_against_the_oracle():
     """tools/fuzz_router.py, 40 trials: random region shapes / densities / net shapes, costs, XR-Maze v2 knobs (guide cost, margin, attempts,
     random guide boxes), router form (round-3 LDS, round-2 LDS, HBM-scratch, LDS-window in front of it, sweeps), policy — whole episodes
-    equal the oracle in every field.  (`tools/final_round4.sh` runs 4000 trials: profiles/r04_z_fuzz_router.txt.)"""
+    equal the oracle in every field.  (`tools/final_round5.sh` runs 4000 trials: profiles/r05_z_fuzz_router.txt.)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_router", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_router.py"))
     mod = importlib.util.module_from_spec(spec)
