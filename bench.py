@@ -835,6 +835,27 @@ def extras_leg(args, regions, dev, batch, obs):
         ex["config3_dqn_attached"]["what"] = r["config"]["workload"]
     except Exception as exn:
         ex["config3_dqn_attached"] = {"error": str(exn)}
+    try:        # BASELINE config 4's per-GPU share (512 envs) with the PPO baseline attached, both placements of the policy, on this one GPU
+        a4 = copy.copy(args)
+        n4 = min(512, len(regions))
+        a4.agent, a4.steps, a4.warmup, a4.global_envs, a4.region_pack, a4.regions, a4.maze_v2, a4.no_stagger = "ppo", 20, 3, n4, None, 0, False, False
+        keep = ("value", "unit", "steps", "ms_per_step", "env_share_of_step_time", "agent_ms_per_step", "env_ms_per_step", "step_split_ms_rank0", "actions_sha")
+        both = {}
+        for name, lrn in (("policy_per_rank", False), ("central_learner_from_compact_state", True)):
+            a4.learner = lrn
+            r = agent_sharded(a4, regions[:n4], dev, 1, 0, 0, n4, True, emit=False)
+            both[name] = {k: r[k] for k in keep}
+            both[name]["parity_ok"] = bool(r["parity"].get("ok"))
+            if lrn:
+                both[name]["compact_state"] = r["compact_state"]
+        both["same_actions_in_both_placements"] = both["policy_per_rank"]["actions_sha"] == both["central_learner_from_compact_state"]["actions_sha"]
+        both["envs"] = n4
+        both["what"] = ("BASELINE config 4 (4096 regions over 8 GPUs, PPO baseline): one GPU's share, 512 envs, full maze route per step, the PPO counterpart choosing every action "
+                        "— evaluated on the shard itself (what config 4 should use) and from gathered compact state (SURVEY 8e's central learner; at N = 1 the gather is a no-op, "
+                        "pack + expand are real); `python bench.py --gpus 8 --global-envs 4096 --agent ppo [--learner]` is the 8-GPU command")
+        ex["config4_ppo_attached_per_gpu_share"] = both
+    except Exception as exn:
+        ex["config4_ppo_attached_per_gpu_share"] = {"error": str(exn)}
     return ex
 
 
@@ -960,7 +981,7 @@ def agent_leg(args, regions, dev, world):
                          "avg_launch_ms": round(env_ms, 4), "algorithmic_bytes_per_launch": int(env_bytes)}}
 
 
-def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner_regions=None):
+def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner_regions=None, emit=True):
     """BASELINE config 4 as stated — "4096 regions sharded 8 x MI355X, PPO baseline, RCCL env gather" — as ONE self-certifying line
     (`--gpus N [--global-envs 4096] --agent ppo`; also N = 1 and `--agent dqn`).  The reference's caller loop is
     `action = ppo_agent.select_action(state); state, done, ... = game.step(action)` (baseline/PPO/train_PPO.py:96-99; the sampling:
@@ -1230,6 +1251,8 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
         if not good:
             out["error"] = "self-certification failed: " + json.dumps({"certify": certify, "parity_ok": parity.get("ok"), "all_ranks_ok": parity.get("all_ranks_ok")})
             print(out["error"], file=sys.stderr)
+        if not emit:
+            return out                     # (called from the default line's `extras`: the caller embeds it)
         print(json.dumps(out), flush=True)
     return 0 if good else 3
 

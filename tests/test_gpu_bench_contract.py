@@ -59,6 +59,11 @@ def test_bench_json_contract(extra):
         # driver-visible side numbers: BASELINE config 1 latency and config 3 with the DQN counterpart attached
         ex = d["extras"]
         assert ex["config1_game_step"]["ms_median"] > 0 and ex["config3_dqn_attached"]["value"] > 0, ex
+        # ... and BASELINE config 4's per-GPU share with the PPO baseline attached, in both placements of the policy (same actions env for env)
+        c4 = ex["config4_ppo_attached_per_gpu_share"]
+        assert c4["policy_per_rank"]["value"] > 0 and c4["central_learner_from_compact_state"]["value"] > 0, c4
+        assert c4["policy_per_rank"]["parity_ok"] and c4["central_learner_from_compact_state"]["parity_ok"] and c4["same_actions_in_both_placements"]
+        assert c4["central_learner_from_compact_state"]["compact_state"]["ratio_to_fp32_planes"] < 0.02
         # ~1 s of the same step after the timed region (clocks / thermals visible); never part of `value`
         su = ex["sustained"]
         assert su["steps"] == 500 and su["value"] > 0 and len(su["ms_per_step_by_100"]) == 5 and min(su["ms_per_step_by_100"]) > 0
