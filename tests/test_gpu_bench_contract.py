@@ -244,3 +244,31 @@ def test_bench_region_pack_with_the_reference_configuration():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert "XR-Maze v2" in d["config"]["workload"] and "region pack" in d["config"]["workload"] and d["value"] > 0
     assert d["kernels"][0]["kernel"] == "xr_step_queue_kernel" and d["roofline"]["frac"] > 0
+
+
+def test_config4_rollout_example_same_episode_in_every_placement():
+    """examples/config4_rollout.py (the library-level form of BASELINE config 4: RegionBatch shards + agents.ppo_actions + dist.CompactStateExchange):
+    one rank or two, policy per rank or central learner from gathered compact state — the same rewards, done counts and actions step by step."""
+    import re
+    import socket
+
+    def run(nproc, extra):
+        env = dict(os.environ, XR_BENCH_BACKEND="gloo", XR_BENCH_SAME_DEVICE="1")
+        script = os.path.join(ROOT, "examples", "config4_rollout.py")
+        if nproc == 1:
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            cmd = [sys.executable, script, "96"] + extra
+        else:
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), script, "96"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [re.sub(r"^(step \d+): .*?rank\(s\): ", r"\1: ", l) for l in out.stdout.splitlines() if l.startswith("step ")]
+        assert len(lines) == 6
+        return lines
+    ref = run(1, [])
+    assert run(1, ["--central"]) == ref
+    assert run(2, []) == ref
+    assert run(2, ["--central"]) == ref
