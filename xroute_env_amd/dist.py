@@ -213,6 +213,13 @@ class ShardedVectorEnv:
         obs, reward, done, info = self.env.step(actions)
         return obs, self._gather(info["record"], self._all), info
 
+    def compact_exchange(self, learner_batch=None) -> "CompactStateExchange":
+        """The compact-state gather of a central learner for this sharded env (CompactStateExchange below): every rank's envs packed to
+        ~1 KB rows, one all_gather, expansion to head rows on the learner — for a policy that reads the grid (the DQN / PPO counterparts),
+        where `learner_step`'s records + legal masks are enough for policies that do not.  `learner_batch` (learner rank): a RegionBatch
+        holding the regions of ALL ranks in global env order (region of global env g at index g)."""
+        return CompactStateExchange(self.env.batch, self.n_total, self.lo, region_base=self.lo, learner_batch=learner_batch, group=self.group)
+
     # ---- learner flow (BASELINE config 4) ------------------------------------------------------------------------
     def learner_reset(self, policy: Callable = first_legal_policy):
         """reset + the first action exchange.  Returns (obs_local, actions_local)."""
