@@ -64,6 +64,27 @@ class OracleVectorEnv:
         return None, torch.from_numpy(r["reward"]), torch.from_numpy(r["done"]), info
 
 
+class _FakeStateBatch:
+    """What dist.CompactStateExchange needs of a RegionBatch (state_row_bytes / pack_state / expand_state), on CPU tensors: the collective
+    logic runs under gloo without a GPU; the kernels behind the real methods are covered by tests/test_gpu_learner_state.py."""
+
+    def __init__(self, n_envs, words):
+        self.n_envs, self.device, self._rb = n_envs, torch.device("cpu"), 16 + 8 * words
+
+    def state_row_bytes(self):
+        return self._rb
+
+    def pack_state(self, out, region_base=0):
+        out.zero_()
+        v = out.view(torch.int32)
+        v[:, 0] = torch.arange(self.n_envs, dtype=torch.int32) + region_base
+        v[:, 1] = 7
+        return out
+
+    def expand_state(self, rows, *unused):
+        return rows.view(torch.int32)[:, 0].clone(), None, None
+
+
 DIMS = dict(dims=(8, 7, 3), k_range=(2, 4))
 
 
@@ -110,7 +131,17 @@ def _worker(rank, world, port, q):
     if rank == 1:
         bad[0, 3] ^= 0x40                                          # rank 1 received a wrong byte in rank 0's slice
     cert.append(verify_gather(local, bad, eq_lo))
-    q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy(), cert))
+    # the compact-state gather of a central learner (dist.CompactStateExchange) over a stand-in batch: ranks with DIFFERENT row sizes agree on
+    # the largest, rows arrive in global env order for equal and for ragged shards, the learner sees every env
+    from xroute_env_amd.dist import CompactStateExchange
+    xch_out = []
+    for n_tot in (10, N_TOTAL):
+        l2, h2 = shard_range(n_tot, world, rank)
+        fb = _FakeStateBatch(h2 - l2, words=3 + 2 * rank)
+        xch = CompactStateExchange(fb, n_tot, l2, region_base=l2)
+        rows = xch.gather()
+        xch_out.append((xch.row_bytes, xch.bytes_per_step, rows.view(torch.int32)[:, :2].clone().numpy(), xch.expand(rows)[0].numpy()))
+    q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy(), cert, xch_out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -173,7 +204,10 @@ def test_two_rank_learner_flow_equals_single_process():
         assert p.exitcode == 0
     single_recs, single_sent, _ = _run_learner(N_TOTAL, STEPS)
     for rank in (0, 1):
-        recs, sent, (lo, hi), plain, eq_all, cert = got[rank]
+        recs, sent, (lo, hi), plain, eq_all, cert, xch_out = got[rank]
+        for (rb, per_step, hdr, regions_seen), n_tot in zip(xch_out, (10, N_TOTAL)):
+            assert rb == 16 + 8 * 5 and per_step == n_tot * rb                  # the larger of the two ranks' row sizes, on both ranks
+            assert hdr[:, 0].tolist() == list(range(n_tot)) and (hdr[:, 1] == 7).all() and regions_seen.tolist() == list(range(n_tot))
         assert len(recs) == STEPS
         assert cert[0] == {"ranks_seen": 2, "gather_verified": True, "rows": 10}
         assert cert[1] == {"ranks_seen": 2, "gather_verified": True, "rows": N_TOTAL}
