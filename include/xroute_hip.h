@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 7
+#define XR_ABI_VERSION 8
 
 /* status codes */
 #define XR_OK            0
@@ -394,6 +394,14 @@ int32_t xr_agent_actor_weights(void);
 int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
                        const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
                        int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream);
+/* ABI 8: the same kernel with PPO's rollout sampling inside (baseline/PPO/PPO.py:124-146 `ActorCritic.act`: `dist = Categorical(action_probs); action =
+ * dist.sample()`; caller `select_action`, :205-217).  env_ids_dev int64 [n_envs] = the GLOBAL id of every env, s0 = the (seed, step) word of
+ * xroute_env_amd.agents.counter_uniform: action_dev = a sample of Categorical(softmax(logits)) by the Gumbel-max trick over counter-based uniforms of
+ * (s0, global env id, rank of the net) — no generator state, so an env gets the same action whichever rank or batch evaluates it, and the same one the
+ * framework path's tensor ops choose (same integer hash, same float operations in the same order).  env_ids_dev == NULL: the greedy action. */
+int32_t xr_agent_actor_sample(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
+                              const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
+                              int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, const int64_t* env_ids_dev, uint64_t s0, void* stream);
 
 /* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
 /* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43).

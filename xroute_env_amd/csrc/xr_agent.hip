@@ -460,7 +460,8 @@ template <bool PRE>       // PRE: the net half of the first layer comes applied 
 __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__ state, const float* __restrict__ head, int64_t head_stride, int ids_off,
                                                        const int32_t* __restrict__ nlegal, const int32_t* __restrict__ region,
                                                        const float* __restrict__ cache_vec, const float* __restrict__ cache_pre, int cache_kmax, const float* __restrict__ wt, int kcap,
-                                                       float* __restrict__ logits, int32_t* __restrict__ action) {
+                                                       float* __restrict__ logits, int32_t* __restrict__ action,
+                                                       const int64_t* __restrict__ env_ids, uint64_t s0) {
     __shared__ float s_w1n[PRE ? 1 : 64 * 128];       // net half of the first layer, [in][out]
     __shared__ float s_w2[128 * 64];
     __shared__ float s_st[64], s_vec[64], s_h1[128];
@@ -478,6 +479,19 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     const float b2 = j < 64 ? wt[XA_B2 + j] : 0.f, w3 = j < 64 ? wt[XA_W3 + j] : 0.f, b3 = wt[XA_B3];
     float best = -INFINITY;
     int besta = 0;
+    // PPO's rollout action (env_ids != null): a sample of Categorical(softmax(logits)) by the Gumbel-max trick, with the counter-based uniform
+    // of xroute_env_amd.agents.counter_uniform — the same integer hash of (s0, GLOBAL env id, rank k of the net), the same float operations in
+    // the same order (u -> -log(-log(u)) -> logit + g -> first maximum), so the kernel picks what the framework's tensor ops pick
+    const uint64_t gid = env_ids ? (uint64_t)env_ids[e] * 16384ull : 0ull;
+    auto score = [&](float lg, int k) -> float {
+        if (!env_ids) return lg;
+        uint64_t x = (gid + (uint64_t)k) ^ s0;
+        x = (x ^ ((x >> 30) & 0x3FFFFFFFFull)) * 0x3F58476D1CE4E5B9ull;
+        x = (x ^ ((x >> 27) & 0x1FFFFFFFFFull)) * 0x14D049BB133111EBull;
+        x = x ^ ((x >> 31) & 0x1FFFFFFFFull);
+        const float u = ((float)(uint32_t)((x >> 20) & 0xFFFFFFull) + 0.5f) * (1.0f / 16777216.0f);
+        return lg - logf(-logf(u));
+    };
     if (PRE) {
         // two nets per round: both waves add their first-layer halves for both nets, then wave 0 runs the second layer of net k and wave 1 that of net
         // k + 1 (every lane busy, half the barriers); thread 0 takes the two logits in order.  The net ids are staged in LDS once and the first-layer
@@ -514,8 +528,9 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
             if (j == 0) {
                 const float l0 = s_lg[0], l1 = s_lg[1];
                 if (logits) { logits[(int64_t)e * kcap + k] = l0; if (k + 1 < nl) logits[(int64_t)e * kcap + k + 1] = l1; }
-                if (l0 > best) { best = l0; besta = id0; }
-                if (k + 1 < nl && l1 > best) { best = l1; besta = id1; }
+                const float s0_ = score(l0, k), s1_ = score(l1, k + 1);
+                if (s0_ > best) { best = s0_; besta = id0; }
+                if (k + 1 < nl && s1_ > best) { best = s1_; besta = id1; }
             }
             c0 = n0; c1 = n1;
         }
@@ -539,7 +554,8 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
             const float lg = p + b3;
             if (j == 0) {
                 if (logits) logits[(int64_t)e * kcap + k] = lg;
-                if (lg > best) { best = lg; besta = id; }
+                const float sc = score(lg, k);
+                if (sc > best) { best = sc; besta = id; }
             }
         }
     }
@@ -606,6 +622,17 @@ int32_t xr_agent_actor_weights(void) { return XA_TOTAL; }
 int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
                        const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
                        int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, void* stream) {
+    return xr_agent_actor_sample(state_dev, head_dev, head_stride, ids_off, nlegal_dev, region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev,
+                                 n_envs, kcap, logits_dev, action_dev, nullptr, 0ull, stream);
+}
+
+// The same with PPO's rollout sampling inside (baseline/PPO/PPO.py:124-146, 205-217: `dist = Categorical(action_probs); action = dist.sample()`):
+// env_ids_dev int64 [n_envs] = the GLOBAL id of every env, s0 = the (seed, step) mix of xroute_env_amd.agents.counter_uniform -> action_dev = a sample of
+// Categorical(softmax(logits)) by the Gumbel-max trick with counter-based uniforms (no generator state: the same env gets the same action whichever
+// rank or batch evaluates it).  env_ids_dev == NULL: the greedy action (xr_agent_actor).
+int32_t xr_agent_actor_sample(const float* state_dev, const float* head_dev, int64_t head_stride, int32_t ids_off, const int32_t* nlegal_dev,
+                              const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
+                              int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, const int64_t* env_ids_dev, uint64_t s0, void* stream) {
     if (!state_dev || !head_dev || !nlegal_dev || !region_dev || !cache_vec_dev || !weights_dev || !action_dev || n_envs < 0 || kcap < 1 || cache_kmax < 1 ||
         ids_off < 0 || head_stride < (int64_t)ids_off + kcap)
         return XR_ERR_INVALID;
@@ -613,10 +640,10 @@ int32_t xr_agent_actor(const float* state_dev, const float* head_dev, int64_t he
     if (n_envs == 0) return XR_OK;
     if (cache_pre_dev)
         hipLaunchKernelGGL(xr_actor_kernel<true>, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
-                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev, env_ids_dev, s0);
     else
         hipLaunchKernelGGL(xr_actor_kernel<false>, dim3(n_envs), dim3(128), 0, static_cast<hipStream_t>(stream), state_dev, head_dev, head_stride, ids_off, nlegal_dev,
-                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev);
+                           region_dev, cache_vec_dev, cache_pre_dev, cache_kmax, weights_dev, kcap, logits_dev, action_dev, env_ids_dev, s0);
     return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
 }
 
