@@ -438,7 +438,8 @@ def main():
             batch.step(acts)
         stagger = (off, pre_seeds)
 
-    fused = (obs is not None) and not args.no_fuse
+    with_obs = obs is not None                      # (the buffer itself is released before the late legs)
+    fused = with_obs and not args.no_fuse
     learner = args.learner and world > 1 and rec_all is not None
     if learner:
         from xroute_env_amd.dist import random_legal_policy, unpack_records
@@ -651,6 +652,10 @@ def main():
                 kernels.append(ent)
             except Exception as ex:
                 kernels.append({"kernel": "xr_step_queue_kernel (in-place)", "error": str(ex)})
+        # the headline's observation buffer (36 GB) and batch are not needed by the legs below, which bring their own: released here, so that every
+        # leg runs beside nothing but itself, like the stand-alone commands the profiles were taken with (bench.py --region-pack ...)
+        obs = None
+        torch.cuda.empty_cache()
         if c5_regions:
             try:
                 kernels.append(config5_leg(args, c5_regions, dev))
@@ -745,7 +750,7 @@ def main():
                                     f"BASELINE configs 2-4), {B} per GPU, ")
                                    +
                                    f"full step = random net-order action + XR-Maze {'v2 (maze_end_iter 3, guide cost 800)' if args.maze_v2 else 'v1'} route + metrics/reward"
-                                   + ("" if obs is None else " + reference-layout fp32 observation of every env")
+                                   + ("" if not with_obs else " + reference-layout fp32 observation of every env")
                                    + (" (queue form: one persistent launch after a planning kernel)" if headline_form == 3 else
                                       " (split form: route kernel + concurrent net-plane writer)" if headline_form == 2 else
                                       " (fused launch: one workgroup per env)" if fused else "")
@@ -771,7 +776,7 @@ def main():
                 out["extras"]["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=obs is not None)
+                out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=with_obs)
             except Exception as ex:          # the oracle is optional for the GPU number itself
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}
