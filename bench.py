@@ -92,6 +92,10 @@ def parse():
                          "counterpart (random-init weights of the reference architecture), env in compact-consumer mode")
     ap.add_argument("--agent-lib-tower", action="store_true", help="--agent: the obstacle tower through the framework's convolutions instead of the fused HIP kernel (A/B)")
     ap.add_argument("--agent-full-obs", action="store_true", help="--agent: feed the full fp32 observation (xr_batch_step_observe) instead of the compact mode")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: take every N > 1 branch anyway — process group on the real backend (RCCL: init with a device id), the async "
+                         "all_gather buffer pairs + Work.wait(), verify_gather, broadcast, all_reduce, the learner's gather — with one rank.  A functional "
+                         "run of the multi-GPU code path on one GPU (also: XR_FORCE_COLLECTIVES=1); the line says so in config.forced_collectives")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="run 1 GiB fill/add kernels first (known HBM byte counts for rocprofv3 --pmc passes)")
     return ap.parse_args()
@@ -314,6 +318,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.force_collectives or os.environ.get("XR_FORCE_COLLECTIVES") == "1":
+        if world != 1:
+            sys.exit("bench.py: --force-collectives is for one rank (with more ranks the collectives run anyway)")
+        os.environ["XR_FORCE_COLLECTIVES"] = "1"            # xroute_env_amd.dist.collectives_on() reads it
+        args.force_collectives = True
+        for k_, v_ in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29500 + os.getpid() % 20000)), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k_, v_)
+    multi = world > 1 or args.force_collectives             # the collective code paths run
     if world != args.gpus:
         # never benchmark a different number of GPUs than the one asked for (a flat, wrong scaling curve)
         if rank == 0:
@@ -334,13 +346,13 @@ def main():
     elif args.regions > 0:
         # `--regions R`: R distinct regions of the config, the SAME on every rank, cycled over the env slots (global env g plays region
         # g % R) — BASELINE config 5's multi-GPU form: 1024 slots of 256x256x12 per GPU over 128 distinct regions, like its one-GPU leg
-        regions = gen_regions(args.config, min(args.regions, max(B, 1)), 0) if not (world > 1 or strong) else gen_regions(args.config, args.regions, 0)
+        regions = gen_regions(args.config, min(args.regions, max(B, 1)), 0) if not (multi or strong) else gen_regions(args.config, args.regions, 0)
     else:
         regions = gen_regions(args.config, B, first_env)
     learner_regions = None
-    if args.agent and args.learner and world > 1 and rank == 0 and not args.region_pack and args.regions == 0:
+    if args.agent and args.learner and multi and rank == 0 and not args.region_pack and args.regions == 0:
         learner_regions = gen_regions(args.config, args.global_envs if strong else args.envs * world, 0)      # the central learner's region table: every env's region
-    do_legs = world == 1 and rank == 0 and not args.no_legs and not args.region_pack
+    do_legs = (not multi) and rank == 0 and not args.no_legs and not args.region_pack
     c5_regions = gen_regions(5, min(args.c5_regions, args.c5_envs)) if do_legs and args.c5_envs > 0 else None
     pack_regions = None
     if do_legs and args.pack_envs > 0 and os.path.exists(PACK_PATH):
@@ -357,7 +369,7 @@ def main():
     backend = os.environ.get("XR_BENCH_BACKEND", "nccl")
     if os.environ.get("XR_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -378,11 +390,11 @@ def main():
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.dist import RECORD_BYTES, gather_records_fixed
 
-    if args.agent and (world > 1 or strong or args.learner):
+    if args.agent and (multi or strong or args.learner):
         # BASELINE config 4 as stated ("4096 regions sharded 8 x MI355X, PPO baseline, RCCL env gather"): every rank evaluates the policy
         # counterpart on ITS shard (or, --learner, rank 0 for all envs from gathered compact state) — one self-certifying line
         rc = agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner_regions)
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         sys.exit(rc)
@@ -407,13 +419,13 @@ def main():
     obs = None if args.no_observation else batch.alloc_observation()
     # compact per-env result record gathered across ranks: the 48-byte xr_step_record the kernels write themselves
     rec_local = torch.empty((B, RECORD_BYTES), dtype=torch.uint8, device=dev)
-    rec_all = torch.empty((world * B, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 and not strong else None
-    if world > 1 and strong:
+    rec_all = torch.empty((world * B, RECORD_BYTES), dtype=torch.uint8, device=dev) if multi and not strong else None
+    if multi and strong:
         rec_all = torch.empty((args.global_envs, RECORD_BYTES), dtype=torch.uint8, device=dev) \
             if args.global_envs % world == 0 else None
     nsteps_total = args.warmup + args.steps
     nlegal_log = torch.zeros((max(nsteps_total, 1), B), dtype=torch.int32, device=dev)
-    n_par = min(B, 256 if world == 1 else 32)          # envs of this rank the oracle replays after the run (`parity`)
+    n_par = min(B, 256 if (not multi) else 32)          # envs of this rank the oracle replays after the run (`parity`)
     if regions[0].n_nodes > 100000:                    # (BASELINE config 5: a Dijkstra over 786 k nodes per search)
         n_par = min(n_par, 16)
     acts_log = torch.zeros((max(nsteps_total, 1), n_par), dtype=torch.int32, device=dev)
@@ -440,7 +452,7 @@ def main():
 
     with_obs = obs is not None                      # (the buffer itself is released before the late legs)
     fused = with_obs and not args.no_fuse
-    learner = args.learner and world > 1 and rec_all is not None
+    learner = args.learner and multi and rec_all is not None
     if learner:
         from xroute_env_amd.dist import random_legal_policy, unpack_records
         Bg_all = rec_all.shape[0]
@@ -478,7 +490,7 @@ def main():
         if ev:
             ev[2].record()
         batch.fetch("nlegal", nlegal_log[i])
-        if world > 1 and rec_pairs is not None and not learner:
+        if multi and rec_pairs is not None and not learner:
             slot = i & 1
             if pending[slot] is not None:
                 pending[slot].wait()
@@ -488,7 +500,7 @@ def main():
             last_gather[0] = slot
             return
         batch.fetch("record", rec_local)
-        if world > 1:
+        if multi:
             if learner:
                 batch.fetch("legal", legal_local)
                 dist.all_gather_into_tensor(legal_all, legal_local)
@@ -506,7 +518,7 @@ def main():
     pending[:] = [None, None]
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     steps0 = batch.total_steps()
@@ -518,7 +530,7 @@ def main():
             w_.wait()
     pending[:] = [None, None]
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     real_steps = batch.total_steps() - steps0
@@ -531,7 +543,7 @@ def main():
 
     # ---- N > 1: the run certifies itself — the gather delivered every rank's records, and every rank's envs replay on the oracle
     certify = None
-    if world > 1:
+    if multi:
         from xroute_env_amd.dist import verify_gather
         gathered, sent = last_gather[0], rec_local
         if isinstance(gathered, int):               # the overlapped gather: the buffer pair of the last step
@@ -545,7 +557,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([float(real_steps)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
     elapsed_max, total_real = float(t.item()), float(s.item())
@@ -712,14 +724,14 @@ def main():
 
     parity = None
     can_replay = not args.region_pack and (len(regions) >= B or args.regions > 0)      # regions == env slots: rotation keeps every slot on its region (--regions: no rotation), the oracle subset can follow
-    if can_replay and (world > 1 or not args.no_cpu_baseline):
+    if can_replay and (multi or not args.no_cpu_baseline):
         try:
             seeds = [args.seed + rank * 7919 + i for i in range(args.warmup + args.steps)]
             parity = parity_check(slot_regions, seeds, stagger, gpu_hash, gpu_cum, n_check=n_par, obs_sha=obs_sha,
                                   actions_log=acts_log.cpu().numpy() if learner else None, v2=main_v2 or None)
         except Exception as ex:
             parity = {"error": str(ex), "ok": False}
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if (parity or {}).get("ok") else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         parity = dict(parity or {}, all_ranks_ok=bool(flag.item() == 1), envs_per_rank=n_par)
@@ -754,13 +766,15 @@ def main():
                                    + (" (queue form: one persistent launch after a planning kernel)" if headline_form == 3 else
                                       " (split form: route kernel + concurrent net-plane writer)" if headline_form == 2 else
                                       " (fused launch: one workgroup per env)" if fused else "")
-                                   + (", RCCL all_gather of per-env results" + ("" if learner else " overlapped with the next step (two buffer pairs, async)") if world > 1 else "")
+                                   + (", RCCL all_gather of per-env results" + ("" if learner else " overlapped with the next step (two buffer pairs, async)") if multi else "")
                                    + (" + learner flow (policy on rank 0, i32 action broadcast)" if learner else "")
                                    + ("" if args.no_stagger else "; episodes staggered to the stationary nets-left distribution before timing"),
                        "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}",
                        "mean_nets_left": round(mean_k, 2), "slots_stepped_per_batch_step": round(total_real / (nst * B * world), 4),
                        "router": {0: "default", 1: "sweep", 2: "dial"}[args.router], "source_sha": source_sha(),
-                       "bench_args": bench_args_key(args, world)},
+                       "bench_args": bench_args_key(args, world),
+                       **({"forced_collectives": "one rank taking every N > 1 branch on the real backend (--force-collectives): a functional run of the multi-GPU code path, not a scaling point"}
+                          if args.force_collectives else {})},
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kernels],
         }
@@ -774,20 +788,20 @@ def main():
             out["extras"] = extras_leg(args, regions, dev, batch, obs)
             if sustained is not None:
                 out["extras"]["sustained"] = sustained
-        if world == 1 and not args.no_cpu_baseline:
+        if (not multi) and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(regions, args.cpu_seconds, with_obs=with_obs)
             except Exception as ex:          # the oracle is optional for the GPU number itself
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}
-        failed = world > 1 and not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
+        failed = multi and not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
         if failed:          # an N-GPU label is only printed for a run that proved it was one
             out["n_gpus"] = None
             out["error"] = (f"N > 1 self-certification failed: ranks_seen {certify['ranks_seen']} of {args.gpus}, gather_verified "
                             f"{certify['gather_verified']}, parity on every rank {parity.get('all_ranks_ok')}")
             print(out["error"], file=sys.stderr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
         if not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok")):
@@ -996,7 +1010,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                   vectors of its own regions cached), steps its slice in compact-consumer mode, and the 48-byte result records are
                   all-gathered (overlapped with the next step) — north_star's "RCCL only for the batched-env gather".
       --learner   SURVEY §8e's central learner: every rank packs the compact state of its envs (xr_batch_pack_state: one bit per node +
-                  the legal bitmask), ONE all_gather carries it, rank 0 expands it to head rows (xr_batch_expand_state), evaluates the
+                  the legal bitmask), ONE gather to rank 0 carries it, rank 0 expands it to head rows (xr_batch_expand_state), evaluates the
                   policy for ALL envs and broadcasts the actions (i32); the ranks step route-only.
 
     PPO samples with counter-based uniforms of (seed, step, GLOBAL env id, net rank) (agents.counter_uniform), so both placements and
@@ -1010,6 +1024,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     from xroute_env_amd.batch import RegionBatch
     from xroute_env_amd.dist import RECORD_BYTES, gather_rows, verify_gather
     learner = bool(args.learner)
+    multi = world > 1 or os.environ.get("XR_FORCE_COLLECTIVES") == "1"          # the collective code paths run (--force-collectives: with one rank)
     cycled = bool(args.region_pack) or args.regions > 0            # global env g plays region g % len(regions); else one region per env slot
     Bg = args.global_envs if strong else B * world
     mixed = len({tuple(int(v) for v in r.dims) for r in regions}) > 1
@@ -1033,7 +1048,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     pol_batch, pol_regions, region_base = batch, regions, 0
     if learner and not cycled:
         region_base = first_env
-        if rank == 0 and world > 1:
+        if rank == 0 and multi:
             pol_regions = learner_regions                # (every region of the job, generated by main() before the GPU was touched)
             pol_batch = RegionBatch(pol_regions, n_envs=1, device=dev)
     evaluates = (not learner) or rank == 0
@@ -1084,7 +1099,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
         off = stagger_offsets(batch.fetch("nlegal").cpu().numpy(), first_env)
         off_d = torch.from_numpy(off).to(dev)
         mx = torch.tensor([int(off.max()) if B else 0], dtype=torch.int64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         n_pre = int(mx.item())
         pre_log = torch.zeros((max(n_pre, 1), B), dtype=torch.int32, device=dev)
@@ -1100,7 +1115,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     nsteps_total = max(args.warmup, 2) + args.steps
     acts_log = torch.zeros((nsteps_total, B), dtype=torch.int32, device=dev)
     rec_pairs = [(torch.empty((B, RECORD_BYTES), dtype=torch.uint8, device=dev),
-                  torch.empty((Bg, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 and Bg % world == 0 else None) for _ in range(2)]
+                  torch.empty((Bg, RECORD_BYTES), dtype=torch.uint8, device=dev) if multi and Bg % world == 0 else None) for _ in range(2)]
     pending = [None, None]
     last_slot = [0]
     split = {"pack_gather": 0.0, "expand": 0.0, "policy": 0.0, "broadcast": 0.0, "env": 0.0}
@@ -1118,7 +1133,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
             else:
                 mark(2)
             mark(3)
-            if world > 1:
+            if multi:
                 dist.broadcast(acts_all, src=0)                             # the actions travel back as one i32[Bg]
             acts.copy_(acts_all[first_env:first_env + B])
         else:
@@ -1140,7 +1155,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
             pending[slot] = None
         loc, glob = rec_pairs[slot]
         batch.fetch("record", loc)
-        if world > 1 and glob is not None:
+        if multi and glob is not None:
             pending[slot] = dist.all_gather_into_tensor(glob, loc, async_op=True)          # the batched-env gather, overlapped with the next step
         last_slot[0] = slot
 
@@ -1152,7 +1167,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
             pending[j].wait(); pending[j] = None
     n = max(args.steps, 1)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n)]
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     steps0 = batch.total_steps()
@@ -1163,7 +1178,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
         if pending[j] is not None:
             pending[j].wait(); pending[j] = None
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     real_steps = batch.total_steps() - steps0
@@ -1172,12 +1187,12 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     gpu_hash = batch.fetch("hash").cpu().numpy().view("uint64")
     gpu_cum = batch.fetch("cum").cpu().numpy()
     nl_now = batch.fetch("nlegal")
-    n_par = min(B, 64 if world == 1 else 32)
+    n_par = min(B, 64 if (not multi) else 32)
     obs_sha = None if learner else obs_sample_sha(head, nl_now, slot_regions[:n_par], n_check=n_par, head_only=True)
 
     # ---- certification: the gather, every rank's oracle replay, and the sharding-invariant digests ---------------------------------
     certify = None
-    if world > 1:
+    if multi:
         sent, gathered = rec_pairs[last_slot[0]]
         if gathered is None:
             gathered = gather_rows(sent)
@@ -1186,7 +1201,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
         certify = verify_gather(sent, gathered, first_env)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     sm = torch.tensor([float(real_steps), split["policy"] + split["expand"], split["env"]], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tsum = sm.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -1198,7 +1213,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
     # actions of every env at every step and every env's final hash chain, in GLOBAL env order (tiny gathers, outside the timed region)
     al = acts_log.t().contiguous()                                   # [B, steps]
     hs = torch.from_numpy(gpu_hash.view("int64").copy()).to(dev).reshape(B, 1)
-    if world > 1:
+    if multi:
         al, hs = gather_rows(al), gather_rows(hs)
     actions_sha = hashlib.sha256(al.cpu().numpy().tobytes()).hexdigest()
     chains_sha = hashlib.sha256(hs.cpu().numpy().tobytes()).hexdigest()
@@ -1210,11 +1225,11 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                           "hash chains, cumulative metrics" + ("" if learner else ", sha256 of planes 0..1 the last compact step wrote vs the oracle's build_3Dgrid restatement"))
     except Exception as ex:
         parity = {"error": str(ex), "ok": False}
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if parity.get("ok") else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         parity = dict(parity, all_ranks_ok=bool(flag.item() == 1), envs_per_rank=n_par)
-    good = world == 1 or (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
+    good = (not multi) or (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
     good = bool(good and parity.get("ok"))
     if rank == 0:
         agent_ms = split["pack_gather"] + split["expand"] + split["policy"] + split["broadcast"]
@@ -1229,17 +1244,19 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                                           if args.region_pack else "of ispd18_test1-sized regions (24x40x9, K~U[4,36]), ")
                                        + f"full maze route per step, {args.agent.upper()} counterpart (random-init weights of the reference architecture, replicated from one seed, eval mode"
                                        + (", actions sampled with counter-based uniforms of (seed, step, global env, net rank)" if args.agent == "ppo" else "") + ") choosing every action; "
-                                       + ("policy on rank 0 for ALL envs from the gathered compact state (xr_batch_pack_state -> all_gather -> xr_batch_expand_state), i32 action broadcast, ranks step route-only"
+                                       + ("policy on rank 0 for ALL envs from the gathered compact state (xr_batch_pack_state -> gather to rank 0 -> xr_batch_expand_state), i32 action broadcast, ranks step route-only"
                                           if learner else
                                           "policy evaluated by every rank on ITS shard, compact-consumer step (xr_batch_step_compact: planes 0..1 per step; net vectors cached per (region, net))")
-                                       + ("; RCCL all_gather of the 48-byte per-env records overlapped with the next step" if world > 1 else "")
+                                       + ("; RCCL all_gather of the 48-byte per-env records overlapped with the next step" if multi else "")
                                        + ("" if args.no_stagger else "; episodes staggered before timing")),
                           "envs_per_gpu": B, "global_envs": Bg, "parallelism": f"env-shard x{world}", "policy_placement": "rank 0 (central learner)" if learner else "every rank (its shard)",
-                          "mean_nets_left": round(float(nl_now.double().mean().item()), 2), "source_sha": source_sha()},
+                          "mean_nets_left": round(float(nl_now.double().mean().item()), 2), "source_sha": source_sha(),
+                          **({"forced_collectives": "one rank taking every N > 1 branch on the real backend (--force-collectives): a functional run of the multi-GPU code path, not a scaling point"}
+                             if (multi and world == 1) else {})},
                "agent_ms_per_step": round(agent_ms, 4), "env_ms_per_step": round(split["env"], 4),
                "env_share_of_step_time": round(split["env"] / max(split["env"] + agent_ms, 1e-9), 4),
                "step_split_ms_rank0": {k_: round(v_, 4) for k_, v_ in split.items()},
-               "slowest_rank_ms": {"policy": round(float(sm[1].item()), 4), "env": round(float(sm[2].item()), 4)} if world > 1 else None,
+               "slowest_rank_ms": {"policy": round(float(sm[1].item()), 4), "env": round(float(sm[2].item()), 4)} if multi else None,
                "actions_sha": actions_sha, "hash_chains_sha": chains_sha, "parity": parity,
                "roofline": {"kernel": "xr_route_kernel" + ("" if learner else " (+ planes 0..1)"), "bound": "hbm",
                             "achieved": round(B * ((4.0 if learner else 12.0) * N_mean) / (max(split["env"], 1e-9) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -1248,6 +1265,9 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                             "note": "the env step of this line is the LDS-resident router (latency-bound): its HBM bytes are the state load" + ("" if learner else " + the two head planes")}}
         if learner:
             out["compact_state"] = {"row_bytes": rb, "bytes_gathered_per_step": Bg * rb, "fp32_head_bytes_per_step": int(Bg * 8 * N_mean),
+                                    "collective": "gather to rank 0 (every other rank sends its rows once over its own link; nobody else receives them)",
+                                    "bytes_per_link_per_step": xch.bytes_per_link,
+                                    "all_gather_bytes_per_link_per_step": int(Bg * rb * (world - 1) / max(world, 1)),
                                     "ratio_to_fp32_planes": round(rb / (8.0 * N_mean), 5),
                                     "what": "per env: region, nets left, legal-net bitmask, one occupancy bit per node (plane 0); plane 1 is the bitmask — "
                                             "what SURVEY §8e's central learner gathers instead of observations"}

@@ -71,7 +71,7 @@ else:
 ret = torch.zeros(n_total, dtype=torch.float64, device=dev)
 for t in range(6):
     if central:
-        rows = xch.gather()                                           # pack + one all_gather: n_total x 1.1 KB
+        rows = xch.gather()                                           # pack + one gather to rank 0: n_local x 1.1 KB per link
         if rank == 0:
             acts_all.copy_(choose(t, *xch.expand(rows)))
         if world > 1:

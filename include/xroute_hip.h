@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XR_ABI_VERSION 8
+#define XR_ABI_VERSION 9
 
 /* status codes */
 #define XR_OK            0
@@ -404,13 +404,17 @@ int32_t xr_agent_actor_sample(const float* state_dev, const float* head_dev, int
                               int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, const int64_t* env_ids_dev, uint64_t s0, void* stream);
 
 /* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
-/* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43).
- * Pass 1 (fields_host == NULL): fills info_host[8] = {kind (1 request, 2 response, 0 empty),
+/* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43; the `message.ParseFromString` of :418,467), with the
+ * runtime's parse rules: the oneof keeps the LAST member on the wire, a repeated occurrence of the same member merges (scalars: last
+ * value, `nodes` / `nets`: appended), unknown fields of every wire type (groups included) are skipped, packed and unpacked `nets` mix.
+ * Pass 1 (fields_host == NULL, nets_host == NULL): fills info_host[8] = {kind (1 request, 2 response, 0 empty),
  * dim_x, dim_y, dim_z, n_nodes, n_nets, is_done, response.net_index} and metrics_host[3].
- * Pass 2: fields_host int32[n_nodes][10] = maze xyz, point xyz, type, is_used, net, pin (wire
- * values, 0-based); nets_host uint32[n_nets]. */
+ * Pass 2: fields_host int32[fields_cap][10] = maze xyz, point xyz, type, is_used, net, pin (wire values, 0-based);
+ * nets_host uint32[nets_cap].  Capacities are in rows / entries; nothing is ever written past them (ABI 9: round 5's two-pointer form
+ * trusted pass 1's counts, which a oneof flip makes smaller than what an earlier, dropped member held).  XR_ERR_RANGE when what the
+ * message finally holds does not fit (info_host carries the counts needed); XR_ERR_PARSE for bytes the runtimes refuse. */
 int32_t xr_proto_decode(const uint8_t* buf_host, size_t len, int64_t* info_host, uint32_t* metrics_host,
-                        int32_t* fields_host, uint32_t* nets_host);
+                        int32_t* fields_host, int64_t fields_cap, uint32_t* nets_host, int64_t nets_cap);
 /* Encodes Message{response{net_index}} exactly as Game.step does (:409-411). Returns bytes written
  * through *len (buf capacity >= 16). */
 int32_t xr_proto_encode_response(int32_t net_index, uint8_t* buf_host, size_t* len);

@@ -139,8 +139,13 @@ def _worker(rank, world, port, q):
         l2, h2 = shard_range(n_tot, world, rank)
         fb = _FakeStateBatch(h2 - l2, words=3 + 2 * rank)
         xch = CompactStateExchange(fb, n_tot, l2, region_base=l2)
-        rows = xch.gather()
-        xch_out.append((xch.row_bytes, xch.bytes_per_step, rows.view(torch.int32)[:, :2].clone().numpy(), xch.expand(rows)[0].numpy()))
+        rows = xch.gather()                          # to the learner (rank 0) only: the other ranks send and receive nothing
+        assert (rows is None) == (rank != 0)
+        everywhere = xch.gather(to_all=True)         # round 5's all_gather form is still there
+        if rank == 0:
+            assert torch.equal(rows, everywhere)
+        rows = everywhere
+        xch_out.append((xch.row_bytes, xch.bytes_per_step, rows.view(torch.int32)[:, :2].clone().numpy(), xch.expand(rows)[0].numpy(), xch.bytes_per_link))
     q.put((rank, [r.numpy() for r in recs], [s.numpy() for s in sent], (lo, hi), [p.numpy() for p in plain], eq_all.numpy(), cert, xch_out))
     dist.barrier()
     dist.destroy_process_group()
@@ -205,8 +210,10 @@ def test_two_rank_learner_flow_equals_single_process():
     single_recs, single_sent, _ = _run_learner(N_TOTAL, STEPS)
     for rank in (0, 1):
         recs, sent, (lo, hi), plain, eq_all, cert, xch_out = got[rank]
-        for (rb, per_step, hdr, regions_seen), n_tot in zip(xch_out, (10, N_TOTAL)):
-            assert rb == 16 + 8 * 5 and per_step == n_tot * rb                  # the larger of the two ranks' row sizes, on both ranks
+        for (rb, per_step, hdr, regions_seen, per_link), n_tot in zip(xch_out, (10, N_TOTAL)):
+            n_loc = shard_range(n_tot, 2, rank)[1] - shard_range(n_tot, 2, rank)[0]
+            assert rb == 16 + 8 * 5                                             # the larger of the two ranks' row sizes, on both ranks
+            assert per_link == n_loc * rb and per_step == n_tot * rb             # a gather to the learner: a rank's rows cross ONE link once
             assert hdr[:, 0].tolist() == list(range(n_tot)) and (hdr[:, 1] == 7).all() and regions_seen.tolist() == list(range(n_tot))
         assert len(recs) == STEPS
         assert cert[0] == {"ranks_seen": 2, "gather_verified": True, "rows": 10}

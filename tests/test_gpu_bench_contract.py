@@ -272,3 +272,49 @@ def test_config4_rollout_example_same_episode_in_every_placement():
     assert run(1, ["--central"]) == ref
     assert run(2, []) == ref
     assert run(2, ["--central"]) == ref
+
+
+def _forced_nccl(bench_args):
+    """bench.py --gpus 1 --force-collectives on the REAL backend (no XR_BENCH_BACKEND override: "nccl" = RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("XR_BENCH_BACKEND", "XR_BENCH_SAME_DEVICE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collectives"] + bench_args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_code_path_runs_with_one_rank():
+    """VERDICT r5 missing #1: every distributed test forces gloo, so `init_process_group("nccl", device_id=..)`, the two-buffer async
+    `all_gather_into_tensor` of uint8 rows + `Work.wait()` on RCCL's stream, `verify_gather`, `broadcast`, `all_reduce(MAX/SUM/MIN)` and the
+    central learner's exchange (row-size `all_reduce`, `gather` to rank 0) had never executed — the first 8-GPU run would also have been the
+    first RCCL call.  `--force-collectives` makes ONE rank take every N > 1 branch on the real backend: env-only, `--agent ppo` per rank,
+    `--learner`, and BASELINE config 5's multi-GPU form.  Same actions and hash chains as the plain one-rank lines."""
+    # env-only headline shape (weak scaling form: the async gather pairs) and its learner form (records + legal masks gathered, broadcast)
+    d = _forced_nccl(["--steps", "4", "--warmup", "2", "--envs", "256", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["gather_verified"] is True and d["ranks_seen"] == 1 and d["gathered_rows"] == 256
+    assert d["parity"]["all_ranks_ok"] is True and d["parity"]["ok"] is True and "forced_collectives" in d["config"]
+    assert "RCCL all_gather" in d["config"]["workload"] and d["value"] > 0
+    dl = _forced_nccl(["--steps", "3", "--warmup", "1", "--envs", "128", "--no-cpu-baseline", "--learner"])
+    assert dl["gather_verified"] is True and dl["ranks_seen"] == 1 and dl["parity"]["all_ranks_ok"] is True
+    # strong-scaling form (--global-envs): the same gather through the other buffer set-up
+    ds = _forced_nccl(["--steps", "3", "--warmup", "1", "--global-envs", "192", "--no-cpu-baseline"])
+    assert ds["scaling"] == "strong" and ds["gather_verified"] is True and ds["gathered_rows"] == 192 and ds["parity"]["all_ranks_ok"] is True
+    # BASELINE config 4: PPO per rank, then the central learner — same actions env for env as the plain one-rank line
+    common = ["--global-envs", "192", "--agent", "ppo", "--steps", "3", "--warmup", "2"]
+    one = _torchrun(1, common)
+    per_rank = _forced_nccl(common)
+    assert per_rank["gather_verified"] is True and per_rank["ranks_seen"] == 1 and per_rank["parity"]["all_ranks_ok"] is True
+    assert per_rank["actions_sha"] == one["actions_sha"] and per_rank["hash_chains_sha"] == one["hash_chains_sha"]
+    assert "forced_collectives" in per_rank["config"] and "RCCL all_gather" in per_rank["config"]["workload"]
+    central = _forced_nccl(common + ["--learner"])
+    assert central["gather_verified"] is True and central["ranks_seen"] == 1 and central["parity"]["all_ranks_ok"] is True
+    assert central["actions_sha"] == one["actions_sha"] and central["hash_chains_sha"] == one["hash_chains_sha"]
+    cs = central["compact_state"]
+    assert cs["collective"].startswith("gather to rank 0") and cs["bytes_per_link_per_step"] == 192 * cs["row_bytes"]
+    assert central["step_split_ms_rank0"]["pack_gather"] > 0 and central["step_split_ms_rank0"]["expand"] > 0
+    # BASELINE config 5's multi-GPU form
+    c5 = _forced_nccl(["--config", "5", "--envs", "8", "--regions", "4", "--no-observation", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert c5["gather_verified"] is True and c5["ranks_seen"] == 1 and c5["parity"]["all_ranks_ok"] is True and "config 5" in c5["config"]["workload"]

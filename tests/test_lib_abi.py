@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_config_defaults():
     L = _lib.lib()
-    assert L.xr_abi_version() == 8
+    assert L.xr_abi_version() == 9
     cfg = _lib.default_config()
     assert cfg.struct_size == C.sizeof(_lib.XrConfig)
     assert (cfg.via_cost, cfg.drc_cost, cfg.drc_unit, cfg.max_route_count) == (800, 8, 400, 10)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("XR_LIB", "libxroute_hip.so"))   # XR_LIB: experiment builds
 
 XR_OK = 0
+ABI_VERSION = 9
 XR_ERR_INVALID, XR_ERR_NOMEM, XR_ERR_HIP, XR_ERR_STATE, XR_ERR_RANGE, XR_ERR_PARSE = -1, -2, -3, -4, -5, -6
 
 XR_ENV_OK, XR_ENV_BAD_ACTION, XR_ENV_UNREACHABLE, XR_ENV_PATH_TRUNC, XR_ENV_WAS_RESET, XR_ENV_ROUTER_ABORT = 0, 1, 2, 4, 8, 16
@@ -114,7 +115,7 @@ def lib():
     L.xr_agent_actor.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.xr_agent_actor_sample.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_uint64, vp]
     L.xr_observation_from_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
-    L.xr_proto_decode.argtypes = [vp, C.c_size_t, vp, vp, vp, vp]
+    L.xr_proto_decode.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_int64, vp, C.c_int64]
     L.xr_proto_encode_response.argtypes = [C.c_int32, vp, C.POINTER(C.c_size_t)]
     L.xr_proto_encode_request.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp,
                                           C.c_int32, vp, C.POINTER(C.c_size_t)]
@@ -122,7 +123,7 @@ def lib():
         fn = getattr(L, name)
         if name not in ("xr_last_error", "xr_config_default"):
             fn.restype = C.c_int32
-    if L.xr_abi_version() != 8:
+    if L.xr_abi_version() != ABI_VERSION:
         raise RuntimeError("libxroute_hip.so ABI version mismatch")
     _LIB = L
     return L

@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
         x = (x ^ ((x >> 30) & 0x3FFFFFFFFull)) * 0x3F58476D1CE4E5B9ull;
         x = (x ^ ((x >> 27) & 0x1FFFFFFFFFull)) * 0x14D049BB133111EBull;
         x = x ^ ((x >> 31) & 0x1FFFFFFFFull);
-        const float u = ((float)(uint32_t)((x >> 20) & 0xFFFFFFull) + 0.5f) * (1.0f / 16777216.0f);
+        const float u = ((float)(uint32_t)((x >> 20) & 0x7FFFFFull) + 0.5f) * (1.0f / 8388608.0f);      // 23 bits: k + 0.5 is exact, u strictly inside (0, 1) (agents.CounterUniform)
         return lg - logf(-logf(u));
     };
     if (PRE) {

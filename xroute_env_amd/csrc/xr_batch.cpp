@@ -308,6 +308,11 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         if (!d.xs_host || !d.ys_host || !d.layer_dir_host || !d.nodes_host)
             return fail(XR_ERR_INVALID, "region %d: null array", r);
         if (d.n_nets < 0 || d.n_nets > XR_MAX_NETS) return fail(XR_ERR_RANGE, "region %d: n_nets %d", r, d.n_nets);
+        // track coordinates within +-2^30 DBU: every difference of two of them (edge lengths, extents) then fits the kernels' int32 arithmetic
+        for (int i = 0; i < d.dim_x; i++)
+            if (d.xs_host[i] < -(1 << 30) || d.xs_host[i] > (1 << 30)) return fail(XR_ERR_RANGE, "region %d: xs[%d] = %d outside +-2^30", r, i, d.xs_host[i]);
+        for (int i = 0; i < d.dim_y; i++)
+            if (d.ys_host[i] < -(1 << 30) || d.ys_host[i] > (1 << 30)) return fail(XR_ERR_RANGE, "region %d: ys[%d] = %d outside +-2^30", r, i, d.ys_host[i]);
         for (int i = 1; i < d.dim_x; i++)
             if (d.xs_host[i] <= d.xs_host[i - 1]) return fail(XR_ERR_INVALID, "region %d: xs not strictly increasing", r);
         for (int i = 1; i < d.dim_y; i++)
@@ -788,7 +793,7 @@ int32_t xr_batch_load_regions(xr_batch* b, const xr_region_desc* regs, int32_t n
         const char* off = getenv("XR_NO_MEASURED_ORDER");
         d.net_meas = (off && off[0] == '1') ? nullptr : b->net_meas.p;
         const char* ht = getenv("XR_HEAVY_CLASS"); const char* hm = getenv("XR_HEAVY_MULT");       // (experiment switches)
-        d.heavy_class = ht ? atoi(ht) : 0; d.heavy_mult = hm ? atoi(hm) : 2;
+        d.heavy_class = std::min(255, std::max(0, ht ? atoi(ht) : 0)); d.heavy_mult = std::min(16, std::max(1, hm ? atoi(hm) : 2));   // (a width of 0 would spin a route to its round cap)
         d.meas_shift = b->lds_dist ? 13 : 15;       // class unit: 8 k cycles (LDS form: a route is 0.1-1.5 M cycles), 32 k (HBM-scratch form: up to 6 M)
     } d.ap_flags = b->ap_flags.p;
     d.legal0 = b->legal0.p; d.n_regions = n_regions;
@@ -847,8 +852,11 @@ static int32_t build_guide_masks(xr_batch* b, hipStream_t st) {
         b->guide_mask.release();
         return XR_OK;                    // (no memory for the masks: the per-route form still applies)
     }
-    XR_HIP(xr_launch_guide_masks(&b->dev, b->guide_mask.p, b->k_max, st));
-    XR_HIP(hipStreamSynchronize(st));
+    // (a mask build that cannot run degrades like one that has no memory: the router decides membership per route, same results)
+    if (xr_launch_guide_masks(&b->dev, b->guide_mask.p, b->k_max, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        b->guide_mask.release();
+        return XR_OK;
+    }
     b->dev.guide_mask = b->guide_mask.p;
     return XR_OK;
 }
@@ -861,8 +869,13 @@ int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, co
     if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_load_guides: load regions first");
     XR_HIP(hipSetDevice(b->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    b->dev.guide_csr = nullptr; b->dev.guide_box = nullptr;
-    if (!box_off_host) { b->guide_csr.release(); b->guide_box.release(); return build_guide_masks(b, st); }      // back to the default guides
+    // (everything is validated and staged BEFORE the batch is touched: a refused table, or one there is no device memory for, leaves
+    //  the guides loaded before — boxes and static masks alike — exactly as they were)
+    if (!box_off_host) {      // back to the default guides
+        b->dev.guide_csr = nullptr; b->dev.guide_box = nullptr;
+        b->guide_csr.release(); b->guide_box.release();
+        return build_guide_masks(b, st);
+    }
     std::vector<int32_t> csr(b->h_csr_size, 0);
     std::vector<int16_t> box;
     for (int r = 0; r < b->n_regions; r++) {
@@ -886,11 +899,15 @@ int32_t xr_batch_load_guides(xr_batch* b, const int32_t* const* box_off_host, co
         }
         c[K + 1] = (int32_t)(box.size() / 6);
     }
-    if (b->guide_csr.alloc(csr.size()) != hipSuccess || b->guide_box.alloc(std::max<size_t>(6, box.size())) != hipSuccess)
-        return fail(XR_ERR_HIP, "xr_batch_load_guides: hipMalloc failed");
-    XR_HIP(hipMemcpyAsync(b->guide_csr.p, csr.data(), csr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (!box.empty()) XR_HIP(hipMemcpyAsync(b->guide_box.p, box.data(), box.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here
+    DevBuf<int32_t> new_csr;
+    DevBuf<int16_t> new_box;
+    if (new_csr.alloc(csr.size()) != hipSuccess || new_box.alloc(std::max<size_t>(6, box.size())) != hipSuccess)
+        return fail(XR_ERR_NOMEM, "xr_batch_load_guides: hipMalloc failed (the guides loaded before stay in force)");
+    XR_HIP(hipMemcpyAsync(new_csr.p, csr.data(), csr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!box.empty()) XR_HIP(hipMemcpyAsync(new_box.p, box.data(), box.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XR_HIP(hipStreamSynchronize(st));   // host staging vectors die here; work enqueued earlier that reads the old tables has finished too
+    std::swap(b->guide_csr.p, new_csr.p); std::swap(b->guide_csr.n, new_csr.n);       // (the old tables are freed when new_* go out of scope)
+    std::swap(b->guide_box.p, new_box.p); std::swap(b->guide_box.n, new_box.n);
     b->dev.guide_csr = b->guide_csr.p; b->dev.guide_box = b->guide_box.p;
     return build_guide_masks(b, st);
 }

@@ -1827,10 +1827,10 @@ __global__ void __launch_bounds__(256) xr_netplanes_pairs_kernel(XrBatchDev b, c
 // global loads for the boxes and a pass over the nodes with up to 8 box tests each (~13 % of a route on the design-derived pack).  One
 // workgroup per (region, net), once per guide load: bit j of byte c = node 8 c + j is OUTSIDE the guide.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) xr_guide_mask_kernel(XrBatchDev b, uint8_t* __restrict__ masks) {
+__global__ void __launch_bounds__(256) xr_guide_mask_kernel(XrBatchDev b, uint8_t* __restrict__ masks, int region_base) {
     __shared__ int s_bb[4], s_ngb;
     __shared__ int4 s_gbx[XR_GUIDE_MAX_BOXES];
-    const int r = blockIdx.y, a = blockIdx.x + 1, tid = threadIdx.x;
+    const int r = region_base + blockIdx.y, a = blockIdx.x + 1, tid = threadIdx.x;
     const XrRegionDev R = b.regions[r];
     if (a > R.n_nets) return;
     const int Y = R.Y, Z = R.Z, YZ = Y * Z, N = R.N;
@@ -2184,8 +2184,13 @@ hipError_t xr_launch_netplanes_pairs(const XrBatchDev* b, const int32_t* pair_re
 
 hipError_t xr_launch_guide_masks(const XrBatchDev* b, uint8_t* masks, int k_max, hipStream_t st) {
     if (b->n_regions <= 0 || k_max <= 0) return hipSuccess;
-    hipLaunchKernelGGL(xr_guide_mask_kernel, dim3(k_max, b->n_regions), dim3(256), 0, st, *b, masks);
-    return hipGetLastError();
+    // (gridDim.y holds at most 65535 workgroups: the regions go in chunks)
+    for (int r0 = 0; r0 < b->n_regions; r0 += 32768) {
+        hipLaunchKernelGGL(xr_guide_mask_kernel, dim3(k_max, (b->n_regions - r0) < 32768 ? (b->n_regions - r0) : 32768), dim3(256), 0, st, *b, masks, r0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t xr_launch_pack_state(const XrBatchDev* b, uint8_t* rows, int64_t row_bytes, int region_base, hipStream_t st) {

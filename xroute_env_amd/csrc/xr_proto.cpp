@@ -23,6 +23,7 @@ struct Reader {
     const uint8_t* end;
     bool ok = true;
     bool more() const { return ok && p < end; }
+    // at most 10 bytes, the 10th without a continuation bit (the protobuf runtimes refuse an 11th: "Too many bytes when decoding varint")
     uint64_t varint() {
         uint64_t v = 0;
         int shift = 0;
@@ -35,6 +36,14 @@ struct Reader {
         ok = false;
         return 0;
     }
+    // a field key: field number 0 and wire types 6 / 7 are illegal on the wire
+    bool key(uint64_t& field, uint32_t& wt) {
+        const uint64_t tag = varint();
+        field = tag >> 3;
+        wt = (uint32_t)(tag & 7);
+        if (!ok || (tag >> 3) == 0 || wt > 5) ok = false;
+        return ok;
+    }
     Reader sub() {
         const uint64_t n = varint();
         if (!ok || n > (uint64_t)(end - p)) { ok = false; return Reader{p, p}; }
@@ -42,13 +51,27 @@ struct Reader {
         p += n;
         return r;
     }
-    void skip(uint32_t wt) {
+    // an unknown field, or a known field number under a wire type its declaration does not have (the runtimes keep those as unknown fields too).
+    // Groups (wire types 3 / 4, proto2's) are still legal to skip: everything up to the END_GROUP key of the same field number, nested ones inside.
+    void skip(uint64_t field, uint32_t wt, int depth = 0) {
         switch (wt) {
         case 0: (void)varint(); break;
         case 1: if (end - p < 8) ok = false; else p += 8; break;
         case 2: (void)sub(); break;
         case 5: if (end - p < 4) ok = false; else p += 4; break;
-        default: ok = false;
+        case 3: {
+            if (depth >= 64) { ok = false; break; }
+            for (;;) {
+                if (p >= end) { ok = false; break; }           // "Missing group end tag"
+                uint64_t f2; uint32_t w2;
+                if (!key(f2, w2)) break;
+                if (w2 == 4) { if (f2 != field) ok = false; break; }
+                skip(f2, w2, depth + 1);
+                if (!ok) break;
+            }
+            break;
+        }
+        default: ok = false;                                    // a stray END_GROUP
         }
     }
 };
@@ -90,54 +113,56 @@ void write_node_body(Writer& w, const int32_t* f) {
     w.field_varint(10, zig(f[9]));
 }
 
-thread_local std::string g_perr;
-
 }  // namespace
 
 extern "C" {
 
-int32_t xr_proto_decode(const uint8_t* buf, size_t len, int64_t* info, uint32_t* metrics, int32_t* fields,
-                        uint32_t* nets) {
-    if ((!buf && len) || !info) return XR_ERR_INVALID;
+int32_t xr_proto_decode(const uint8_t* buf, size_t len, int64_t* info, uint32_t* metrics, int32_t* fields, int64_t fields_cap,
+                        uint32_t* nets, int64_t nets_cap) {
+    if ((!buf && len) || !info || (fields && fields_cap < 0) || (nets && nets_cap < 0)) return XR_ERR_INVALID;
     for (int i = 0; i < 8; i++) info[i] = 0;
+    uint32_t met[3] = {0, 0, 0};
     if (metrics) metrics[0] = metrics[1] = metrics[2] = 0;
+    if (!fields) fields_cap = 0;
+    if (!nets) nets_cap = 0;
     Reader m{buf, buf + len};
-    // a oneof keeps the LAST member seen; a repeated occurrence of the same message field merges
+    // The runtimes' parse rules this follows (google.protobuf message.ParseFromString, which the reference calls at
+    // baseline/baseline_utils.py:418,467): a oneof keeps the LAST member seen and drops what the other member held; a repeated occurrence
+    // of the SAME message field merges (scalars: last value wins, repeated fields: appended).  A row is stored only while it fits the
+    // caller's capacity, so that a member that is dropped later (and may be longer than what finally remains) never writes past the buffers;
+    // what remains at the end always fits a buffer sized by pass 1, because it is exactly what pass 1 counted.
     int64_t n_nodes = 0, n_nets = 0;
     while (m.more()) {
-        const uint64_t tag = m.varint();
-        if (!m.ok) return XR_ERR_PARSE;
-        const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+        uint64_t field; uint32_t wt;
+        if (!m.key(field, wt)) return XR_ERR_PARSE;
         if (field == 1 && wt == 2) {
-            if (info[0] != 1) { n_nodes = 0; n_nets = 0; info[1] = info[2] = info[3] = 0; info[6] = 0;
-                                if (metrics) metrics[0] = metrics[1] = metrics[2] = 0; }
+            if (info[0] != 1) { n_nodes = 0; n_nets = 0; info[1] = info[2] = info[3] = 0; info[6] = 0; info[7] = 0;
+                                met[0] = met[1] = met[2] = 0; }
             info[0] = 1;
             Reader r = m.sub();
             if (!m.ok) return XR_ERR_PARSE;
             while (r.more()) {
-                const uint64_t t2 = r.varint();
-                if (!r.ok) return XR_ERR_PARSE;
-                const uint32_t f2 = (uint32_t)(t2 >> 3), w2 = (uint32_t)(t2 & 7);
+                uint64_t f2; uint32_t w2;
+                if (!r.key(f2, w2)) return XR_ERR_PARSE;
                 if (w2 == 0 && (f2 >= 1 && f2 <= 3)) info[f2] = (int64_t)(uint32_t)r.varint();
-                else if (w2 == 0 && (f2 >= 5 && f2 <= 7)) { const uint32_t v = (uint32_t)r.varint(); if (metrics) metrics[f2 - 5] = v; }
+                else if (w2 == 0 && (f2 >= 5 && f2 <= 7)) met[f2 - 5] = (uint32_t)r.varint();
                 else if (w2 == 0 && f2 == 8) info[6] = r.varint() ? 1 : 0;
                 else if (f2 == 4 && w2 == 2) {
                     Reader nd = r.sub();
                     if (!r.ok) return XR_ERR_PARSE;
                     int32_t f[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                     while (nd.more()) {
-                        const uint64_t t3 = nd.varint();
-                        if (!nd.ok) return XR_ERR_PARSE;
-                        const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+                        uint64_t f3; uint32_t w3;
+                        if (!nd.key(f3, w3)) return XR_ERR_PARSE;
                         if (w3 == 0 && f3 >= 1 && f3 <= 10) {
                             const uint64_t v = nd.varint();
                             if (f3 <= 6 || f3 >= 9) f[f3 - 1] = unzig(v);
                             else if (f3 == 7) f[6] = (int32_t)(uint32_t)v;
                             else f[7] = v ? 1 : 0;
-                        } else nd.skip(w3);
+                        } else nd.skip(f3, w3);
                         if (!nd.ok) return XR_ERR_PARSE;
                     }
-                    if (fields) memcpy(fields + n_nodes * 10, f, sizeof(f));
+                    if (n_nodes < fields_cap) memcpy(fields + n_nodes * 10, f, sizeof(f));
                     n_nodes++;
                 } else if (f2 == 9 && w2 == 2) {          // packed
                     Reader pk = r.sub();
@@ -145,36 +170,39 @@ int32_t xr_proto_decode(const uint8_t* buf, size_t len, int64_t* info, uint32_t*
                     while (pk.more()) {
                         const uint32_t v = (uint32_t)pk.varint();
                         if (!pk.ok) return XR_ERR_PARSE;
-                        if (nets) nets[n_nets] = v;
+                        if (n_nets < nets_cap) nets[n_nets] = v;
                         n_nets++;
                     }
                 } else if (f2 == 9 && w2 == 0) {          // unpacked form is also legal
                     const uint32_t v = (uint32_t)r.varint();
-                    if (nets) nets[n_nets] = v;
+                    if (n_nets < nets_cap) nets[n_nets] = v;
                     n_nets++;
-                } else r.skip(w2);
+                } else r.skip(f2, w2);
                 if (!r.ok) return XR_ERR_PARSE;
             }
         } else if (field == 2 && wt == 2) {
-            if (info[0] != 2) info[7] = 0;
+            if (info[0] != 2) { n_nodes = 0; n_nets = 0; info[1] = info[2] = info[3] = 0; info[6] = 0; info[7] = 0;
+                                met[0] = met[1] = met[2] = 0; }
             info[0] = 2;
             Reader r = m.sub();
             if (!m.ok) return XR_ERR_PARSE;
             while (r.more()) {
-                const uint64_t t2 = r.varint();
-                if (!r.ok) return XR_ERR_PARSE;
-                const uint32_t f2 = (uint32_t)(t2 >> 3), w2 = (uint32_t)(t2 & 7);
+                uint64_t f2; uint32_t w2;
+                if (!r.key(f2, w2)) return XR_ERR_PARSE;
                 if (f2 == 1 && w2 == 0) info[7] = unzig(r.varint());
-                else r.skip(w2);
+                else r.skip(f2, w2);
                 if (!r.ok) return XR_ERR_PARSE;
             }
         } else {
-            m.skip(wt);
+            m.skip(field, wt);
         }
         if (!m.ok) return XR_ERR_PARSE;
     }
     info[4] = n_nodes;
     info[5] = n_nets;
+    if (metrics) { metrics[0] = met[0]; metrics[1] = met[1]; metrics[2] = met[2]; }
+    // pass 2 with buffers smaller than what the message holds: nothing was written past them, the counts say what is needed
+    if ((fields && n_nodes > fields_cap) || (nets && n_nets > nets_cap)) return XR_ERR_RANGE;
     return XR_OK;
 }
 

@@ -18,6 +18,7 @@ is how the world_size-2 tests exercise it without GPUs.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -27,6 +28,16 @@ RECORD_BYTES = 48
 # int32 column view of a record row ([B, 48] uint8 -> [B, 12] int32; reward = float64 view column 0)
 REC_DELTA, REC_CUM, REC_NLEGAL, REC_ENV_STEPS, REC_PATH_LEN, REC_FLAGS = slice(2, 5), slice(5, 8), 8, 9, 10, 11
 RECORD_FIELDS = ("reward", "delta", "cum", "nlegal", "env_steps", "path_len", "done", "status")
+
+
+def collectives_on(group=None) -> bool:
+    """True when the collective code paths run: a process group exists and holds more than one rank — or exactly one with
+    XR_FORCE_COLLECTIVES=1, the switch that makes a ONE-rank job take every N > 1 branch (init with a device id, the async all_gather
+    pairs, verify_gather, broadcast, all_reduce, the learner's gather) on the real backend.  With one GPU that is the only way to execute
+    the RCCL code path before an 8-GPU node does (tests/test_gpu_bench_contract.py: the forced-nccl lines)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("XR_FORCE_COLLECTIVES") == "1"
 
 
 def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -77,7 +88,7 @@ def pack_records(reward, delta, done, nlegal, cum=None, env_steps=None, path_len
 def gather_rows(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """All-gather per-env rows of every rank, in rank (= env id) order.  Equal shard sizes use one
     all_gather_into_tensor; ragged shards fall back to all_gather on padded blocks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return local if out is None else out.copy_(local)
     world = dist.get_world_size(group)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -122,7 +133,7 @@ def verify_gather(local: torch.Tensor, gathered: torch.Tensor, lo: int, group=No
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = local.device
     mine = torch.cat([torch.tensor([rank, lo, local.shape[0]], dtype=torch.int64, device=dev), rows_checksum(local)])
-    if world == 1:
+    if not collectives_on(group):
         ok = bool(torch.equal(local, gathered[lo:lo + local.shape[0]]))
         return {"ranks_seen": 1, "gather_verified": ok, "rows": int(local.shape[0])}
     table = torch.empty((world, 4), dtype=torch.int64, device=dev)
@@ -182,6 +193,7 @@ class ShardedVectorEnv:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.multi = collectives_on(group)
         self.lo, self.hi = shard_range(n_total, self.world, self.rank)
         regions = [generate_region(env_seed(config, e), **CONFIGS[config]) for e in range(self.lo, self.hi)]
         if env_factory is None:
@@ -202,7 +214,7 @@ class ShardedVectorEnv:
         return self.env.reset()
 
     def _gather(self, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.world == 1:
+        if not self.multi:
             return rows
         if self.equal and out is not None:
             return gather_records_fixed(rows, out, self.group)
@@ -236,13 +248,13 @@ class ShardedVectorEnv:
 
     def _exchange(self, info: dict, policy: Callable) -> torch.Tensor:
         rec_all = self._gather(info["record"], self._all)
-        if self.equal and self.world > 1 and (self._legal_all is None or self._legal_all.shape[1] != info["legal"].shape[1]):
+        if self.equal and self.multi and (self._legal_all is None or self._legal_all.shape[1] != info["legal"].shape[1]):
             self._legal_all = torch.empty((self.n_total, info["legal"].shape[1]), dtype=info["legal"].dtype, device=self.device)
         legal_all = self._gather(info["legal"], self._legal_all)
         self._records_all = rec_all
         if self.rank == 0:
             self._actions_all.copy_(policy(unpack_records(rec_all), legal_all).to(torch.int32))
-        if self.world > 1:
+        if self.multi:
             dist.broadcast(self._actions_all, src=0, group=self.group)      # actions travel the other way
         return self._actions_all[self.lo:self.hi].contiguous()
 
@@ -250,41 +262,72 @@ class ShardedVectorEnv:
 class CompactStateExchange:
     """The compact-state gather of a CENTRAL learner (BASELINE config 4's `--learner` placement): every rank packs what planes 0..1
     of its envs' observations are functions of (`RegionBatch.pack_state`: region, nets left, legal bitmask, one occupancy bit per node), ONE
-    all_gather carries the rows, the learner expands them to the fp32 head rows its policy reads (`RegionBatch.expand_state`, byte-identical to
-    what `step_compact` writes).  fp32 planes are never gathered.
+    collective carries the rows TO THE LEARNER, which expands them to the fp32 head rows its policy reads (`RegionBatch.expand_state`,
+    byte-identical to what `step_compact` writes).  fp32 planes are never gathered.
+
+    The collective is a `gather` to the learner rank (round 6; it was an all_gather): only the learner reads the rows, so every other rank
+    sends its n_local x row_bytes once over its own xGMI link to the learner and receives nothing — 1/N of what an all_gather moves per
+    link and (N - 1)/N less in total (`bytes_per_link`, `bytes_per_step`).  north_star keeps RCCL "only for the batched-env gather": the
+    all_gather that remains in the design is the one of the 48-byte records.
 
     batch          the rank's RegionBatch (its shard)
     n_total        env slots over all ranks; `lo` = global id of this rank's first env (contiguous shards, `shard_range`)
     region_base    what turns the shard's local region index into an index of the learner's region table (0 when every rank loaded the same regions)
     learner_batch  on the learner rank: a RegionBatch whose region table holds every region of the job (default: `batch`)"""
 
-    def __init__(self, batch, n_total: int, lo: int, region_base: int = 0, learner_batch=None, group=None):
+    def __init__(self, batch, n_total: int, lo: int, region_base: int = 0, learner_batch=None, group=None, learner_rank: int = 0):
         self.batch, self.learner = batch, (learner_batch if learner_batch is not None else batch)
         self.n_total, self.lo, self.region_base, self.group = int(n_total), int(lo), int(region_base), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.multi = collectives_on(group)
+        self.learner_rank = int(learner_rank)
         rb = max(batch.state_row_bytes(), self.learner.state_row_bytes())
-        if self.world > 1:                       # one row size for everybody (ranks may hold regions with different net counts)
+        if self.multi:                           # one row size for everybody (ranks may hold regions with different net counts)
             t = torch.tensor([rb], dtype=torch.int64, device=batch.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             rb = int(t.item())
         self.row_bytes = rb
         self.rows_local = torch.empty((batch.n_envs, rb), dtype=torch.uint8, device=batch.device)
-        self.equal = self.world > 1 and self.n_total == self.world * batch.n_envs
-        self.rows_all = torch.empty((self.n_total, rb), dtype=torch.uint8, device=batch.device) if self.equal else None
+        self.equal = self.multi and self.n_total == self.world * batch.n_envs
+        on_learner = self.rank == self.learner_rank
+        self.rows_all = torch.empty((self.n_total, rb), dtype=torch.uint8, device=batch.device) if self.equal and on_learner else None
+        self._sizes = None                       # ragged shards: rows of every rank (exchanged once)
 
     @property
     def bytes_per_step(self) -> int:
+        """rows the learner holds after the gather, in bytes (its own shard included: that part never leaves its GPU)"""
         return self.n_total * self.row_bytes
 
-    def gather(self) -> torch.Tensor:
-        """pack this rank's envs and all-gather the rows: uint8 [n_total, row_bytes] in global env order (on every rank)"""
+    @property
+    def bytes_per_link(self) -> int:
+        """bytes one non-learner rank puts on its link to the learner per step (the all_gather it replaces: (N - 1) / N x n_total x row_bytes per ring link)"""
+        return self.batch.n_envs * self.row_bytes
+
+    def gather(self, to_all: bool = False) -> Optional[torch.Tensor]:
+        """pack this rank's envs and send the rows to the learner: uint8 [n_total, row_bytes] in global env order on the learner rank, None on the
+        others.  `to_all=True`: the round-5 form (an all_gather, every rank gets the rows)."""
         self.batch.pack_state(self.rows_local, region_base=self.region_base)
-        if self.world == 1:
+        if not self.multi:
             return self.rows_local
+        if to_all:
+            return gather_rows(self.rows_local, group=self.group)
+        on_learner = self.rank == self.learner_rank
         if self.equal:
-            dist.all_gather_into_tensor(self.rows_all, self.rows_local, group=self.group)
-            return self.rows_all
-        return gather_rows(self.rows_local, group=self.group)
+            # (chunks of a contiguous [n_total, rb] tensor are contiguous views: the learner receives straight into global env order)
+            dist.gather(self.rows_local, gather_list=list(self.rows_all.chunk(self.world)) if on_learner else None, dst=self.learner_rank, group=self.group)
+            return self.rows_all if on_learner else None
+        if self._sizes is None:                  # ragged shards: sizes once, then padded blocks
+            n = torch.tensor([self.rows_local.shape[0]], dtype=torch.int64, device=self.rows_local.device)
+            sizes = [torch.zeros_like(n) for _ in range(self.world)]
+            dist.all_gather(sizes, n, group=self.group)
+            self._sizes = [int(v.item()) for v in sizes]
+        m = max(self._sizes)
+        pad = torch.zeros((m, self.row_bytes), dtype=torch.uint8, device=self.rows_local.device)
+        pad[: self.rows_local.shape[0]] = self.rows_local
+        blocks = [torch.empty_like(pad) for _ in range(self.world)] if on_learner else None
+        dist.gather(pad, gather_list=blocks, dst=self.learner_rank, group=self.group)
+        return torch.cat([blk[:n_] for blk, n_ in zip(blocks, self._sizes)], dim=0) if on_learner else None
 
     def expand(self, rows: torch.Tensor, head_out=None, nlegal_out=None, region_out=None):
         """learner rank: rows -> (head fp32 [n, 2 * n_max], nlegal int32 [n], region int32 [n]); rows that do not parse are flagged -1"""

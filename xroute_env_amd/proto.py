@@ -40,14 +40,14 @@ def decode_message(raw: bytes) -> DecodedMessage:
     buf = (C.c_uint8 * max(len(raw), 1)).from_buffer_copy(raw if len(raw) else b"\0")
     info = (C.c_int64 * 8)()
     metrics = (C.c_uint32 * 3)()
-    rc = L.xr_proto_decode(buf, len(raw), info, metrics, None, None)
+    rc = L.xr_proto_decode(buf, len(raw), info, metrics, None, 0, None, 0)
     if rc != 0:
         raise _lib.XRouteError(rc, "malformed protobuf message")
     n_nodes, n_nets = int(info[4]), int(info[5])
     fields = np.zeros((n_nodes, 10), np.int32)
     nets = np.zeros(n_nets, np.uint32)
     if n_nodes or n_nets:
-        rc = L.xr_proto_decode(buf, len(raw), info, metrics, fields.ctypes.data, nets.ctypes.data)
+        rc = L.xr_proto_decode(buf, len(raw), info, metrics, fields.ctypes.data, n_nodes, nets.ctypes.data, n_nets)
         if rc != 0:
             raise _lib.XRouteError(rc, "malformed protobuf message")
     return DecodedMessage(kind=int(info[0]), dims=(int(info[1]), int(info[2]), int(info[3])), fields=fields,
@@ -93,7 +93,7 @@ def region_wire_fields(region, nodes: Optional[np.ndarray] = None) -> np.ndarray
 
 def request_to_data(msg: DecodedMessage) -> list:
     """The `data` list of handle_messange (baseline_utils.py:15-40), 1-based nets and pins."""
-    f = msg.fields
+    f = msg.fields.astype(np.int64)      # the reference adds 1 to Python ints: net 2^31 - 1 becomes 2^31, not a wrapped int32
     ntype = f[:, 6]
     node_type = np.where(ntype == ACCESS, f[:, 8] + 1, np.where(ntype == BLOCKAGE, -1, 0))
     node_pin = np.where(ntype == ACCESS, f[:, 9] + 1, -1)
