@@ -668,6 +668,10 @@ def main():
         # leg runs beside nothing but itself, like the stand-alone commands the profiles were taken with (bench.py --region-pack ...)
         obs = None
         torch.cuda.empty_cache()
+        try:
+            kernels.append(config2_leg(args, dev))
+        except Exception as ex:
+            kernels.append({"kernel": "xr_ingest_state_kernel + xr_obs_kernel (BASELINE config 2)", "error": str(ex)})
         if c5_regions:
             try:
                 kernels.append(config5_leg(args, c5_regions, dev))
@@ -794,6 +798,10 @@ def main():
             except Exception as ex:          # the oracle is optional for the GPU number itself
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}
+        if parity is not None:       # mirrored into keys the driver's parser keeps
+            out["config"]["parity_ok"] = bool(parity.get("ok"))
+            out["roofline"]["parity_ok"] = bool(parity.get("ok"))
+        out["legs"] = legs_summary(out)         # LAST: the tail of the line holds every leg
         failed = multi and not (certify["gather_verified"] and certify["ranks_seen"] == args.gpus and parity.get("all_ranks_ok"))
         if failed:          # an N-GPU label is only printed for a run that proved it was one
             out["n_gpus"] = None
@@ -813,6 +821,202 @@ def bench_args_key(args, world):
             "config": args.config, "regions": args.regions, "seed": args.seed, "router": args.router, "obs_mode": args.obs_mode,
             "no_stagger": bool(args.no_stagger), "region_pack": os.path.basename(args.region_pack) if args.region_pack else None,
             "maze_v2": bool(args.maze_v2)}
+
+
+def config1_wire_leg(seconds=4.0):
+    """BASELINE config 1 as SURVEY §8d states it — "B = 1, 24x40x9, K = 10: CPU oracle only, single thread (+ proto encode/decode loopback)" — the
+    reference's own plumbing (examples/launch_training.py:57-86 starts ONE simulator; every step is a ZMQ round trip of the whole region,
+    baseline/baseline_utils.py:409-423) restated on the host cores of this box, one thread, no GPU anywhere:
+
+        simulator side   oracle/xr_oracle.c routes the chosen net (`OracleEnv.step`), the new state is serialised as the ~200 KB
+                         `Message{request}` (serve.SimState.encode -> xr_proto_encode_request)
+        agent side       xr_proto_decode (C ABI), `handle_messange`'s `data` lists (proto.request_to_data), the fp32 grid by the oracle's
+                         build_3Dgrid restatement, the `Message{response}` going back (xr_proto_encode_response -> xr_proto_decode)
+
+    Sockets are not timed (loopback in one process): this is a LOWER bound of the reference path's per-step cost on these cores, with compiled
+    stand-ins for its Python.  Per-component milliseconds; the in-process GPU `Game.step` of the same region stands beside it in `extras`."""
+    import numpy as np
+    from oracle import xr_oracle as orc
+    from xroute_env_amd import proto
+    from xroute_env_amd.regions import config_regions, pack_records, unpack_records
+    from xroute_env_amd.serve import SimState
+    regs = config_regions(1, 8)
+    proto.decode_message(proto.encode_response(0))          # (library load outside the timed loop)
+    comp = {k: 0.0 for k in ("sim_route", "encode_request", "decode_request", "data_lists", "build_3Dgrid", "response_round_trip")}
+    n_steps = n_bytes = 0
+    t_end = time.perf_counter() + seconds
+    ep = 0
+    while time.perf_counter() < t_end or n_steps == 0:
+        reg = regs[ep % len(regs)]
+        ep += 1
+        env = orc.OracleEnv(reg)
+        ntype, _, net, pin = unpack_records(reg.nodes)
+        while env.nlegal() > 0:
+            a = int(env.legal()[0])
+            t0 = time.perf_counter()
+            raw_resp = proto.encode_response(a - 1)                     # the agent's answer (baseline_utils.py:409-411) ...
+            a_sim = proto.decode_message(raw_resp).net_index + 1        # ... parsed by the simulator
+            t1 = time.perf_counter()
+            env.step(a_sim)
+            t2 = time.perf_counter()
+            owner = env.owner()[: reg.n_nodes]
+            legal = env.legal()
+            st = SimState(tuple(reg.dims), proto.region_wire_fields(reg, pack_records(ntype, (owner != 0).astype(np.int64), net, pin)),
+                          tuple(int(v) for v in env.cum()), np.asarray(legal, np.uint32) - 1, len(legal) == 0)
+            raw = st.encode()
+            t3 = time.perf_counter()
+            msg = proto.decode_message(raw)
+            t4 = time.perf_counter()
+            data = proto.request_to_data(msg)
+            t5 = time.perf_counter()
+            obs = env.observation()
+            t6 = time.perf_counter()
+            comp["response_round_trip"] += t1 - t0; comp["sim_route"] += t2 - t1; comp["encode_request"] += t3 - t2
+            comp["decode_request"] += t4 - t3; comp["data_lists"] += t5 - t4; comp["build_3Dgrid"] += t6 - t5
+            n_steps += 1
+            n_bytes += len(raw)
+            assert len(data[1]) == reg.n_nodes and obs.size == (2 + 7 * len(legal)) * reg.n_nodes
+    per = {k: round(v / n_steps * 1e3, 4) for k, v in comp.items()}
+    total = sum(comp.values()) / n_steps
+    return {"ms_per_step": round(total * 1e3, 4), "value": round(1.0 / total, 2), "unit": "env-steps/s", "cores": 1, "steps": n_steps,
+            "request_bytes_mean": int(n_bytes / n_steps), "ms_per_component": per,
+            "what": "BASELINE config 1 (SURVEY 8d): one ispd18_test1-sized region (24x40x9, K = 10), ONE thread of this box's host: oracle route + the real ~200 KB "
+                    "Request encoded and decoded through the C-ABI codec + handle_messange's data lists + the oracle's build_3Dgrid + the Response, loopback "
+                    "(no sockets): a lower bound of the reference's per-step path with compiled stand-ins for its Python (the reference's own build_3Dgrid alone: "
+                    "21 ms per call, BASELINE.md)"}
+
+
+def config2_leg(args, dev):
+    """BASELINE config 2: "256 parallel regions on 1 x MI355X, random net-order policy, grid-build + reward only" — the env driven by an EXTERNAL
+    simulator's states: per step every env ingests a new state (xr_batch_ingest_state: occupancy of every node, nets left, cumulative metrics ->
+    metric deltas, f64 reward, done, the 48-byte record) and builds the reference-layout fp32 observation of it (xr_batch_observation); NO route in
+    the timed region.  The states are produced beforehand by a twin batch that routes (random net-order policy, untimed), so the whole thing is
+    checked like every other leg: the oracle replays the twin's actions and rebuilds the observations the timed launches wrote."""
+    import numpy as np
+    import torch
+    from xroute_env_amd.batch import RegionBatch
+    B, S, n_t = 256, 6, max(args.steps, 10)
+    regs = gen_regions_inline(2, B)
+    twin = RegionBatch(regs, n_envs=B, device=dev, auto_reset=False)
+    main = RegionBatch(regs, n_envs=B, device=dev, auto_reset=False)
+    twin.reset(); main.reset()
+    a = torch.empty(B, dtype=torch.int32, device=dev)
+    owners, legals, cums, acts_log = [], [], [], []
+    for i in range(S):                                     # the scripted states: S random-order steps of every env (K0 >= 4 > S - 2: nobody finishes early... see `done`)
+        twin.random_actions(args.seed + 0xC2 + i, a)
+        acts_log.append(a.clone())
+        twin.step(a)
+        owners.append(twin.fetch("owner").clone()); legals.append(twin.fetch("legal").clone()); cums.append(twin.fetch("cum").clone())
+    obs = main.alloc_observation()
+    rec = torch.empty((B, 48), dtype=torch.uint8, device=dev)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_t)]
+    for w in range(2):                                     # warm-up (first touch of the 9 GB buffer)
+        main.ingest_state(owners[w % S], legals[w % S], cums[w % S]); main.observation(obs)
+    main.reset()
+    k_sum = 0.0
+    for i, ev in enumerate(evs):
+        j = i % S
+        if j == 0 and i:
+            main.reset()                                   # (untimed) back to the initial state: the deltas of state 0 are relative to it
+        ev[0].record()
+        main.ingest_state(owners[j], legals[j], cums[j])
+        ev[1].record()
+        main.observation(obs)
+        main.fetch("record", rec)
+        ev[2].record()
+        k_sum += float(main.fetch("nlegal").double().sum().item())
+    torch.cuda.synchronize(dev)
+    ing_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / n_t
+    obs_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / n_t
+    N = float(regs[0].n_nodes)
+    k_mean = k_sum / (n_t * B)
+    # SURVEY 8(d): ingest reads the new occupancy and writes the state (2·N + 2·N), the observation reads the compact state (node_net + owner: 4·N) and
+    # writes 4·N·(2 + 7K)
+    ing_bytes = 4.0 * N * B
+    obs_bytes = (4.0 * N + 4.0 * N * (2.0 + 7.0 * k_mean)) * B
+    # ---- checks: the last timed step ingested state j_last; its records and observation against the twin (same state) and the oracle
+    j_last = (n_t - 1) % S
+    r = main.records()
+    want_delta = (cums[j_last] - (cums[j_last - 1] if j_last else torch.from_numpy(np.array([rg.metrics0 for rg in regs], np.int32)).to(dev))).cpu().numpy()
+    ok_delta = bool(np.array_equal(np.asarray(r["delta"]), want_delta))
+    w_rew = -1.0 * (500.0 * want_delta[:, 0].astype(np.float64) + 4.0 * want_delta[:, 2] + 0.5 * want_delta[:, 1])
+    ok_rew = bool(np.array_equal(np.asarray(r["reward"], np.float64), w_rew))
+    from oracle import xr_oracle as orc
+    n_chk, ok_obs = 16, True
+    al = torch.stack(acts_log).cpu().numpy()
+    for e in range(0, B, B // n_chk):
+        env = orc.OracleEnv(regs[e])
+        for i in range(j_last + 1):
+            if al[i, e]:
+                env.step(int(al[i, e]))
+        ro = env.observation()
+        ok_obs = ok_obs and bool(np.array_equal(ro.ravel(), obs[e, : ro.size].cpu().numpy()))
+    ent = kernel_entry("xr_ingest_state_kernel + xr_obs_kernel (BASELINE config 2: 256 envs, grid-build + reward only)", ing_ms + obs_ms, ing_bytes + obs_bytes,
+                       float(B), "hbm-write",
+                       "256 env slots of ispd18_test1-sized regions (24x40x9, K~U[4,36]); per step every env ingests a new externally produced state "
+                       "(xr_batch_ingest_state: owner row copy, nets-left mask, metric deltas, f64 reward, done, record) and writes its reference-layout fp32 "
+                       "observation (xr_batch_observation) — no route; bytes = 4·N ingest + 4·N state read + 4·N·(2+7K) observation per env. 256 envs are "
+                       "one wave of workgroups on a quarter of the chip's CUs x 4: the launch is too short to reach the 4096-env write rate")
+    ent.update(envs=B, ingest_ms=round(ing_ms, 4), observation_ms=round(obs_ms, 4), mean_nets_left=round(k_mean, 2),
+               ingest_frac=round(ing_bytes / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), observation_frac=round(obs_bytes / (obs_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+               parity={"deltas_equal": ok_delta, "rewards_bit_equal": ok_rew, "observations_equal": ok_obs, "observations_checked": n_chk,
+                       "ok": bool(ok_delta and ok_rew and ok_obs),
+                       "what": "records of the last timed ingest vs the twin batch's cumulative metrics (deltas) and the reference's reward expression in f64; "
+                               "observation bytes of 16 envs vs the oracle replaying the twin's actions"})
+    twin.close(); main.close()
+    return ent
+
+
+def gen_regions_inline(config, n):
+    from xroute_env_amd.regions import config_regions
+    return config_regions(config, n)
+
+
+def legs_summary(out):
+    """Every leg of the line in <= 1.5 KB, LAST in the JSON (the driver keeps the tail of the line): ms per launch, fraction of the HBM peak (or
+    M env-steps/s where bandwidth is not the bound), and the leg's own oracle check."""
+    short = [("xr_step_queue_kernel (in-place", "step_inplace"), ("BASELINE config 5", "c5_route_1024"), ("BASELINE config 2", "c2_obs_reward_256"),
+             ("region pack, XR-Maze v2", "pack_v2_step"), ("XR-Maze v2 + the design's guide", "pack_v2_route"), ("design-derived ispd18_test1 region pack)", "pack_step"),
+             ("XR-Maze v2", "v2_route"), ("xr_step_queue_kernel", "step"), ("xr_route_kernel", "route_only"), ("xr_obs_kernel", "obs")]
+    legs = {}
+    for k in out.get("kernels", []):
+        name = next((s_ for pat, s_ in short if pat in k.get("kernel", "")), k.get("kernel", "?")[:24])
+        while name in legs:
+            name += "'"
+        if "error" in k:
+            legs[name] = {"error": str(k["error"])[:60]}
+            continue
+        e = {"ms": round(k["ms"], 4), "frac": round(k["frac"], 4), "Meps": round(k["env_steps_per_s"] / 1e6, 3)}
+        if isinstance(k.get("parity"), dict):
+            e["ok"] = bool(k["parity"].get("ok"))
+        if "launch_utilisation" in k:
+            e["util"] = k["launch_utilisation"]["utilisation"]
+        if "at_4x_slots" in k:
+            e["ms_4096"] = k["at_4x_slots"]["ms"]
+        legs[name] = e
+    if "step" in legs and isinstance(out.get("parity"), dict):
+        legs["step"]["ok"] = bool(out["parity"].get("ok"))
+    ex = out.get("extras") or {}
+    g = ex.get("config1_game_step") or {}
+    if "ms_median" in g:
+        legs["c1_game_step"] = {"ms": g["ms_median"]}
+    w = ex.get("config1_wire_loopback") or {}
+    if "ms_per_step" in w:
+        legs["c1_wire_loopback_cpu"] = {"ms": w["ms_per_step"], "eps": w["value"]}
+    d3 = ex.get("config3_dqn_attached") or {}
+    if "value" in d3:
+        legs["c3_dqn_1024"] = {"ms": d3["ms_per_step"], "Meps": round(d3["value"] / 1e6, 3), "env_share": d3.get("env_share_of_step_time")}
+    c4 = ex.get("config4_ppo_attached_per_gpu_share") or {}
+    for key, nm in (("policy_per_rank", "c4_ppo_512_rank"), ("central_learner_from_compact_state", "c4_ppo_512_learner")):
+        if isinstance(c4.get(key), dict) and "value" in c4[key]:
+            legs[nm] = {"ms": c4[key]["ms_per_step"], "Meps": round(c4[key]["value"] / 1e6, 3), "ok": bool(c4[key].get("parity_ok"))}
+    tr = ex.get("ppo_training_cadence") or {}
+    if "refill_ms" in tr:
+        legs["ppo_cadence_100"] = {"refill_ms": tr["refill_ms"], "window_ms": tr.get("window_ms"), "refill_share": tr.get("refill_share_of_window")}
+    su = ex.get("sustained") or {}
+    if "ms_per_step" in su:
+        legs["sustained_500"] = {"ms": su["ms_per_step"]}
+    return legs
 
 
 def extras_leg(args, regions, dev, batch, obs):
@@ -846,6 +1050,10 @@ def extras_leg(args, regions, dev, batch, obs):
         del g
     except Exception as exn:
         ex["config1_game_step"] = {"error": str(exn)}
+    try:
+        ex["config1_wire_loopback"] = config1_wire_leg(min(4.0, max(1.0, args.cpu_seconds / 3)))
+    except Exception as exn:
+        ex["config1_wire_loopback"] = {"error": str(exn)}
     try:
         a2 = copy.copy(args)
         a2.agent, a2.agent_full_obs, a2.steps, a2.warmup = "dqn", False, 20, 3
@@ -982,7 +1190,7 @@ def agent_leg(args, regions, dev, world):
             "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
             "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack ({len(grouped.shapes)} grid shapes, fused tower for "
-                                    f"{sum(t is not None for t in grouped.towers)} of them; XR-Maze {'v2 (the reference configuration)' if args.maze_v2 else 'v1'}), full maze route per step, "
+                                    f"{sum(t is not None for t in grouped.towers)} of them; XR-Maze {'v2 (the reference TCL knob values, this build semantics)' if args.maze_v2 else 'v1'}), full maze route per step, "
                                     if mixed else f"BASELINE config 3/4 shape: {B} ispd18_test1-sized regions, full maze route per step, ")
                                    +
                                    f"{args.agent.upper()} counterpart (random-init weights of the reference architecture, eval mode) choosing every action; "
@@ -1240,7 +1448,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                "scaling": "strong" if strong else "weak", "vs_baseline": None,
                "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
                "config": {"workload": (f"BASELINE config 4 shape: a {Bg}-env batch, {B} per GPU, "
-                                       + (f"over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)} (XR-Maze {'v2: the reference configuration' if v2 else 'v1'}), "
+                                       + (f"over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)} (XR-Maze {'v2: the reference TCL knob values, this build semantics' if v2 else 'v1'}), "
                                           if args.region_pack else "of ispd18_test1-sized regions (24x40x9, K~U[4,36]), ")
                                        + f"full maze route per step, {args.agent.upper()} counterpart (random-init weights of the reference architecture, replicated from one seed, eval mode"
                                        + (", actions sampled with counter-based uniforms of (seed, step, global env, net rank)" if args.agent == "ppo" else "") + ") choosing every action; "
@@ -1417,7 +1625,7 @@ def pack_leg(args, pack, dev, v2=None):
     info = b.observe_info()
     k_after = klog.to(torch.float64)
     nbytes = float((4.0 * n_nodes).sum().item()) + float((4.0 * (2.0 + 7.0 * k_after) * n_nodes[None, :]).sum().item()) / n_t
-    name = ("xr_step_queue_kernel (design-derived ispd18_test1 region pack, XR-Maze v2 + the design's guide rectangles: the reference's configuration)"
+    name = ("xr_step_queue_kernel (design-derived ispd18_test1 region pack, XR-Maze v2 + the design's guide rectangles: the reference's TCL knob VALUES under this build's semantics — rip-up == 4x penalty, DESIGN 3.1)"
             if v2 else "xr_step_queue_kernel (design-derived ispd18_test1 region pack)")
     ent = kernel_entry(name, ms, nbytes, real,
                        "hbm-write (routing phase: lds-latency)",
@@ -1503,6 +1711,17 @@ def config5_leg(args, c5_regions, dev):
     torch.cuda.synchronize(dev)
     ms = sum(a.elapsed_time(bb) for a, bb in evs) / n_t
     real = (b5.total_steps() - s0) / n_t
+    # how busy the chip is inside such a launch: cycles of every env's route (XR_FETCH_PHASES slot 7) of the LAST timed launch — a launch lasts
+    # as long as its longest route, so mean / max is the fraction of the workgroup slots doing anything
+    util = None
+    try:
+        cyc = b5.fetch("phases").reshape(Bc, 8)[:, 7].double()
+        cyc = cyc[cyc > 0]
+        if cyc.numel():
+            util = {"mean_route_cycles": round(float(cyc.mean().item())), "p50_route_cycles": round(float(cyc.median().item())),
+                    "max_route_cycles": round(float(cyc.max().item())), "utilisation": round(float((cyc.mean() / cyc.max()).item()), 4)}
+    except Exception:
+        util = None
     N = float(c5_regions[0].n_nodes)
     # SURVEY §8(d) prices an HBM-resident maze route as FULL sweeps: 4·N state load + 9·N·S + 10·L per env-step.  The frontier
     # router does no sweep at all: it creates the field word of a node when a neighbour first relaxes it and resets exactly
@@ -1511,7 +1730,9 @@ def config5_leg(args, c5_regions, dev):
     formula_8d = (4.0 * N * Bc * n_t + 9.0 * N * sweeps + 10.0 * plen) / n_t
     nbytes = (24.0 * touched + 10.0 * plen) / n_t if touched > 0 else formula_8d
     ent = kernel_entry("xr_route_kernel (BASELINE config 5: 256x256x12)", ms, nbytes, real, "l2-latency",
-                       f"{Bc} env slots over {len(c5_regions)} distinct regions, K = 32, route-only (compact state). Bound by the latency of "
+                       f"{Bc} env slots over {len(c5_regions)} distinct regions, K = 32, route-only (compact state). BASELINE calls this config an "
+                       "'HBM-roofline stress'; as built it is an L2-ATOMIC LATENCY CHAIN: a route is ~10^3 dependent passes over a frontier held in L2, the "
+                       "launch ends with its longest route (`launch_utilisation`), HBM sees 0.6 % of its peak. Bound by the latency of "
                        "dependent L2 atomics, not by bandwidth: bytes = 24 B per node the route touched + 10 B per path node (the frontier "
                        "router's algorithmic bytes); `bytes_8d_full_sweep_formula` = what SURVEY §8(d)'s full-sweep form (4·N + 9·N·S + 10·L, "
                        "S = rounds) would move for the same routes; env_steps_per_s is the figure of merit")
@@ -1533,6 +1754,9 @@ def config5_leg(args, c5_regions, dev):
     if first_ms is not None:
         ent["first_steps_ms"] = round(first_ms, 4)
         ent["note"] += "; stationary nets-left distribution (episodes staggered first, round 5); `first_steps_ms`: the same launches on 1024 FRESH episodes, what rounds 1-4 reported here"
+    if util is not None:
+        ent["launch_utilisation"] = dict(util, what="cycles of every route of the last timed launch; utilisation = mean / max: the launch is as long as its longest "
+                                                    "route, the workgroup slots of the short ones idle (closed in DESIGN.md §9: four rounds of bit-exact A/Bs inside the pass)")
     ent["mean_rounds"] = sweeps / (n_t * Bc)
     ent["mean_path_nodes"] = plen / (n_t * Bc)
     ent["mean_touched_nodes"] = touched / (n_t * Bc)
@@ -1540,6 +1764,34 @@ def config5_leg(args, c5_regions, dev):
     gpu_hash = b5.fetch("hash").cpu().numpy().view("uint64")
     gpu_cum = b5.fetch("cum").cpu().numpy()
     b5.close()
+    try:        # the same kernel on 4x the slots (BASELINE's 1024 per GPU is the chain-bound shape: few routes per CU, the launch = its longest route)
+        if not args.no_stagger and Bc >= 256 and 4 * Bc <= 4096:
+            B4 = 4 * Bc
+            b4 = RegionBatch(c5_regions, n_envs=B4, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult, launch_order=args.launch_order)
+            b4.reset()
+            a4 = torch.empty(B4, dtype=torch.int32, device=dev)
+            off4 = torch.from_numpy(stagger_offsets(b4.fetch("nlegal").cpu().numpy(), 0)).to(dev)
+            z4 = torch.zeros_like(a4)
+            for i in range(int(off4.max().item())):
+                b4.random_actions(args.seed ^ 0xC5C5 ^ i, a4)
+                torch.where(off4 > i, a4, z4, out=a4)
+                b4.step(a4)
+            for i in range(2):
+                b4.random_actions(555 + i, a4); b4.step(a4)
+            ev4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            s4 = b4.total_steps()
+            for i, (e0, e1) in enumerate(ev4):
+                b4.random_actions(600 + i, a4)
+                e0.record(); b4.step(a4); e1.record()
+            torch.cuda.synchronize(dev)
+            ms4 = sum(x.elapsed_time(y) for x, y in ev4) / 3
+            cyc = b4.fetch("phases").reshape(B4, 8)[:, 7].double(); cyc = cyc[cyc > 0]
+            ent["at_4x_slots"] = {"envs": B4, "ms": round(ms4, 4), "env_steps_per_s": round((b4.total_steps() - s4) / 3 / (ms4 * 1e-3), 1),
+                                  "utilisation": round(float((cyc.mean() / cyc.max()).item()), 4) if cyc.numel() else None,
+                                  "what": "the same route kernel on 4096 slots of the same regions (timing only; parity is the 1024-slot leg's): more routes per CU hide the long chains"}
+            b4.close()
+    except Exception as ex4:
+        ent["at_4x_slots"] = {"error": str(ex4)}
     try:        # the same launches with the LDS-window form in front (xr_config.window: off by default — this is the measurement behind that)
         bw = RegionBatch(c5_regions, n_envs=Bc, device=dev, auto_reset=True, router=args.router, dial_mult=args.dial_mult,
                          launch_order=args.launch_order, window=1000)

@@ -186,8 +186,9 @@ typedef struct xr_region_desc {
 #define XR_FETCH_ROUTE_ORDER 18 /* int32[B]     env slots in the order the last longest-first route-only launch handed them out (xr_config.launch_order) */
 #define XR_FETCH_REPLAY   19   /* int32 [B]     replays of the current region so far (region rotation, examples/launch_training.py:28-46) */
 #define XR_FETCH_ENV_STEPS 20  /* int64 [B]     real steps of every env slot since create */
-#define XR_FETCH_PHASES   14   /* int64 [B][8]  debug: route-kernel phase cycle counts (zero unless the library was
-                                                 built with -DXR_PHASE_TIMING) */
+#define XR_FETCH_PHASES   14   /* int64 [B][8]  slot 7: shader-clock cycles of the env's last route (frontier router; what the measured launch order
+                                                 is built from — bench.py's launch utilisation = mean / max over a launch); slots 0..6: route-kernel
+                                                 phase cycle counts, zero unless the library was built with -DXR_PHASE_TIMING (which also owns slot 7) */
 
 /* Per-env result of the last xr_batch_step* / xr_batch_reset: what Game.step returns besides the observation
  * (baseline/baseline_utils.py:426-439) plus what Game.reset records (:472-473), packed for one transfer — also the
@@ -301,6 +302,17 @@ int32_t xr_batch_net_planes(xr_batch* b, const int32_t* pair_region_dev, const i
  *                             fit, nlegal != popcount(legal), a legal bit beyond the region's nets) is left unwritten and flagged
  *                             nlegal = region = -1. */
 int32_t xr_batch_state_row_bytes(const xr_batch* b, int64_t* row_bytes);
+/* The client half of Game.step WITHOUT the route (ABI 9; BASELINE config 2: "grid-build + reward only"): a new state of every env slot, as an
+ * external simulator's `Request` carries it, becomes the batch's state — replaces baseline/baseline_utils.py:420-438 for a batch (`data =
+ * handle_messange(..)`; the metric deltas `*_cur_step - *_last_step`, :426-433; `done = len(netSet) == 0`, :435-436) with the trainers' reward
+ * (baseline/DQN/train_DQN.py:98-99, double) computed in the same kernel.  Follow it with xr_batch_observation for the fp32 grid (build_3Dgrid, :423).
+ *   owner_dev   int16 [n_envs][n_max]        occupancy of every node in flat order: 0 free, the 1-based net id holding it, XR_OWNER_FOREIGN
+ *                                            (16-byte aligned rows: n_max is a multiple of 8)
+ *   legal_dev   uint64 [n_envs][legal_words] bit n-1 = net n is still to route (`Request.nets`, +1); bits beyond the region's nets are dropped
+ *   cum_dev     int32 [n_envs][3]            cumulative violation / wirelength / via (`reward_violation`, `reward_wire_length`, `reward_via`)
+ * Afterwards XR_FETCH_RECORD / _DELTA / _REWARD / _DONE / _NLEGAL describe the step; env_steps advanced by one; the hash chain (routed paths) is
+ * untouched.  Enqueues one kernel, never synchronises. */
+int32_t xr_batch_ingest_state(xr_batch* b, const int16_t* owner_dev, const uint64_t* legal_dev, const int32_t* cum_dev, void* stream);
 int32_t xr_batch_pack_state(xr_batch* b, uint8_t* rows_dev, int64_t row_bytes, int32_t region_base, void* stream);
 int32_t xr_batch_expand_state(xr_batch* b, const uint8_t* rows_dev, int64_t row_bytes, int32_t n_rows, float* head_out_dev, int64_t head_stride,
                               int32_t* nlegal_out_dev, int32_t* region_out_dev, void* stream);

@@ -28,6 +28,7 @@ L.xr_batch_state_row_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
 L.xr_batch_pack_state.argtypes = [vp, vp, C.c_int64, C.c_int32, vp]
 L.xr_batch_expand_state.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp]
 L.xr_batch_route_order.argtypes = [vp, vp, C.c_int32, vp, vp]
+L.xr_batch_ingest_state.argtypes = [vp, vp, vp, vp, vp]
 L.xr_batch_route_occupancy.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
 L.xr_batch_observe_timing.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
 L.xr_observation_from_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
@@ -87,7 +88,7 @@ pre = [L.xr_batch_assign(h, p), L.xr_batch_sizes(h, None, None, None, None, None
        L.xr_batch_net_planes(h, p, p, 1, p, 1 << 20, None), L.xr_batch_random_actions(h, p, 1, None), L.xr_batch_observation(h, p, 1 << 20, 0, 1, None),
        L.xr_batch_fetch(h, 0, p, 1 << 16, None), L.xr_batch_store(h, 0, p, 36, None), L.xr_batch_load_guides(h, None, None, None),
        L.xr_batch_state_row_bytes(h, C.byref(i64)), L.xr_batch_pack_state(h, p, 1 << 10, 0, None), L.xr_batch_expand_state(h, p, 1 << 10, 1, p, 1 << 20, p, p, None),
-       L.xr_batch_route_order(h, p, 100, None, None), L.xr_batch_route_occupancy(h, C.byref(i32), C.byref(i64))]
+       L.xr_batch_route_order(h, p, 100, None, None), L.xr_batch_route_occupancy(h, C.byref(i32), C.byref(i64)), L.xr_batch_ingest_state(h, p, p, p, None)]
 assert all(r == X.XR_ERR_STATE for r in pre), pre
 for fn, a in ((L.xr_batch_assign, (None, None)), (L.xr_batch_step, (None, None, None)), (L.xr_batch_fetch, (None, 0, None, 0, None)), (L.xr_batch_store, (None, 0, None, 0, None)), (L.xr_batch_state_row_bytes, (None, None))):
     assert fn(*a) == X.XR_ERR_INVALID
@@ -188,6 +189,13 @@ for ci, kw in enumerate(cfgs):
         assert L.xr_batch_expand_state(h, rp, rb.value, -1, out.ctypes.data, 2 * N, act.ctypes.data, act.ctypes.data, None) == X.XR_ERR_RANGE
         assert L.xr_batch_expand_state(h, rp, rb.value, B, None, 2 * N, act.ctypes.data, act.ctypes.data, None) == X.XR_ERR_INVALID
         assert L.xr_batch_expand_state(h, rp, rb.value, B, out.ctypes.data, 1, act.ctypes.data, act.ctypes.data, None) == X.XR_ERR_RANGE
+        # ingest of an external state: null / misaligned pointers are refused
+        ow = np.zeros(B * N + 8, np.int16); op = ow.ctypes.data; op += (-op) % 16
+        lgw = np.zeros(B * lwv + 1, np.uint64); cm = np.zeros(B * 3, np.int32)
+        assert L.xr_batch_ingest_state(h, op, lgw.ctypes.data, cm.ctypes.data, None) == 0
+        assert L.xr_batch_ingest_state(h, op + 2, lgw.ctypes.data, cm.ctypes.data, None) == X.XR_ERR_INVALID
+        assert L.xr_batch_ingest_state(h, op, lgw.ctypes.data + 4, cm.ctypes.data, None) == X.XR_ERR_INVALID
+        assert L.xr_batch_ingest_state(h, op, None, cm.ctypes.data, None) == X.XR_ERR_INVALID
         # guides: valid tables, then hostile ones; a refused table leaves the batch usable
         offs, boxes = [], []
         for r in regs:

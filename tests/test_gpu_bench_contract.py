@@ -48,7 +48,7 @@ def test_bench_json_contract(extra):
         assert pk["parity"]["observations_equal"] is True and pk["parity"]["observations_checked"] >= 16
         # the reference's own configuration (maze_end_iter 3, follow_guide over the design's rectangles) as a FULL step, and every
         # XR-Maze v2 / config 5 leg: each with its own oracle replay
-        v2full = [k for k in d["kernels"] if "the reference's configuration" in k["kernel"]]
+        v2full = [k for k in d["kernels"] if "the reference's TCL knob VALUES" in k["kernel"]]
         assert len(v2full) == 1 and v2full[0]["parity"]["ok"] is True and v2full[0]["parity"]["observations_equal"] is True
         for k in d["kernels"]:
             if "XR-Maze v2" in k["kernel"] or "config 5" in k["kernel"]:

@@ -1,0 +1,78 @@
+"""xr_batch_ingest_state (ABI 9): the client half of the reference's Game.step WITHOUT the route — a new state of every env slot, as an external
+simulator's Request carries it, becomes the batch's state (reference baseline/baseline_utils.py:420-438: metric deltas = new - previous cumulative
+values, done = no nets left; reward baseline/DQN/train_DQN.py:98-99) — BASELINE config 2 ("grid-build + reward only").  The states come from a twin
+batch that routes; what the ingesting batch then reports and the observation it builds are compared with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xr_oracle as orc
+from xroute_env_amd import _lib
+from xroute_env_amd.regions import generate_region
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims", [(24, 40, 9), (7, 5, 3), (13, 11, 4)])
+def test_ingested_states_give_the_reference_deltas_reward_done_and_observation(dims):
+    from xroute_env_amd.batch import RegionBatch
+    dev = "cuda:0"
+    regions = [generate_region(8800 + i, dims=dims, k_range=(1, 9), net_span=5) for i in range(24)]
+    twin = RegionBatch(regions, device=dev)
+    main = RegionBatch(regions, device=dev)
+    envs = [orc.OracleEnv(r) for r in regions]
+    twin.reset(); main.reset()
+    prev = np.array([r.metrics0 for r in regions], np.int64)
+    a = torch.empty(len(regions), dtype=torch.int32, device=dev)
+    for step in range(10):
+        twin.random_actions(100 + step, a)
+        twin.step(a)
+        acts = a.cpu().numpy()
+        main.ingest_state(twin.fetch("owner"), twin.fetch("legal"), twin.fetch("cum"))
+        rec = main.records()
+        obs = main.observation().cpu().numpy()
+        for i, env in enumerate(envs):
+            if acts[i]:
+                env.step(int(acts[i]))
+            cum = env.cum().astype(np.int64)
+            d = cum - prev[i]
+            prev[i] = cum
+            assert rec["delta"][i].tolist() == d.tolist() and rec["cum"][i].tolist() == cum.tolist()
+            want = -1 * (float(d[0]) * 500 + float(d[2]) * 4 + float(d[1]) * 0.5)        # the trainers' expression (train_DQN.py:98-99)
+            assert rec["reward"][i] == want and rec["nlegal"][i] == env.nlegal() and bool(rec["done"][i]) == (env.nlegal() == 0)
+            assert rec["status"][i] == 0 and rec["env_steps"][i] == step + 1
+            ro = env.observation()
+            assert np.array_equal(ro.ravel(), obs[i, : ro.size])
+        assert main.legal_sets() == twin.legal_sets()
+    # the batch goes on from an ingested state like from any other: routing the next net gives the oracle's result
+    legal = main.legal_sets()
+    acts = [min(s) if s else 0 for s in legal]
+    main.step(torch.tensor(acts, dtype=torch.int32, device=dev))
+    rec = main.records()
+    for i, env in enumerate(envs):
+        if acts[i]:
+            assert rec["delta"][i].tolist() == env.step(acts[i])["delta"].tolist()
+
+
+def test_ingest_state_drops_net_bits_beyond_the_region_and_checks_its_arguments():
+    from xroute_env_amd.batch import RegionBatch
+    dev = "cuda:0"
+    regions = [generate_region(8900 + i, dims=(9, 8, 3), k_range=(k, k), net_span=4) for i, k in enumerate((2, 5, 70))]
+    b = RegionBatch(regions, device=dev)
+    b.reset()
+    assert b.legal_words == 2
+    owner = b.fetch("owner").clone()
+    legal = torch.full((3, 2), -1, dtype=torch.int64, device=dev)            # every bit set, also the ones that name no net
+    cum = torch.tensor([[1, 2, 3], [0, 0, 0], [7, 8, 9]], dtype=torch.int32, device=dev)
+    b.ingest_state(owner, legal, cum)
+    assert [len(s) for s in b.legal_sets()] == [2, 5, 70] and b.fetch("nlegal").tolist() == [2, 5, 70]
+    assert b.fetch("cum").tolist() == cum.tolist()
+    with pytest.raises(ValueError):
+        b.ingest_state(owner[:, :-1].contiguous(), legal, cum)
+    with pytest.raises(ValueError):
+        b.ingest_state(owner, legal.to(torch.int32), cum)
+    with pytest.raises(ValueError):
+        b.ingest_state(owner, legal, cum.to(torch.int64))
+    import ctypes as C
+    assert b.L.xr_batch_ingest_state(b._h, None, C.c_void_p(legal.data_ptr()), C.c_void_p(cum.data_ptr()), None) == _lib.XR_ERR_INVALID
+    assert b.L.xr_batch_ingest_state(b._h, C.c_void_p(owner.data_ptr() + 2), C.c_void_p(legal.data_ptr()), C.c_void_p(cum.data_ptr()), None) == _lib.XR_ERR_INVALID

@@ -367,6 +367,60 @@ def test_guide_boxes_are_validated():
     RegionBatch([reg], device="cuda:0", guide_cost=500).close()
 
 
+@pytest.mark.parametrize("no_mask", [False, True])
+def test_a_refused_guide_reload_leaves_the_loaded_guides_in_force(no_mask):
+    """xr_batch_load_guides used to null the box tables before validating, so a refused reload left the STATIC MASKS of the old
+    boxes routing in the mask form while the per-route form (XR_NO_GUIDE_MASK=1) fell back to the default guides — two forms built to be
+    result-identical, no longer so.  Now everything is validated and staged first: after a refused reload both forms keep routing with the
+    boxes loaded before (== the oracle with those boxes)."""
+    import subprocess
+    import sys
+    child = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.test_gpu_route import _random_guides
+from xroute_env_amd import _lib
+from xroute_env_amd.batch import RegionBatch
+from xroute_env_amd.regions import generate_region
+from oracle import xr_oracle as orc
+import ctypes as C
+v2 = dict(guide_cost=1000, guide_margin=1, maze_end_iter=3)
+regions = [_random_guides(generate_region(3700 + i), 91 + i) for i in range(8)]
+batch = RegionBatch(regions, device="cuda:0", **v2)
+envs = [orc.OracleEnv(r, **v2) for r in regions]
+# a reload whose LAST region carries a box outside the grid: refused ...
+n = len(regions)
+offs, boxes, keep = (C.c_void_p * n)(), (C.c_void_p * n)(), []
+for i, r in enumerate(regions):
+    off = np.ascontiguousarray(r.guide_off, np.int32); box = np.ascontiguousarray(r.guide_box, np.int16).reshape(-1, 6).copy()
+    if i == n - 1:
+        box[0, 2] = 30000
+    else:
+        box[:, 0] = 0; box[:, 1] = 0                 # (other boxes than before: were they adopted, routes would change)
+    keep += [off, box]; offs[i], boxes[i] = off.ctypes.data, box.ctypes.data
+rc = batch.L.xr_batch_load_guides(batch._h, offs, boxes, None)
+assert rc == _lib.XR_ERR_RANGE, rc
+# ... and the batch still routes with the boxes it had
+batch.reset()
+for _ in range(60):
+    legal = batch.legal_sets()
+    if not any(legal):
+        break
+    acts = [max(s) if s else 0 for s in legal]
+    batch.step(torch.tensor(acts, dtype=torch.int32, device="cuda:0"))
+    rec = batch.records()
+    for i, env in enumerate(envs):
+        if acts[i]:
+            ref = env.step(acts[i])
+            assert rec["delta"][i].tolist() == ref["delta"].tolist(), (i, acts[i])
+assert [int(h) for h in batch.fetch("hash").cpu().numpy().view(np.uint64)] == [e.hash() for e in envs]
+print("GUIDES_KEPT")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **({"XR_NO_GUIDE_MASK": "1"} if no_mask else {}))
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "GUIDES_KEPT" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
 def test_xr_maze_v2_refused_where_unsupported():
     from xroute_env_amd._lib import XRouteError
     from xroute_env_amd.batch import RegionBatch

@@ -89,3 +89,26 @@ def test_no_reference_source_under_tests_or_repo():
         if ".git" in dirpath or "gpurun_out" in dirpath:
             continue
         assert not (names & set(files)), (dirpath, names & set(files))
+
+
+def test_integration_md_stub_is_generated_from_the_binding():
+    """INTEGRATION.md §3.3 (the ctypes stub a maintainer would start from) is generated from xroute_env_amd/_lib.py by
+    tools/gen_integration_stub.py: the ABI version, the config struct and every entry point's argument types cannot go stale."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_integration_stub", os.path.join(root, "tools", "gen_integration_stub.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN): doc.index(gen.END)].strip()
+    assert block == gen.stub_text().strip(), "run `python tools/gen_integration_stub.py`"
+    from xroute_env_amd import _lib
+    L = _lib.lib()
+    no_args = {"xr_abi_version", "xr_last_error", "xr_agent_obstacle_tower_weights", "xr_agent_actor_weights"}
+    assert all(getattr(L, n).argtypes for n in _lib.SYMBOLS if n not in no_args), "every exported symbol is bound with its argument types"
+    # ... and the header declares exactly the symbols the binding lists
+    import re
+    hdr = open(os.path.join(root, "include", "xroute_hip.h")).read()
+    declared = set(re.findall(r"^(?:int32_t|void|const char\*)\s+(xr_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))

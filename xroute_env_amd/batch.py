@@ -227,6 +227,20 @@ class RegionBatch:
             _lib.check(self.L.xr_batch_pack_state(self._h, C.c_void_p(out.data_ptr()), rb, int(region_base), _stream_ptr(self.device)))
         return out
 
+    def ingest_state(self, owner: torch.Tensor, legal: torch.Tensor, cum: torch.Tensor):
+        """Adopt a new state of every env slot produced by an EXTERNAL simulator (the client half of the reference's Game.step without the
+        route, baseline/baseline_utils.py:420-438 — BASELINE config 2): owner int16 [n_envs, n_max], legal int64 / uint64 [n_envs, legal_words],
+        cum int32 [n_envs, 3].  The records then carry the metric deltas, the reward and `done`; `observation()` builds the grid."""
+        if owner.dtype != torch.int16 or tuple(owner.shape) != (self.n_envs, self.n_max) or not owner.is_contiguous():
+            raise ValueError("owner must be a contiguous int16 [n_envs, n_max] tensor")
+        if legal.dtype not in (torch.int64, torch.uint64) or tuple(legal.shape) != (self.n_envs, self.legal_words) or not legal.is_contiguous():
+            raise ValueError("legal must be a contiguous 64-bit [n_envs, legal_words] tensor")
+        if cum.dtype != torch.int32 or tuple(cum.shape) != (self.n_envs, 3) or not cum.is_contiguous():
+            raise ValueError("cum must be a contiguous int32 [n_envs, 3] tensor")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.xr_batch_ingest_state(self._h, C.c_void_p(owner.data_ptr()), C.c_void_p(legal.data_ptr()), C.c_void_p(cum.data_ptr()),
+                                                    _stream_ptr(self.device)))
+
     def expand_state(self, rows: torch.Tensor, head_out: Optional[torch.Tensor] = None, nlegal_out: Optional[torch.Tensor] = None,
                      region_out: Optional[torch.Tensor] = None):
         """Learner side: packed rows (uint8 [n, row_bytes], e.g. the all_gather of every rank's `pack_state`) -> (head [n, stride] fp32 with

@@ -36,6 +36,7 @@ hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const in
 hipError_t xr_launch_pack_state(const XrBatchDev*, uint8_t*, int64_t, int, hipStream_t);
 hipError_t xr_launch_guide_masks(const XrBatchDev*, uint8_t*, int, hipStream_t);
 hipError_t xr_launch_expand_state(const XrBatchDev*, const uint8_t*, int64_t, int, float*, int64_t, int32_t*, int32_t*, int, hipStream_t);
+hipError_t xr_launch_ingest_state(const XrBatchDev*, const int16_t*, const uint64_t*, const int32_t*, hipStream_t);
 }
 
 namespace {
@@ -1215,6 +1216,17 @@ int32_t xr_batch_expand_state(xr_batch* b, const uint8_t* rows_dev, int64_t row_
     const bool aligned = (head_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(head_out_dev) & 15) == 0);
     XR_HIP(xr_launch_expand_state(&b->dev, rows_dev, row_bytes, n_rows, head_out_dev, head_stride, nlegal_out_dev, region_out_dev, aligned ? 1 : 0,
                                   static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_ingest_state(xr_batch* b, const int16_t* owner_dev, const uint64_t* legal_dev, const int32_t* cum_dev, void* stream) {
+    if (!b || !owner_dev || !legal_dev || !cum_dev) return fail(XR_ERR_INVALID, "xr_batch_ingest_state: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_ingest_state: load regions first");
+    if ((reinterpret_cast<uintptr_t>(owner_dev) & 15) != 0 || (reinterpret_cast<uintptr_t>(legal_dev) & 7) != 0 || (reinterpret_cast<uintptr_t>(cum_dev) & 3) != 0)
+        return fail(XR_ERR_INVALID, "xr_batch_ingest_state: owner rows must be 16-byte aligned, legal words 8-byte, metrics 4-byte");
+    XR_HIP(hipSetDevice(b->cfg.device));
+    b->obs_valid_ptr = nullptr;                       // whatever observation a caller holds no longer describes the batch
+    XR_HIP(xr_launch_ingest_state(&b->dev, owner_dev, legal_dev, cum_dev, static_cast<hipStream_t>(stream)));
     return XR_OK;
 }
 

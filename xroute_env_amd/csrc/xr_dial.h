@@ -167,6 +167,9 @@ __device__ __forceinline__ void xr_step_epilogue(const XrBatchDev& b, const int 
         const long long dt = (long long)__builtin_readcyclecounter() - xr_s_route_t0;
         const int cls = (int)min((dt >> b.meas_shift) + 1ll, 255ll);
         b.net_meas[xr_s_route_net] = (uint8_t)max(cls, 1);
+#ifndef XR_PHASE_TIMING
+        b.phase_cycles[(int64_t)e * 8 + 7] = dt;      // cycles of this env's last route (XR_FETCH_PHASES, slot 7): bench.py's launch utilisation = mean / max over a launch
+#endif
     }
     fnv_mix(h, (uint32_t)a);
     fnv_mix(h, (uint32_t)d_vio); fnv_mix(h, (uint32_t)d_wl); fnv_mix(h, (uint32_t)d_via);

@@ -118,6 +118,50 @@ __device__ void xr_env_reset(const XrBatchDev& b, int e, int rotate, int extra_s
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ingest of a NEW state of every env that an external simulator produced (BASELINE config 2: "grid-build + reward only"): the client
+// half of Game.step (reference baseline/baseline_utils.py:420-438) without the route — what a `Request` carries per env (occupancy of
+// every node, the nets still to route, the cumulative metrics) becomes the env's state; the metric deltas are new - previous cumulative
+// values (:426-428), the reward is the trainers' expression in double (baseline/DQN/train_DQN.py:98-99), done = no nets left (:435-436).
+// One workgroup per env: a 16-byte vector copy of the owner row (2·N read + 2·N written), the legal bitmask cut to the region's nets.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xr_ingest_state_kernel(XrBatchDev b, const int16_t* __restrict__ owner_in, const uint64_t* __restrict__ legal_in,
+                                                              const int32_t* __restrict__ cum_in) {
+    __shared__ int s_cnt[4];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const XrRegionDev R = b.regions[b.env_region[e]];
+    const int4* s4 = reinterpret_cast<const int4*>(owner_in + (int64_t)e * b.n_max);
+    int4* d4 = reinterpret_cast<int4*>(b.owner + (int64_t)e * b.n_max);
+    const int nvec = (R.N + 7) >> 3;                         // rows are padded to multiples of 8 elements (n_max)
+    for (int i = tid; i < nvec; i += blockDim.x) d4[i] = s4[i];
+    int cnt = 0;
+    for (int w = tid; w < b.legal_words; w += blockDim.x) {
+        const int lo = w * 64, K = R.n_nets;
+        const uint64_t allowed = K >= lo + 64 ? ~0ULL : (K > lo ? ((1ULL << (K - lo)) - 1ULL) : 0ULL);
+        const uint64_t v = legal_in[(int64_t)e * b.legal_words + w] & allowed;      // (a bit beyond the region's nets names no net: dropped)
+        b.legal[(int64_t)e * b.legal_words + w] = v;
+        cnt += __popcll(v);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const int nl = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int c0 = cum_in[3 * e], c1 = cum_in[3 * e + 1], c2 = cum_in[3 * e + 2];
+        const int d_vio = c0 - b.cum[3 * e], d_wl = c1 - b.cum[3 * e + 1], d_via = c2 - b.cum[3 * e + 2];
+        b.cum[3 * e] = c0; b.cum[3 * e + 1] = c1; b.cum[3 * e + 2] = c2;
+        b.delta[3 * e] = d_vio; b.delta[3 * e + 1] = d_wl; b.delta[3 * e + 2] = d_via;
+        const double s = b.w_violation * (double)d_vio + b.w_via * (double)d_via + b.w_wirelength * (double)d_wl;
+        b.reward[e] = -1.0 * s;
+        b.nlegal[e] = nl;
+        b.done[e] = (nl == 0);
+        b.status[e] = XR_ENV_OK;
+        b.path_len[e] = 0;
+        b.env_steps[e] += 1;
+        xr_publish_record(b, e);
+    }
+}
+
 __global__ void xr_reset_kernel(XrBatchDev b, const uint8_t* __restrict__ mask, int rotate) {
     const int e = blockIdx.x;
     if (mask && !mask[e]) return;
@@ -2191,6 +2235,12 @@ hipError_t xr_launch_guide_masks(const XrBatchDev* b, uint8_t* masks, int k_max,
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t xr_launch_ingest_state(const XrBatchDev* b, const int16_t* owner_in, const uint64_t* legal_in, const int32_t* cum_in, hipStream_t st) {
+    if (b->n_envs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xr_ingest_state_kernel, dim3(b->n_envs), dim3(256), 0, st, *b, owner_in, legal_in, cum_in);
+    return hipGetLastError();
 }
 
 hipError_t xr_launch_pack_state(const XrBatchDev* b, uint8_t* rows, int64_t row_bytes, int region_base, hipStream_t st) {
