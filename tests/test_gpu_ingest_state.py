@@ -57,15 +57,15 @@ def test_ingested_states_give_the_reference_deltas_reward_done_and_observation(d
 def test_ingest_state_drops_net_bits_beyond_the_region_and_checks_its_arguments():
     from xroute_env_amd.batch import RegionBatch
     dev = "cuda:0"
-    regions = [generate_region(8900 + i, dims=(9, 8, 3), k_range=(k, k), net_span=4) for i, k in enumerate((2, 5, 70))]
+    regions = [generate_region(8900 + i, dims=(9, 8, 3), k_range=(k, k), net_span=4) for i, k in enumerate((2, 5, 40))]
     b = RegionBatch(regions, device=dev)
     b.reset()
-    assert b.legal_words == 2
+    ks = [r.n_nets for r in regions]
     owner = b.fetch("owner").clone()
-    legal = torch.full((3, 2), -1, dtype=torch.int64, device=dev)            # every bit set, also the ones that name no net
+    legal = torch.full((3, b.legal_words), -1, dtype=torch.int64, device=dev)            # every bit set, also the ones that name no net
     cum = torch.tensor([[1, 2, 3], [0, 0, 0], [7, 8, 9]], dtype=torch.int32, device=dev)
     b.ingest_state(owner, legal, cum)
-    assert [len(s) for s in b.legal_sets()] == [2, 5, 70] and b.fetch("nlegal").tolist() == [2, 5, 70]
+    assert [len(s) for s in b.legal_sets()] == ks and b.fetch("nlegal").tolist() == ks and ks[0] < ks[2] <= 64 * b.legal_words
     assert b.fetch("cum").tolist() == cum.tolist()
     with pytest.raises(ValueError):
         b.ingest_state(owner[:, :-1].contiguous(), legal, cum)
