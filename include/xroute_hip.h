@@ -415,6 +415,20 @@ int32_t xr_agent_actor_sample(const float* state_dev, const float* head_dev, int
                               const int32_t* region_dev, const float* cache_vec_dev, const float* cache_pre_dev, int32_t cache_kmax, const float* weights_dev,
                               int32_t n_envs, int32_t kcap, float* logits_dev, int32_t* action_dev, const int64_t* env_ids_dev, uint64_t s0, void* stream);
 
+/* The NET tower of the same network (ABI 9: `net_conv1 -> net_align_conv1 -> net_conv2 -> net_align_conv2`, baseline/baseline_utils.py:246-262, 350-357) for
+ * n_pairs (region, net) pairs of ONE grid shape (D, H, W) = (dim_z, dim_y, dim_x), straight from the access-point lists of the regions loaded in `b` — the 7 planes
+ * of a net (baseline/build_3Dgrid.py:106-142) are never formed: they are 0/1 planes whose non-zeros are the net's access points, ResidualBlock(7) of such an input
+ * differs from its response to an empty grid only within two voxels of one, and the aligning convolution is linear (xr_agent.hip, the NET branch).
+ *   pair_region_dev / pair_net_dev  int32 [n_pairs]: region index in `b`, 1-based net id
+ *   weights_dev   xr_agent_net_tower_weights() floats, bg_dev fp32 [od*oh*ow*7] = align1(block(0)) of this shape: both packed by agents.FusedNetTower
+ *   out_dev       fp32 [n_pairs][64] (min-max normalised when normalize != 0, like the obstacle tower's rows)
+ *   flags_dev     int32 [n_pairs], ZEROED BY THE CALLER: 1 = the net's neighbourhood lists do not fit LDS (more than ~20 scattered access points: the caller's
+ *                 framework path takes that net), 2 = the pair names a region of another shape or a net it does not have; such rows of out_dev stay unwritten
+ * XR_ERR_RANGE for grid shapes the kernel does not take. */
+int32_t xr_agent_net_tower_weights(void);
+int32_t xr_batch_net_vectors(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs, int32_t D, int32_t H, int32_t W,
+                             const float* weights_dev, const float* bg_dev, float* out_dev, int32_t* flags_dev, int32_t normalize, void* stream);
+
 /* ---- wire format (net_ordering.proto v1), host only ---------------------------------------- */
 /* Replaces handle_messange's protobuf decode (baseline/baseline_utils.py:9-43; the `message.ParseFromString` of :418,467), with the
  * runtime's parse rules: the oneof keeps the LAST member on the wire, a repeated occurrence of the same member merges (scalars: last

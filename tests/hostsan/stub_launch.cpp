@@ -27,5 +27,7 @@ hipError_t xr_launch_netplanes_pairs(const XrBatchDev*, const int32_t*, const in
 hipError_t xr_launch_pack_state(const XrBatchDev*, uint8_t*, int64_t, int, hipStream_t) { xr_stub_launches++; return hipSuccess; }
 hipError_t xr_launch_guide_masks(const XrBatchDev*, uint8_t*, int, hipStream_t) { xr_stub_launches++; return hipSuccess; }
 hipError_t xr_launch_ingest_state(const XrBatchDev*, const int16_t*, const uint64_t*, const int32_t*, hipStream_t) { xr_stub_launches++; return hipSuccess; }
+hipError_t xr_launch_net_tower(const void*, const int32_t*, const int32_t*, int32_t, const int32_t*, const int32_t*, int32_t, int32_t, int32_t, int32_t, const float*, const float*,
+                               float*, int32_t*, int32_t, hipStream_t, int32_t* status) { *status = 0; xr_stub_launches++; return hipSuccess; }
 hipError_t xr_launch_expand_state(const XrBatchDev*, const uint8_t*, int64_t, int, float*, int64_t, int32_t*, int32_t*, int, hipStream_t) { xr_stub_launches++; return hipSuccess; }
 }

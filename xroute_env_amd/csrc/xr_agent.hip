@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "../../include/xroute_hip.h"
+#include "xr_device.h"
 
 namespace {
 
@@ -50,6 +51,28 @@ constexpr int XT_C2 = XT_C1 + 4104;         // same       block(7).conv2
 constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padded to 8][kw]: the 12 weights a lane of the last stage needs are neighbours
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_TOTAL = XT_KV + 64;
+// the NET tower (same 7-channel block + last convolution, its own weights in the XT_C1 .. XT_KV slots; XT_A1 .. XT_AL1 unused) has a sparse front end
+// behind them (agents.FusedNetTower.pack):
+constexpr int XN_A0 = XT_TOTAL;             // 27*8      block(7).conv1, input plane 0 (the access-point mask): [tap][co padded to 8]
+constexpr int XN_AS = XN_A0 + 216;          // 27*8      the same, planes 1..6 summed (they are ONE aliased plane, baseline/build_3Dgrid.py:125)
+constexpr int XN_BA = XN_AS + 216;          // 8         its bias (BatchNorm folded)
+constexpr int XN_WB = XN_BA + 8;            // 27*7*8    block(7).conv2: [tap][ci][co padded to 8]
+constexpr int XN_ZBG = XN_WB + 1512;        // 64*8      conv2 of the background relu(bias) + its bias, by which taps fall outside the grid:
+                                            //           class = md << 4 | mh << 2 | mw, m = (coordinate > 0) | (coordinate < dim - 1) << 1
+constexpr int XN_WL = XN_ZBG + 512;         // 125*7*8   align1: [tap][ci][co padded to 8]
+constexpr int XN_TOTAL = XN_WL + 7000;
+
+// what the net tower's front end reads besides the weights
+struct XnArgs {
+    const XrRegionDev* regions;
+    const int32_t* net_csr;
+    const int32_t* ap_feat;         // node index | "has a same-net axis neighbour" << 31, per access point (xr_batch.cpp)
+    const int32_t* pair_region;
+    const int32_t* pair_net;        // 1-based
+    const float* bg;                // align1(block(0)) of this grid shape: [od][oh][ow][7]
+    int32_t* flags;                 // per pair: 0 ok, 1 lists do not fit (caller: framework path), 2 another shape / no such net
+    int32_t n_regions;
+};
 
 // A operand of the paired implicit GEMM (see the 7-channel block below): lane l holds row m = l & 15 = (dw, co) and k = l >> 4 = c4 of every
 // one of the 63 (kd, kh, ci) steps: W[co][ci][kd][kh][kw = c4 - dw], 0 where kw is no tap or co is the padding channel — laid out by the caller
@@ -128,9 +151,9 @@ __device__ __forceinline__ bool xt_tile_item(int k, int wv, int nw, int T, int* 
 #define XT_LAP(k) do { } while (0)
 #endif
 
-template <int BT>
+template <int BT, bool NET>
 __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
-                                                          const float* __restrict__ wt, float* __restrict__ out, int normalize) {
+                                                          const float* __restrict__ wt, float* __restrict__ out, int normalize, XnArgs na) {
     extern __shared__ __attribute__((aligned(16))) float xt_smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int e = blockIdx.x;
@@ -161,6 +184,171 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     float* red = xt_smem + g.tail + 8;                // [nthr / 64][cols + 2][3]: every wave's column sums of the last stage
     for (int i = tid; i < 8 + (nthr >> 6) * (g.cols + 2) * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
 
+    float wA[64];
+    if constexpr (NET) {
+        // ==== the net tower's SPARSE front end: P = align1(block(x)) of a net's 7 planes without ever forming them (agents.FusedNetTower) ====
+        // x is 1 at the net's access points (plane 0; planes 1..6: the aliased "has a same-net axis neighbour" flag) and 0 elsewhere.  With S1 / S2 =
+        // the 3x3x3 / 5x5x5 neighbourhoods of the access points:  y = relu(conv_a(x) + b_a) differs from relu(b_a) on S1 only;  o1 = relu(conv_b(y) +
+        // b_b + x) differs from bg1 = block(0) on S2 only, where bg1 = relu(zbg[class of the voxel]);  P = align1(bg1) + align1(o1 - bg1): `na.bg`
+        // (per shape, from the caller) plus a gather of align1's taps over S2.  Sets are bitmasks over the plane + popcount prefixes (slot of a voxel
+        // = voxels of the set before it: lists in voxel order, whatever order the marks arrive in — same input, same bits).
+        const int HW = H * W, MW = (N + 31) >> 5;
+        const int r = na.pair_region[e], a = na.pair_net[e];
+        bool bad = (unsigned)r >= (unsigned)na.n_regions;
+        XrRegionDev R = na.regions[bad ? 0 : r];
+        bad = bad || R.Z != D || R.Y != H || R.X != W || a < 1 || a > R.n_nets;
+        if (bad) { if (tid == 0) na.flags[e] = 2; return; }
+        const int lo = na.net_csr[R.net_off + a], nap = na.net_csr[R.net_off + a + 1] - lo;      // (<= XR_MAX_AP_PER_NET = 128, xr_batch_load_regions)
+        uint32_t* msk = reinterpret_cast<uint32_t*>(bufC1);                 // [4][MW]: S1, S2, access points, their "adjacent" flags
+        int* pre = reinterpret_cast<int*>(bufC1) + 4 * MW;                   // [2][MW]: set voxels before word i of S1 / S2
+        int* s_ap = pre + 2 * MW;                                            // [128][2]: flat index of the access point, its "adjacent" flag
+        int* s_cnt = s_ap + 256;                                             // n1, n2
+        float* s_tab = reinterpret_cast<float*>(s_cnt + 8);                  // A0[216] AS[216] ba[8] zbg[512]
+        const int fixed = 6 * MW + 256 + 8 + 952;
+        for (int i = tid; i < 4 * MW; i += nthr) msk[i] = 0u;
+        for (int i = tid; i < 952; i += nthr) s_tab[i] = i < 440 ? wt[XN_A0 + i] : wt[XN_ZBG + i - 440];
+        if (tid < nap) {
+            const int v = na.ap_feat[R.ap_off + lo + tid], f = v & 0x7FFFFFFF;
+            s_ap[2 * tid] = f; s_ap[2 * tid + 1] = (int)((uint32_t)v >> 31);
+        }
+        __syncthreads();
+        for (int i = tid; i < nap * 125; i += nthr) {
+            const int k = i / 125, o = i - k * 125, dd = o / 25 - 2, dh = (o / 5) % 5 - 2, dw = o % 5 - 2;
+            const int f = s_ap[2 * k], d = f / HW + dd, h = (f / W) % H + dh, w = f % W + dw;
+            if ((unsigned)d < (unsigned)D && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                const int v = (d * H + h) * W + w;
+                atomicOr(&msk[MW + (v >> 5)], 1u << (v & 31));
+                if (abs(dd) <= 1 && abs(dh) <= 1 && abs(dw) <= 1) atomicOr(&msk[v >> 5], 1u << (v & 31));
+                if (o == 62) {                                               // the access point itself
+                    atomicOr(&msk[2 * MW + (v >> 5)], 1u << (v & 31));
+                    if (s_ap[2 * k + 1]) atomicOr(&msk[3 * MW + (v >> 5)], 1u << (v & 31));
+                }
+            }
+        }
+        __syncthreads();
+        if (wv < 2) {                                                        // wave 0: S1, wave 1: S2 — exclusive popcount prefixes
+            const uint32_t* m = msk + wv * MW;
+            int* pr = pre + wv * MW;
+            const int per = (MW + 63) >> 6, base = lane * per;
+            int sum = 0;
+            for (int j = 0; j < per; j++) sum += base + j < MW ? __popc(m[base + j]) : 0;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            int run = incl - sum;
+            for (int j = 0; j < per; j++)
+                if (base + j < MW) { pr[base + j] = run; run += __popc(m[base + j]); }
+            if (lane == 63) s_cnt[wv] = incl;
+        }
+        __syncthreads();
+        const int n1 = s_cnt[0], n2 = s_cnt[1];
+        // lists: S1 (voxel ids + dy) in b's space — free until the background is loaded —, S2 (voxel ids + do) behind the fixed part
+        const int c1_words = g.tail - nB;
+        if ((n1 + 1) / 2 + 7 * n1 > nB || fixed + (n2 + 1) / 2 + 7 * n2 > c1_words) { if (tid == 0) na.flags[e] = 1; return; }
+        uint16_t* vox1 = reinterpret_cast<uint16_t*>(bufB);
+        float* dy = bufB + (n1 + 1) / 2;
+        uint16_t* vox2 = reinterpret_cast<uint16_t*>(bufC1 + fixed);
+        float* dq = bufC1 + fixed + (n2 + 1) / 2;
+        if (tid < 2 * MW) {
+            const int which = tid >= MW, wd = tid - which * MW;
+            uint32_t bits = msk[which * MW + wd];
+            int p = pre[which * MW + wd];
+            uint16_t* vx = which ? vox2 : vox1;
+            while (bits) { const int b = __builtin_ctz(bits); vx[p++] = (uint16_t)(wd * 32 + b); bits &= bits - 1; }
+        }
+        __syncthreads();
+        // ---- dy = relu(b_a + the access points' stamps) - relu(b_a) on S1
+        for (int s = tid; s < n1; s += nthr) {
+            const int v = vox1[s], d = v / HW, h = (v / W) % H, w = v % W;
+            float acc[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) acc[c] = s_tab[432 + c];
+            for (int k = 0; k < nap; k++) {
+                const int f = s_ap[2 * k], kd = f / HW - d + 1, kh = (f / W) % H - h + 1, kw = f % W - w + 1;
+                if ((unsigned)kd < 3u && (unsigned)kh < 3u && (unsigned)kw < 3u) {
+                    const int t = ((kd * 3 + kh) * 3 + kw) * 8;
+                    const bool adj = s_ap[2 * k + 1] != 0;
+#pragma unroll
+                    for (int c = 0; c < 7; c++) acc[c] = acc[c] + s_tab[t + c] + (adj ? s_tab[216 + t + c] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 7; c++) dy[s * 7 + c] = fmaxf(acc[c], 0.f) - fmaxf(s_tab[432 + c], 0.f);
+        }
+        __syncthreads();
+        // ---- dq = o1 - bg1 on S2: conv_b over the S1 voxels within one voxel, + x at an access point
+        for (int s = tid; s < n2; s += nthr) {
+            const int v = vox2[s], d = v / HW, h = (v / W) % H, w = v % W;
+            const int cls = ((((d > 0) | ((d < D - 1) << 1)) << 4) | (((h > 0) | ((h < H - 1) << 1)) << 2) | ((w > 0) | ((w < W - 1) << 1))) * 8;
+            float z[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) z[c] = s_tab[440 + cls + c];
+#pragma unroll 1
+            for (int t = 0; t < 27; t++) {
+                const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+                const int ud = d + kd, uh = h + kh, uw = w + kw;
+                if ((unsigned)ud < (unsigned)D && (unsigned)uh < (unsigned)H && (unsigned)uw < (unsigned)W) {
+                    const int u = v + kd * HW + kh * W + kw;
+                    const uint32_t mw_ = msk[u >> 5];
+                    if ((mw_ >> (u & 31)) & 1u) {
+                        const float* yr = dy + (pre[u >> 5] + __popc(mw_ & ((1u << (u & 31)) - 1u))) * 7;
+                        const float* __restrict__ wk = wt + XN_WB + t * 56;
+#pragma unroll
+                        for (int ci = 0; ci < 7; ci++) {
+                            const float yv = yr[ci];
+#pragma unroll
+                            for (int c = 0; c < 7; c++) z[c] += wk[ci * 8 + c] * yv;
+                        }
+                    }
+                }
+            }
+            const bool isap = (msk[2 * MW + (v >> 5)] >> (v & 31)) & 1u, isadj = (msk[3 * MW + (v >> 5)] >> (v & 31)) & 1u;
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                const float xv = c == 0 ? (isap ? 1.f : 0.f) : (isadj ? 1.f : 0.f);
+                dq[s * 7 + c] = fmaxf(z[c] + xv, 0.f) - fmaxf(s_tab[440 + cls + c], 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- P = the background (now that dy is dead) + align1's taps gathered over S2
+        for (int i = tid; i < nB; i += nthr) bufB[i] = na.bg[i];
+        xt_load_wA(wt + XT_C1, lane, wA);                      // (the first matrix stage's operands: in flight under the gather)
+        __syncthreads();
+        const uint32_t* m2 = msk + MW;
+        const int* pre2 = pre + MW;
+        const int ncell = od * oh * ow;
+        for (int qo = tid; qo < ncell; qo += nthr) {
+            const int hz = qo % oh, wz = (qo / oh) % ow, dz = qo / (ow * oh), i = (dz * oh + hz) * ow + wz;
+            const int d0 = dz * g.sd - 1, h0 = hz * g.sh - 1, w0 = wz * g.sw - 1;
+            float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool any = false;
+#pragma unroll 1
+            for (int t = 0; t < 125; t++) {
+                const int kd = t / 25, kh = (t / 5) % 5, kw = t % 5;
+                const int ud = d0 + kd, uh = h0 + kh, uw = w0 + kw;
+                if ((unsigned)ud < (unsigned)D && (unsigned)uh < (unsigned)H && (unsigned)uw < (unsigned)W) {
+                    const int u = (ud * H + uh) * W + uw;
+                    const uint32_t mw_ = m2[u >> 5];
+                    if ((mw_ >> (u & 31)) & 1u) {
+                        const float* qr = dq + (pre2[u >> 5] + __popc(mw_ & ((1u << (u & 31)) - 1u))) * 7;
+                        const float* __restrict__ wk = wt + XN_WL + t * 56;
+                        any = true;
+#pragma unroll
+                        for (int ci = 0; ci < 7; ci++) {
+                            const float qv = qr[ci];
+#pragma unroll
+                            for (int c = 0; c < 7; c++) acc[c] += wk[ci * 8 + c] * qv;
+                        }
+                    }
+                }
+            }
+            if (any) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) bufB[i * 7 + c] += acc[c];
+            }
+        }
+        __syncthreads();
+    } else {
     const float* __restrict__ src = head + (int64_t)e * stride;
     for (int i = tid; i < Np; i += nthr) { xpad[i] = 0.f; ypad[i] = 0.f; }
     __syncthreads();
@@ -190,7 +378,6 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     XT_LAP(3);
     // the A operand of the 7-channel block's first convolution: 16 loads per lane, issued here so that the aligning convolution hides them
     // (it fetches nothing through the vector memory path; earlier, the 64 registers would squeeze the 1-channel stages)
-    float wA[64];
     xt_load_wA(wt + XT_C1, lane, wA);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
@@ -221,6 +408,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int co = 0; co < 7; co++) bufB[i * 7 + co] = acc[co >> 1][co & 1];
     }
     __syncthreads();
+    }       // (!NET)
     XT_LAP(4);
     // ---- ResidualBlock(7) on the standard grid [7,3,64,64] (P = b, zero elsewhere): first activation on h < oh + 3, w < ow + 3 ----
     // Both 7 -> 7-channel 3x3x3 convolutions run on the matrix pipe as an implicit GEMM of v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered
@@ -602,14 +790,52 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     g.tail = (int)(nB + c1_alloc);
     const size_t lds = (size_t)(nB + c1_alloc + 8 + (threads / 64) * (g.cols + 2) * 3) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
-    const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024>)
-                   : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512>);
+    const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, false>)
+                   : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256, false>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512, false>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (threads == 1024) hipLaunchKernelGGL(xr_ob_tower_kernel<1024>, dim3(n_envs), dim3(1024), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
-    else if (threads == 256) hipLaunchKernelGGL(xr_ob_tower_kernel<256>, dim3(n_envs), dim3(256), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
-    else hipLaunchKernelGGL(xr_ob_tower_kernel<512>, dim3(n_envs), dim3(512), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize);
+    const XnArgs none{};
+    if (threads == 1024) hipLaunchKernelGGL((xr_ob_tower_kernel<1024, false>), dim3(n_envs), dim3(1024), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
+    else if (threads == 256) hipLaunchKernelGGL((xr_ob_tower_kernel<256, false>), dim3(n_envs), dim3(256), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
+    else hipLaunchKernelGGL((xr_ob_tower_kernel<512, false>), dim3(n_envs), dim3(512), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
     return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
+}
+
+int32_t xr_agent_net_tower_weights(void) { return XN_TOTAL; }
+
+// The net tower of the reference's RepresentationNetwork (`net_conv1 -> net_align_conv1 -> net_conv2 -> net_align_conv2`, baseline/baseline_utils.py:246-262,
+// 350-357) for n_pairs (region, net) pairs of ONE grid shape, straight from the regions' access-point lists: the same kernel as the obstacle tower with a sparse
+// front end (see XnArgs / the NET branch).  Called by xr_batch_net_vectors (xr_batch.cpp), which owns the region tables.  bg_dev: fp32 [od*oh*ow*7];
+// out_dev fp32 [n_pairs][64]; flags_dev int32 [n_pairs] (zeroed by the caller): 1 = the net's lists do not fit LDS, 2 = wrong shape / no such net — those rows
+// of out_dev are left unwritten.
+hipError_t xr_launch_net_tower(const void* regions, const int32_t* net_csr, const int32_t* ap_feat, int32_t n_regions, const int32_t* pair_region_dev,
+                               const int32_t* pair_net_dev, int32_t n_pairs, int32_t D, int32_t H, int32_t W, const float* weights_dev, const float* bg_dev,
+                               float* out_dev, int32_t* flags_dev, int32_t normalize, hipStream_t st, int32_t* status) {
+    *status = XR_OK;
+    if (n_pairs == 0) return hipSuccess;
+    XtDims g;
+    g.D = D; g.H = H; g.W = W;
+    auto strd = [](int s, int t) { return (s > t ? (s - t + t - 1) / t : 0) + 1; };
+    g.sd = strd(D, 3); g.sh = strd(H, 64); g.sw = strd(W, 64);
+    if (D + 2 < 5 || H + 2 < 5 || W + 2 < 5) { *status = XR_ERR_RANGE; return hipSuccess; }
+    g.od = (D + 2 - 5) / g.sd + 1; g.oh = (H + 2 - 5) / g.sh + 1; g.ow = (W + 2 - 5) / g.sw + 1;
+    if (g.od > 3 || g.oh + 3 > 64 || g.ow + 3 > 64 || (int64_t)D * H * W >= 65536) { *status = XR_ERR_RANGE; return hipSuccess; }
+    g.cols = g.ow + 2;
+    const int64_t nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
+    const int64_t fixed = 6 * (((int64_t)D * H * W + 31) / 32) + 256 + 8 + 952;
+    if (nB < 1024 * 3 || nC1 < fixed + 1024) { *status = XR_ERR_RANGE; return hipSuccess; }
+    g.y_in_b = 1; g.strip = 3; g.vec_load = 0;
+    g.tail = (int)(nB + nC1);
+    const size_t lds = (size_t)(nB + nC1 + 8 + 16 * (g.cols + 2) * 3) * sizeof(float);
+    if (lds > 160 * 1024) { *status = XR_ERR_RANGE; return hipSuccess; }
+    const void* fn = reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, true>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    XnArgs na;
+    na.regions = static_cast<const XrRegionDev*>(regions); na.net_csr = net_csr; na.ap_feat = ap_feat; na.pair_region = pair_region_dev; na.pair_net = pair_net_dev;
+    na.bg = bg_dev; na.flags = flags_dev; na.n_regions = n_regions;
+    hipLaunchKernelGGL((xr_ob_tower_kernel<1024, true>), dim3(n_pairs), dim3(1024), lds, st, static_cast<const float*>(nullptr), (int64_t)0, n_pairs, g, weights_dev, out_dev, normalize, na);
+    return hipGetLastError();
 }
 
 int32_t xr_agent_actor_weights(void) { return XA_TOTAL; }

@@ -37,6 +37,8 @@ hipError_t xr_launch_pack_state(const XrBatchDev*, uint8_t*, int64_t, int, hipSt
 hipError_t xr_launch_guide_masks(const XrBatchDev*, uint8_t*, int, hipStream_t);
 hipError_t xr_launch_expand_state(const XrBatchDev*, const uint8_t*, int64_t, int, float*, int64_t, int32_t*, int32_t*, int, hipStream_t);
 hipError_t xr_launch_ingest_state(const XrBatchDev*, const int16_t*, const uint64_t*, const int32_t*, hipStream_t);
+hipError_t xr_launch_net_tower(const void*, const int32_t*, const int32_t*, int32_t, const int32_t*, const int32_t*, int32_t, int32_t, int32_t, int32_t, const float*, const float*,
+                               float*, int32_t*, int32_t, hipStream_t, int32_t*);
 }
 
 namespace {
@@ -1227,6 +1229,20 @@ int32_t xr_batch_ingest_state(xr_batch* b, const int16_t* owner_dev, const uint6
     XR_HIP(hipSetDevice(b->cfg.device));
     b->obs_valid_ptr = nullptr;                       // whatever observation a caller holds no longer describes the batch
     XR_HIP(xr_launch_ingest_state(&b->dev, owner_dev, legal_dev, cum_dev, static_cast<hipStream_t>(stream)));
+    return XR_OK;
+}
+
+int32_t xr_batch_net_vectors(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs, int32_t D, int32_t H, int32_t W,
+                             const float* weights_dev, const float* bg_dev, float* out_dev, int32_t* flags_dev, int32_t normalize, void* stream) {
+    if (!b || !weights_dev || !bg_dev || (n_pairs > 0 && (!pair_region_dev || !pair_net_dev || !out_dev || !flags_dev)))
+        return fail(XR_ERR_INVALID, "xr_batch_net_vectors: null argument");
+    if (!b->loaded) return fail(XR_ERR_STATE, "xr_batch_net_vectors: load regions first");
+    if (n_pairs < 0 || D < 1 || H < 1 || W < 1) return fail(XR_ERR_RANGE, "xr_batch_net_vectors: n_pairs %d, grid %dx%dx%d", n_pairs, D, H, W);
+    XR_HIP(hipSetDevice(b->cfg.device));
+    int32_t status = XR_OK;
+    XR_HIP(xr_launch_net_tower(b->regions.p, b->net_csr.p, b->ap_feat.p, b->n_regions, pair_region_dev, pair_net_dev, n_pairs, D, H, W, weights_dev, bg_dev, out_dev,
+                               flags_dev, normalize, static_cast<hipStream_t>(stream), &status));
+    if (status != XR_OK) return fail(status, "xr_batch_net_vectors: the fused net tower does not take a %dx%dx%d grid (the caller keeps the framework path)", D, H, W);
     return XR_OK;
 }
 
