@@ -60,7 +60,8 @@ constexpr int XN_WB = XN_BA + 8;            // 27*7*8    block(7).conv2: [tap][c
 constexpr int XN_ZBG = XN_WB + 1512;        // 64*8      conv2 of the background relu(bias) + its bias, by which taps fall outside the grid:
                                             //           class = md << 4 | mh << 2 | mw, m = (coordinate > 0) | (coordinate < dim - 1) << 1
 constexpr int XN_WL = XN_ZBG + 512;         // 125*7*8   align1: [tap][ci][co padded to 8]
-constexpr int XN_TOTAL = XN_WL + 7000;
+constexpr int XN_WSUM = XN_WL + 7000;       // 1 (+7)    sum over align1's taps and input channels of max_co |W|: bounds every partial sum of the scatter per unit of |o1 - bg1|
+constexpr int XN_TOTAL = XN_WSUM + 8;
 
 // what the net tower's front end reads besides the weights
 struct XnArgs {
@@ -190,81 +191,105 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         // x is 1 at the net's access points (plane 0; planes 1..6: the aliased "has a same-net axis neighbour" flag) and 0 elsewhere.  With S1 / S2 =
         // the 3x3x3 / 5x5x5 neighbourhoods of the access points:  y = relu(conv_a(x) + b_a) differs from relu(b_a) on S1 only;  o1 = relu(conv_b(y) +
         // b_b + x) differs from bg1 = block(0) on S2 only, where bg1 = relu(zbg[class of the voxel]);  P = align1(bg1) + align1(o1 - bg1): `na.bg`
-        // (per shape, from the caller) plus a gather of align1's taps over S2.  Sets are bitmasks over the plane + popcount prefixes (slot of a voxel
-        // = voxels of the set before it: lists in voxel order, whatever order the marks arrive in — same input, same bits).
-        const int HW = H * W, MW = (N + 31) >> 5;
-        const int r = na.pair_region[e], a = na.pair_net[e];
-        bool bad = (unsigned)r >= (unsigned)na.n_regions;
-        XrRegionDev R = na.regions[bad ? 0 : r];
-        bad = bad || R.Z != D || R.Y != H || R.X != W || a < 1 || a > R.n_nets;
+        // (per shape, from the caller) plus align1's taps of the S2 voxels.
+        // Sets are bitmasks, ONE 32-bit word per (d, h) row of the plane (W <= 32), + popcount prefixes: the slot of a voxel = voxels of the set before
+        // it — lists in row order whatever order the marks arrive in.  Rows are ordered by (d + 1) % sd first: an S2 voxel reaches an output depth
+        // only through the taps kd = (d + 1) mod sd (+ sd ...), so the voxels of one residue class run the same taps — uniform weights, all lanes busy.
+        // The taps are SCATTERED from the voxels (every (voxel, tap) pair is real work; gathered per output cell, 87 % of the lanes idled through taps
+        // that hit nothing: 275 k of 430 k cycles) with INTEGER atomics in fixed point (order-independent: same input, same bits): scale =
+        // 2^30 / (sum over taps and input channels of max_co |W| x max |o1 - bg1|), an upper bound of every partial sum.
+        const int HW = H * W, R = D * H;
+        const int r_ = na.pair_region[e], a = na.pair_net[e];
+        bool bad = (unsigned)r_ >= (unsigned)na.n_regions;
+        XrRegionDev Rg = na.regions[bad ? 0 : r_];
+        bad = bad || Rg.Z != D || Rg.Y != H || Rg.X != W || a < 1 || a > Rg.n_nets;
         if (bad) { if (tid == 0) na.flags[e] = 2; return; }
-        const int lo = na.net_csr[R.net_off + a], nap = na.net_csr[R.net_off + a + 1] - lo;      // (<= XR_MAX_AP_PER_NET = 128, xr_batch_load_regions)
-        uint32_t* msk = reinterpret_cast<uint32_t*>(bufC1);                 // [4][MW]: S1, S2, access points, their "adjacent" flags
-        int* pre = reinterpret_cast<int*>(bufC1) + 4 * MW;                   // [2][MW]: set voxels before word i of S1 / S2
-        int* s_ap = pre + 2 * MW;                                            // [128][2]: flat index of the access point, its "adjacent" flag
-        int* s_cnt = s_ap + 256;                                             // n1, n2
-        float* s_tab = reinterpret_cast<float*>(s_cnt + 8);                  // A0[216] AS[216] ba[8] zbg[512]
-        const int fixed = 6 * MW + 256 + 8 + 952;
-        for (int i = tid; i < 4 * MW; i += nthr) msk[i] = 0u;
+        const int lo = na.net_csr[Rg.net_off + a], nap = na.net_csr[Rg.net_off + a + 1] - lo;      // (<= XR_MAX_AP_PER_NET = 128, xr_batch_load_regions)
+        uint32_t* msk = reinterpret_cast<uint32_t*>(bufC1);                 // [4][R]: S1, S2, access points, their "adjacent" flags
+        int* pre = reinterpret_cast<int*>(bufC1) + 4 * R;                    // [2][R]: set voxels before row i of S1 / S2
+        int* s_ap = pre + 2 * R;                                             // [128][2]: the access point's d << 11 | h << 5 | w in the plane, its "adjacent" flag
+        int* s_cnt = s_ap + 256;                                             // n1, n2, bits of max |dq|
+        int* s_dp = s_cnt + 8;                                               // dperm[32] (d -> position in class order), dinv[32], cs[sd + 1] (first position of every class)
+        float* s_tab = reinterpret_cast<float*>(s_dp + 112);                 // A0[216] AS[216] ba[8] zbg[512]
+        const int fixed = 6 * R + 256 + 8 + 112 + 952;
+        const int sd = g.sd;
+        for (int i = tid; i < 4 * R; i += nthr) msk[i] = 0u;
         for (int i = tid; i < 952; i += nthr) s_tab[i] = i < 440 ? wt[XN_A0 + i] : wt[XN_ZBG + i - 440];
-        if (tid < nap) {
-            const int v = na.ap_feat[R.ap_off + lo + tid], f = v & 0x7FFFFFFF;
-            s_ap[2 * tid] = f; s_ap[2 * tid + 1] = (int)((uint32_t)v >> 31);
+        if (tid < nap) {                                                     // (integer divisions by run-time values cost ~40 instructions each: once per access point)
+            const int v = na.ap_feat[Rg.ap_off + lo + tid], f = v & 0x7FFFFFFF, d = f / HW, rem = f - d * HW, h = rem / W;
+            s_ap[2 * tid] = (d << 11) | (h << 5) | (rem - h * W); s_ap[2 * tid + 1] = (int)((uint32_t)v >> 31);
+        }
+        if (tid == 0) {
+            int pos = 0;
+            for (int c = 0; c < sd; c++) {
+                s_dp[64 + c] = pos;
+                for (int d = 0; d < D; d++)
+                    if ((d + 1) % sd == c) { s_dp[d] = pos; s_dp[32 + pos] = d; pos++; }
+            }
+            s_dp[64 + sd] = pos;
+            s_cnt[2] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < nap * 125; i += nthr) {
-            const int k = i / 125, o = i - k * 125, dd = o / 25 - 2, dh = (o / 5) % 5 - 2, dw = o % 5 - 2;
-            const int f = s_ap[2 * k], d = f / HW + dd, h = (f / W) % H + dh, w = f % W + dw;
-            if ((unsigned)d < (unsigned)D && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                const int v = (d * H + h) * W + w;
-                atomicOr(&msk[MW + (v >> 5)], 1u << (v & 31));
-                if (abs(dd) <= 1 && abs(dh) <= 1 && abs(dw) <= 1) atomicOr(&msk[v >> 5], 1u << (v & 31));
-                if (o == 62) {                                               // the access point itself
-                    atomicOr(&msk[2 * MW + (v >> 5)], 1u << (v & 31));
-                    if (s_ap[2 * k + 1]) atomicOr(&msk[3 * MW + (v >> 5)], 1u << (v & 31));
+        for (int i = tid; i < nap * 25; i += nthr) {
+            const int k = i / 25, o = i - k * 25, dd = o / 5 - 2, dh = o % 5 - 2;
+            const int f = s_ap[2 * k], d = (f >> 11) + dd, h = ((f >> 5) & 63) + dh, w = f & 31;
+            if ((unsigned)d < (unsigned)D && (unsigned)h < (unsigned)H) {
+                const int row = s_dp[d] * H + h;
+                const int l2 = max(w - 2, 0), h2 = min(w + 2, W - 1);
+                atomicOr(&msk[R + row], ((2u << h2) - 1u) & ~((1u << l2) - 1u));
+                if (abs(dd) <= 1 && abs(dh) <= 1) {
+                    const int l1 = max(w - 1, 0), h1 = min(w + 1, W - 1);
+                    atomicOr(&msk[row], ((2u << h1) - 1u) & ~((1u << l1) - 1u));
+                }
+                if (o == 12) {                                               // the access point itself
+                    atomicOr(&msk[2 * R + row], 1u << w);
+                    if (s_ap[2 * k + 1]) atomicOr(&msk[3 * R + row], 1u << w);
                 }
             }
         }
         __syncthreads();
         if (wv < 2) {                                                        // wave 0: S1, wave 1: S2 — exclusive popcount prefixes
-            const uint32_t* m = msk + wv * MW;
-            int* pr = pre + wv * MW;
-            const int per = (MW + 63) >> 6, base = lane * per;
+            const uint32_t* m = msk + wv * R;
+            int* pr = pre + wv * R;
+            const int per = (R + 63) >> 6, base = lane * per;
             int sum = 0;
-            for (int j = 0; j < per; j++) sum += base + j < MW ? __popc(m[base + j]) : 0;
+            for (int j = 0; j < per; j++) sum += base + j < R ? __popc(m[base + j]) : 0;
             int incl = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
             int run = incl - sum;
             for (int j = 0; j < per; j++)
-                if (base + j < MW) { pr[base + j] = run; run += __popc(m[base + j]); }
+                if (base + j < R) { pr[base + j] = run; run += __popc(m[base + j]); }
             if (lane == 63) s_cnt[wv] = incl;
         }
         __syncthreads();
         const int n1 = s_cnt[0], n2 = s_cnt[1];
-        // lists: S1 (voxel ids + dy) in b's space — free until the background is loaded —, S2 (voxel ids + do) behind the fixed part
+        // lists: S1 (voxel ids + dy) in b's space — free until the scatter —, S2 (voxel ids + dq) behind the fixed part
         const int c1_words = g.tail - nB;
         if ((n1 + 1) / 2 + 7 * n1 > nB || fixed + (n2 + 1) / 2 + 7 * n2 > c1_words) { if (tid == 0) na.flags[e] = 1; return; }
-        uint16_t* vox1 = reinterpret_cast<uint16_t*>(bufB);
+        uint16_t* vox1 = reinterpret_cast<uint16_t*>(bufB);                  // d << 11 | h << 5 | w
         float* dy = bufB + (n1 + 1) / 2;
         uint16_t* vox2 = reinterpret_cast<uint16_t*>(bufC1 + fixed);
         float* dq = bufC1 + fixed + (n2 + 1) / 2;
-        if (tid < 2 * MW) {
-            const int which = tid >= MW, wd = tid - which * MW;
-            uint32_t bits = msk[which * MW + wd];
-            int p = pre[which * MW + wd];
+        for (int t = tid; t < 2 * R; t += nthr) {
+            const int which = t >= R, wd = t - which * R;
+            uint32_t bits = msk[which * R + wd];
+            if (!bits) continue;
+            int p = pre[which * R + wd];
             uint16_t* vx = which ? vox2 : vox1;
-            while (bits) { const int b = __builtin_ctz(bits); vx[p++] = (uint16_t)(wd * 32 + b); bits &= bits - 1; }
+            const int dp = wd / H, dh = (s_dp[32 + dp] << 11) | ((wd - dp * H) << 5);
+            while (bits) { const int b = __builtin_ctz(bits); vx[p++] = (uint16_t)(dh | b); bits &= bits - 1; }
         }
         __syncthreads();
+        XT_LAP(1);
         // ---- dy = relu(b_a + the access points' stamps) - relu(b_a) on S1
         for (int s = tid; s < n1; s += nthr) {
-            const int v = vox1[s], d = v / HW, h = (v / W) % H, w = v % W;
+            const int ev = vox1[s], d = ev >> 11, h = (ev >> 5) & 63, w = ev & 31;
             float acc[7];
 #pragma unroll
             for (int c = 0; c < 7; c++) acc[c] = s_tab[432 + c];
             for (int k = 0; k < nap; k++) {
-                const int f = s_ap[2 * k], kd = f / HW - d + 1, kh = (f / W) % H - h + 1, kw = f % W - w + 1;
+                const int f = s_ap[2 * k], kd = (f >> 11) - d + 1, kh = ((f >> 5) & 63) - h + 1, kw = (f & 31) - w + 1;
                 if ((unsigned)kd < 3u && (unsigned)kh < 3u && (unsigned)kw < 3u) {
                     const int t = ((kd * 3 + kh) * 3 + kw) * 8;
                     const bool adj = s_ap[2 * k + 1] != 0;
@@ -276,76 +301,101 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             for (int c = 0; c < 7; c++) dy[s * 7 + c] = fmaxf(acc[c], 0.f) - fmaxf(s_tab[432 + c], 0.f);
         }
         __syncthreads();
-        // ---- dq = o1 - bg1 on S2: conv_b over the S1 voxels within one voxel, + x at an access point
+        XT_LAP(2);
+        // ---- dq = o1 - bg1 on S2: conv_b over the S1 voxels within one voxel (per neighbouring row: one mask word, a 3-bit window), + x at an access point
+        float dmax = 0.f;
         for (int s = tid; s < n2; s += nthr) {
-            const int v = vox2[s], d = v / HW, h = (v / W) % H, w = v % W;
+            const int ev = vox2[s], d = ev >> 11, h = (ev >> 5) & 63, w = ev & 31, row = s_dp[d] * H + h;
             const int cls = ((((d > 0) | ((d < D - 1) << 1)) << 4) | (((h > 0) | ((h < H - 1) << 1)) << 2) | ((w > 0) | ((w < W - 1) << 1))) * 8;
-            float z[7];
+            xt_f2 z[4];
 #pragma unroll
-            for (int c = 0; c < 7; c++) z[c] = s_tab[440 + cls + c];
+            for (int j = 0; j < 4; j++) z[j] = reinterpret_cast<const xt_f2*>(s_tab + 440 + cls)[j];
 #pragma unroll 1
-            for (int t = 0; t < 27; t++) {
-                const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
-                const int ud = d + kd, uh = h + kh, uw = w + kw;
-                if ((unsigned)ud < (unsigned)D && (unsigned)uh < (unsigned)H && (unsigned)uw < (unsigned)W) {
-                    const int u = v + kd * HW + kh * W + kw;
-                    const uint32_t mw_ = msk[u >> 5];
-                    if ((mw_ >> (u & 31)) & 1u) {
-                        const float* yr = dy + (pre[u >> 5] + __popc(mw_ & ((1u << (u & 31)) - 1u))) * 7;
-                        const float* __restrict__ wk = wt + XN_WB + t * 56;
+            for (int kk = 0; kk < 9; kk++) {
+                const int kd = kk / 3, kh = kk - kd * 3, nd = d + kd - 1, nh = h + kh - 1;
+                if ((unsigned)nd >= (unsigned)D || (unsigned)nh >= (unsigned)H) continue;
+                const int nrow = s_dp[nd] * H + nh;
+                const uint32_t word = msk[nrow];
+                const uint32_t win = (w > 0 ? word >> (w - 1) : word << 1) & 7u;          // bit kw <-> column w + kw - 1
+                if (!win) continue;
+                const int pbase = pre[nrow];
+#pragma unroll 1
+                for (int kw = 0; kw < 3; kw++) {
+                    if (!((win >> kw) & 1u)) continue;
+                    const int uw = w + kw - 1;
+                    const float* yr = dy + (pbase + __popc(word & ((1u << uw) - 1u))) * 7;
+                    const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XN_WB + (kk * 3 + kw) * 56);
 #pragma unroll
-                        for (int ci = 0; ci < 7; ci++) {
-                            const float yv = yr[ci];
+                    for (int ci = 0; ci < 7; ci++) {
+                        const float yv = yr[ci];
 #pragma unroll
-                            for (int c = 0; c < 7; c++) z[c] += wk[ci * 8 + c] * yv;
-                        }
+                        for (int j = 0; j < 4; j++) z[j] += wk[ci * 4 + j] * yv;
                     }
                 }
             }
-            const bool isap = (msk[2 * MW + (v >> 5)] >> (v & 31)) & 1u, isadj = (msk[3 * MW + (v >> 5)] >> (v & 31)) & 1u;
+            const bool isap = (msk[2 * R + row] >> w) & 1u, isadj = (msk[3 * R + row] >> w) & 1u;
 #pragma unroll
             for (int c = 0; c < 7; c++) {
                 const float xv = c == 0 ? (isap ? 1.f : 0.f) : (isadj ? 1.f : 0.f);
-                dq[s * 7 + c] = fmaxf(z[c] + xv, 0.f) - fmaxf(s_tab[440 + cls + c], 0.f);
+                const float q_ = fmaxf(z[c >> 1][c & 1] + xv, 0.f) - fmaxf(s_tab[440 + cls + c], 0.f);
+                dq[s * 7 + c] = q_;
+                dmax = fmaxf(dmax, fabsf(q_));
             }
         }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        if (lane == 0 && dmax > 0.f) atomicMax(&s_cnt[2], __float_as_int(dmax));            // (non-negative floats order like their bit patterns)
         __syncthreads();
-        // ---- P = the background (now that dy is dead) + align1's taps gathered over S2
-        for (int i = tid; i < nB; i += nthr) bufB[i] = na.bg[i];
-        xt_load_wA(wt + XT_C1, lane, wA);                      // (the first matrix stage's operands: in flight under the gather)
+        XT_LAP(3);
+        // ---- the scatter: fixed-point sums of align1's taps in b's space (dy is dead), then P = background + sums
+        int* accB = reinterpret_cast<int*>(bufB);
+        for (int i = tid; i < nB; i += nthr) accB[i] = 0;
+        xt_load_wA(wt + XT_C1, lane, wA);                      // (the first matrix stage's operands: in flight under the scatter)
         __syncthreads();
-        const uint32_t* m2 = msk + MW;
-        const int* pre2 = pre + MW;
-        const int ncell = od * oh * ow;
-        for (int qo = tid; qo < ncell; qo += nthr) {
-            const int hz = qo % oh, wz = (qo / oh) % ow, dz = qo / (ow * oh), i = (dz * oh + hz) * ow + wz;
-            const int d0 = dz * g.sd - 1, h0 = hz * g.sh - 1, w0 = wz * g.sw - 1;
-            float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bool any = false;
+        XT_LAP(11);
+        const float qmax = __int_as_float(s_cnt[2]);
+        const float bound = wt[XN_WSUM] * qmax;
+        const float scale = qmax > 0.f ? 1073741824.f / bound : 0.f;
+        if (qmax > 0.f) {
+            // work units (wave-uniform): the 25 tap rows (kd, kh), dealt round-robin over the waves; a unit runs its 5 taps over every voxel of the
+            // residue class kd belongs to (chunks of 64): the 56 weights of a tap are fetched once per wave and tap (scalar loads), not once per chunk
+            const int* pre2 = pre + R;
+            const int inv_sd = 65536 / sd + 1;
+            for (int u = wv; u < 25; u += nw) {
+                const int kd = u / 5, kh = u - kd * 5, c = kd % sd;
+                const int r0 = s_dp[64 + c] * H, r1 = s_dp[64 + c + 1] * H;
+                const int s_lo = r0 < R ? pre2[r0] : n2, s_hi = r1 < R ? pre2[r1] : n2;
+                if (s_hi <= s_lo) continue;
 #pragma unroll 1
-            for (int t = 0; t < 125; t++) {
-                const int kd = t / 25, kh = (t / 5) % 5, kw = t % 5;
-                const int ud = d0 + kd, uh = h0 + kh, uw = w0 + kw;
-                if ((unsigned)ud < (unsigned)D && (unsigned)uh < (unsigned)H && (unsigned)uw < (unsigned)W) {
-                    const int u = (ud * H + uh) * W + uw;
-                    const uint32_t mw_ = m2[u >> 5];
-                    if ((mw_ >> (u & 31)) & 1u) {
-                        const float* qr = dq + (pre2[u >> 5] + __popc(mw_ & ((1u << (u & 31)) - 1u))) * 7;
-                        const float* __restrict__ wk = wt + XN_WL + t * 56;
-                        any = true;
+                for (int kw = 0; kw < 5; kw++) {
+                    const xt_f2* __restrict__ wk = reinterpret_cast<const xt_f2*>(wt + XN_WL + ((kd * 5 + kh) * 5 + kw) * 56);
+                    xt_f2 wr[28];
+#pragma unroll
+                    for (int i = 0; i < 28; i++) wr[i] = wk[i];
+                    for (int s = s_lo + lane; s < s_hi; s += 64) {
+                        const int ev = vox2[s], d = ev >> 11, h = (ev >> 5) & 63, w = ev & 31;
+                        const int th = h + 1 - kh, td = d + 1 - kd, tw = w + 1 - kw;           // (td: a multiple of sd — that is what the class is; sh = sw = 1: the launcher's condition)
+                        const int dz = (td * inv_sd) >> 16;                                     // td / sd without the division (td < 64)
+                        if ((unsigned)th >= (unsigned)oh || td < 0 || dz >= od || (unsigned)tw >= (unsigned)ow) continue;
+                        const float* qr = dq + s * 7;
+                        xt_f2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                         for (int ci = 0; ci < 7; ci++) {
                             const float qv = qr[ci];
 #pragma unroll
-                            for (int c = 0; c < 7; c++) acc[c] += wk[ci * 8 + c] * qv;
+                            for (int j = 0; j < 4; j++) acc[j] += wr[ci * 4 + j] * qv;
                         }
+                        int* o = accB + ((dz * oh + th) * ow + tw) * 7;
+#pragma unroll
+                        for (int co = 0; co < 7; co++) atomicAdd(o + co, __float2int_rn(acc[co >> 1][co & 1] * scale));
                     }
                 }
             }
-            if (any) {
-#pragma unroll
-                for (int c = 0; c < 7; c++) bufB[i * 7 + c] += acc[c];
-            }
+        }
+        __syncthreads();
+        {
+            const float inv = qmax > 0.f ? bound * (1.f / 1073741824.f) : 0.f;
+            for (int i = tid; i < nB; i += nthr) bufB[i] = na.bg[i] + (float)accB[i] * inv;
         }
         __syncthreads();
     } else {
@@ -623,6 +673,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         out[(int64_t)e * 64 + 8] = (float)(xt_lap[9] - xt_lap[8]);          //               wave 0's own tiles
         out[(int64_t)e * 64 + 9] = (float)(xt_lap[10] - xt_lap[9]);         //               the next convolution's operands arrive
         out[(int64_t)e * 64 + 10] = (float)(xt_lap[5] - xt_lap[10]);        //               waiting for the other waves
+        if (NET) { out[(int64_t)e * 64 + 11] = (float)(xt_lap[11] - xt_lap[3]); out[(int64_t)e * 64 + 12] = (float)(xt_lap[4] - xt_lap[11]); }      // background load / gather
     }
 #endif
 }
@@ -822,8 +873,8 @@ hipError_t xr_launch_net_tower(const void* regions, const int32_t* net_csr, cons
     if (g.od > 3 || g.oh + 3 > 64 || g.ow + 3 > 64 || (int64_t)D * H * W >= 65536) { *status = XR_ERR_RANGE; return hipSuccess; }
     g.cols = g.ow + 2;
     const int64_t nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
-    const int64_t fixed = 6 * (((int64_t)D * H * W + 31) / 32) + 256 + 8 + 952;
-    if (nB < 1024 * 3 || nC1 < fixed + 1024) { *status = XR_ERR_RANGE; return hipSuccess; }
+    const int64_t fixed = 6 * ((int64_t)D * H) + 256 + 8 + 112 + 952;      // (the NET front end's fixed LDS part: one mask word per (d, h) row)
+    if (nB < 1024 * 3 || nC1 < fixed + 1024 || W > 32 || D > 32 || H > 64 || g.sh != 1 || g.sw != 1) { *status = XR_ERR_RANGE; return hipSuccess; }      // (packed coordinates 5 + 6 + 5 bits)
     g.y_in_b = 1; g.strip = 3; g.vec_load = 0;
     g.tail = (int)(nB + nC1);
     const size_t lds = (size_t)(nB + nC1 + 8 + 16 * (g.cols + 2) * 3) * sizeof(float);
