@@ -18,6 +18,7 @@ prof() {   # name, bench args...: kernel stats + PMC traffic of one command
     python3 $R/tools/pmc_parse.py $(ls $OUT/${name}pmcF/*/*counter_collection.csv $OUT/${name}pmcF/*counter_collection.csv 2>/dev/null | head -1) \
             $(ls $OUT/${name}pmcW/*/*counter_collection.csv $OUT/${name}pmcW/*counter_collection.csv 2>/dev/null | head -1) $OUT/${name}pmcF.log > $OUT/${name}pmc_traffic.json 2>> $OUT/pmc_parse.err
     head -c 500 $OUT/${name}pmc_traffic.json; echo
+    rm -rf $OUT/${name}trace $OUT/${name}pmcF $OUT/${name}pmcW          # (databases of tens of MB each: gpurun_out/ only travels back under 64 MiB)
 }
 prof ""
 prof pack_ --region-pack $R/tests/golden/ispd18_test1_regions.npz
@@ -26,7 +27,8 @@ prof packv2_ --region-pack $R/tests/golden/ispd18_test1_regions.npz --maze-v2
 for A in dqn ppo; do
     timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/agent_${A}_trace -o t -- python3 $R/bench.py --agent $A --envs 4096 --steps 20 --warmup 3 > $OUT/agent_${A}_4096.json 2> $OUT/agent_${A}_trace.log
     python3 $R/tools/rocpd_summary.py $OUT/agent_${A}_trace > $OUT/agent_${A}_4096_kernel_stats.csv 2>> $OUT/kernel_stats.err
-    echo "agent $A: convolution-library kernels in the trace: $(grep -ci -E 'miopen|igemm|batched_transpose|Cijk|naive_conv' $OUT/agent_${A}_4096_kernel_stats.csv)"
+    rm -rf $OUT/agent_${A}_trace
+    echo "agent $A: convolution-library kernels in the trace: $(grep -ci -E 'miopen|igemm|batched_transpose|naive_conv' $OUT/agent_${A}_4096_kernel_stats.csv)" | tee -a $OUT/agent_no_conv_library.txt
 done
 cd $R; unset XR_BENCH_NO_FORK
 timeout 300 python bench.py --agent dqn --envs 1024 --steps 20 --warmup 3 > $OUT/agent_dqn_1024.json 2>/dev/null
@@ -81,4 +83,4 @@ timeout 600 make -C xroute_env_amd/csrc ttiming > /dev/null 2>&1
 XR_LIB=libxroute_hip_ttiming.so XT_PHASES=1 timeout 300 python tools/net_tower_probe.py 1024 2>&1 | grep -v amdgpu > $OUT/net_tower_phases.txt; cat $OUT/net_tower_phases.txt
 XR_TOWER_LIBS=libxroute_hip_ttiming.so XT_PHASES=1 timeout 300 python tools/tower_probe.py 1024 9 40 24 2>&1 | grep -v amdgpu > $OUT/tower_phases.txt; tail -14 $OUT/tower_phases.txt
 timeout 900 python tools/soak.py 2>&1 | grep -v amdgpu | tail -8 > $OUT/parity_soak.txt; cat $OUT/parity_soak.txt
-ls $OUT | head -80
+rm -rf $R/gpurun_out/${TAG}_sq $R/gpurun_out/${TAG}_c5 2>/dev/null; du -sh $R/gpurun_out; ls $OUT | head -80

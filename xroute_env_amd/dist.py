@@ -313,6 +313,10 @@ class CompactStateExchange:
         if to_all:
             return gather_rows(self.rows_local, group=self.group)
         on_learner = self.rank == self.learner_rank
+        if self.rows_local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # (gloo has no `gather` for device tensors — the two-ranks-on-one-GPU functional tests run on it: its all_gather, the learner keeps the rows)
+            rows = gather_rows(self.rows_local, group=self.group)
+            return rows if on_learner else None
         if self.equal:
             # (chunks of a contiguous [n_total, rb] tensor are contiguous views: the learner receives straight into global env order)
             dist.gather(self.rows_local, gather_list=list(self.rows_all.chunk(self.world)) if on_learner else None, dst=self.learner_rank, group=self.group)
