@@ -36,6 +36,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# this process mixes two OpenMP users — the oracle (checker / cpu_baseline legs, all host cores) and the framework's CPU operators (the agents' weight
+# snapshots are packed by a few small CPU convolutions): idle OpenMP threads must sleep, not spin, or each side's parallel regions start among the other's
+# spinning threads (measured: a 8 ms pack took ~100 ms right after an oracle replay).  Before any OpenMP runtime is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 256 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / v_pk_fma_f32, 256 FLOP per clock and CU

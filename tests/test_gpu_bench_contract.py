@@ -64,6 +64,21 @@ def test_bench_json_contract(extra):
         assert c4["policy_per_rank"]["value"] > 0 and c4["central_learner_from_compact_state"]["value"] > 0, c4
         assert c4["policy_per_rank"]["parity_ok"] and c4["central_learner_from_compact_state"]["parity_ok"] and c4["same_actions_in_both_placements"]
         assert c4["central_learner_from_compact_state"]["compact_state"]["ratio_to_fp32_planes"] < 0.02
+        # round 6: BASELINE config 1 as SURVEY 8d states it (one host thread: oracle + the real Request through the codec), config 2 (ingest + reward +
+        # observation of 256 envs, no route), config 5's launch utilisation, the PPO counterpart at the reference's training cadence — and ALL legs
+        # once more, compact, as the LAST key of the line (the driver keeps the tail of it)
+        w1 = ex["config1_wire_loopback"]
+        assert w1["cores"] == 1 and w1["ms_per_step"] > 0 and w1["request_bytes_mean"] > 100000 and set(w1["ms_per_component"]) >= {"sim_route", "encode_request", "decode_request", "build_3Dgrid"}
+        c2 = [k for k in d["kernels"] if "BASELINE config 2" in k["kernel"]][0]
+        assert c2["envs"] == 256 and c2["parity"]["ok"] is True and c2["parity"]["rewards_bit_equal"] is True and c2["ingest_ms"] > 0 and c2["observation_ms"] > 0
+        c5 = [k for k in d["kernels"] if "config 5" in k["kernel"]][0]
+        assert 0 < c5["launch_utilisation"]["utilisation"] <= 1 and "LATENCY CHAIN" in c5["note"]
+        tc = ex["ppo_training_cadence"]
+        assert tc["update_every_steps"] == 100 and tc["refill_ms"] > 0 and tc["window_ms"] > tc["refill_ms"] and tc["net_vectors_by"]["framework_convolutions"] == 0
+        assert list(d.keys())[-1] == "legs" and len(json.dumps(d["legs"])) <= 1600
+        lg = d["legs"]
+        assert lg["step"]["ok"] is True and lg["c2_obs_reward_256"]["ok"] is True and lg["c5_route_1024"]["ok"] is True and "c1_wire_loopback_cpu" in lg and "ppo_cadence_100" in lg
+        assert d["config"]["parity_ok"] is True and d["roofline"]["parity_ok"] is True
         # ~1 s of the same step after the timed region (clocks / thermals visible); never part of `value`
         su = ex["sustained"]
         assert su["steps"] == 500 and su["value"] > 0 and len(su["ms_per_step_by_100"]) == 5 and min(su["ms_per_step_by_100"]) > 0
