@@ -828,7 +828,8 @@ def bench_args_key(args, world):
 
 
 def config1_wire_leg(seconds=4.0):
-    """BASELINE config 1 as SURVEY §8d states it — "B = 1, 24x40x9, K = 10: CPU oracle only, single thread (+ proto encode/decode loopback)" — the
+    """A `cpu_baseline` leg (kind "port": the oracle is the thing timed here, as in `cpu_baseline`, never the product).
+    BASELINE config 1 as SURVEY §8d states it — "B = 1, 24x40x9, K = 10: CPU oracle only, single thread (+ proto encode/decode loopback)" — the
     reference's own plumbing (examples/launch_training.py:57-86 starts ONE simulator; every step is a ZMQ round trip of the whole region,
     baseline/baseline_utils.py:409-423) restated on the host cores of this box, one thread, no GPU anywhere:
 
@@ -882,7 +883,7 @@ def config1_wire_leg(seconds=4.0):
             assert len(data[1]) == reg.n_nodes and obs.size == (2 + 7 * len(legal)) * reg.n_nodes
     per = {k: round(v / n_steps * 1e3, 4) for k, v in comp.items()}
     total = sum(comp.values()) / n_steps
-    return {"ms_per_step": round(total * 1e3, 4), "value": round(1.0 / total, 2), "unit": "env-steps/s", "cores": 1, "steps": n_steps,
+    return {"ms_per_step": round(total * 1e3, 4), "value": round(1.0 / total, 2), "unit": "env-steps/s", "cores": 1, "kind": "port", "steps": n_steps,
             "request_bytes_mean": int(n_bytes / n_steps), "ms_per_component": per,
             "what": "BASELINE config 1 (SURVEY 8d): one ispd18_test1-sized region (24x40x9, K = 10), ONE thread of this box's host: oracle route + the real ~200 KB "
                     "Request encoded and decoded through the C-ABI codec + handle_messange's data lists + the oracle's build_3Dgrid + the Response, loopback "
