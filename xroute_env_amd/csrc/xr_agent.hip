@@ -403,7 +403,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                         }
                         int* o = accB + ((dz * oh + th) * ow + tw) * 7;
 #pragma unroll
+#ifdef XN_PLAIN_RMW      /* timing experiment only (racy): what the scatter costs without the atomics */
+                        for (int co = 0; co < 7; co++) o[co] += __float2int_rn(acc[co >> 1][co & 1] * scale);
+#else
                         for (int co = 0; co < 7; co++) atomicAdd(o + co, __float2int_rn(acc[co >> 1][co & 1] * scale));
+#endif
                     }
                 }
             }
