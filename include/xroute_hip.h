@@ -426,6 +426,10 @@ int32_t xr_agent_actor_sample(const float* state_dev, const float* head_dev, int
  *                 framework path takes that net), 2 = the pair names a region of another shape or a net it does not have; such rows of out_dev stay unwritten
  * XR_ERR_RANGE for grid shapes the kernel does not take. */
 int32_t xr_agent_net_tower_weights(void);
+/* How the towers' 7 -> 7-channel convolutions run (both kernels): 1 (default) = split-bf16 operands on v_mfma_f32_16x16x32_bf16 — every fp32 weight and activation held
+ * as hi = bf16(v), lo = bf16(v - hi), a product as hi x hi + hi x lo + lo x hi accumulated in fp32 (normalised vectors within 1.1e-5 of the fp32 form on the reference
+ * fixtures); 0 = fp32 operands on v_mfma_f32_16x16x4_f32 (environment XR_TOWER_FP32=1 before the first call).  Both weight layouts travel in the packed vectors. */
+int32_t xr_agent_matrix_mode(void);
 int32_t xr_batch_net_vectors(xr_batch* b, const int32_t* pair_region_dev, const int32_t* pair_net_dev, int32_t n_pairs, int32_t D, int32_t H, int32_t W,
                              const float* weights_dev, const float* bg_dev, float* out_dev, int32_t* flags_dev, int32_t normalize, void* stream);
 

@@ -105,7 +105,7 @@ def test_integration_md_stub_is_generated_from_the_binding():
     assert block == gen.stub_text().strip(), "run `python tools/gen_integration_stub.py`"
     from xroute_env_amd import _lib
     L = _lib.lib()
-    no_args = {"xr_abi_version", "xr_last_error", "xr_agent_obstacle_tower_weights", "xr_agent_actor_weights", "xr_agent_net_tower_weights"}
+    no_args = {"xr_abi_version", "xr_last_error", "xr_agent_obstacle_tower_weights", "xr_agent_actor_weights", "xr_agent_net_tower_weights", "xr_agent_matrix_mode"}
     assert all(getattr(L, n).argtypes for n in _lib.SYMBOLS if n not in no_args), "every exported symbol is bound with its argument types"
     # ... and the header declares exactly the symbols the binding lists
     import re

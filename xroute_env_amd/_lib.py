@@ -29,7 +29,7 @@ SYMBOLS = [
     "xr_batch_create", "xr_batch_destroy", "xr_batch_load_regions", "xr_batch_assign", "xr_batch_sizes",
     "xr_batch_reset", "xr_batch_step", "xr_batch_step_observe", "xr_batch_step_observe_inplace", "xr_batch_step_compact", "xr_batch_net_planes", "xr_batch_route_order", "xr_batch_observe_timing", "xr_batch_route_occupancy", "xr_batch_random_actions", "xr_batch_observation", "xr_batch_fetch", "xr_batch_store", "xr_batch_load_guides",
     "xr_batch_state_row_bytes", "xr_batch_pack_state", "xr_batch_expand_state", "xr_batch_ingest_state",
-    "xr_agent_obstacle_tower_weights", "xr_agent_obstacle_tower", "xr_agent_net_tower_weights", "xr_batch_net_vectors", "xr_agent_actor_weights", "xr_agent_actor", "xr_agent_actor_sample",
+    "xr_agent_obstacle_tower_weights", "xr_agent_obstacle_tower", "xr_agent_net_tower_weights", "xr_agent_matrix_mode", "xr_batch_net_vectors", "xr_agent_actor_weights", "xr_agent_actor", "xr_agent_actor_sample",
     "xr_observation_from_records", "xr_proto_decode", "xr_proto_encode_response", "xr_proto_encode_request",
 ]
 
@@ -116,6 +116,7 @@ def lib():
     L.xr_agent_obstacle_tower_weights.argtypes = []
     L.xr_agent_obstacle_tower.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp]
     L.xr_agent_net_tower_weights.argtypes = []
+    L.xr_agent_matrix_mode.argtypes = []
     L.xr_batch_net_vectors.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
     L.xr_agent_actor_weights.argtypes = []
     L.xr_agent_actor.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp]

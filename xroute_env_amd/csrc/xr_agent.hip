@@ -50,7 +50,9 @@ constexpr int XT_C1 = XT_AL1 + 1008;        // 16*64*4 + 8 block(7).conv1 as the
 constexpr int XT_C2 = XT_C1 + 4104;         // same       block(7).conv2
 constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padded to 8][kw]: the 12 weights a lane of the last stage needs are neighbours
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
-constexpr int XT_TOTAL = XT_KV + 64;
+constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3): [(kd, kh)][hi / lo][lane][4 words]
+constexpr int XT_C2B = XT_C1B + 4608;       // same       block(7).conv2
+constexpr int XT_TOTAL = XT_C2B + 4608;
 // the NET tower (same 7-channel block + last convolution, its own weights in the XT_C1 .. XT_KV slots; XT_A1 .. XT_AL1 unused) has a sparse front end
 // behind them (agents.FusedNetTower.pack):
 constexpr int XN_A0 = XT_TOTAL;             // 27*8      block(7).conv1, input plane 0 (the access-point mask): [tap][co padded to 8]
@@ -86,6 +88,51 @@ __device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lan
         const xt_f4 v = src[s4 * 64];
         wA[s4 * 4 + 0] = v[0]; wA[s4 * 4 + 1] = v[1]; wA[s4 * 4 + 2] = v[2]; wA[s4 * 4 + 3] = v[3];
     }
+}
+
+// ---- matrix mode 1 (round 6): the 7 -> 7-channel convolutions on v_mfma_f32_16x16x32_bf16 with SPLIT operands — every fp32 value v is held as two bf16,
+// hi = bf16(v) and lo = bf16(v - hi) (v - hi - lo <= 2^-17 |v|), and a product is three instructions, hi x hi + hi x lo + lo x hi, accumulated in fp32 (the dropped
+// lo x lo term is <= 2^-16 of the product).  One instruction takes K = 32 = the four input columns x eight channel slots of one (kd, kh) tap row — what the fp32
+// form (K = 4) needs seven instructions for, at 32 cycles each against ~17 — so a tap row costs 3 x 17 instead of 7 x 32 cycles of the matrix pipe.  Lane l holds, for
+// BOTH operands, the k-values of its quarter q = l >> 4 in the same order, so the sum over k does not care how the hardware numbers them; C / D are laid out like
+// the fp32 form's: the epilogues are shared.  Activations live in LDS as ONE word per value, hi << 16 | lo (same footprint as fp32): a lane reads its cell's seven
+// channel words as before and two byte permutes per word pair make the hi and the lo fragment.  Measured against the fp32 form on the reference fixtures (CPU
+// emulation first, tests/test_agents.py): normalised vectors within 1.1e-5 — the noise of a different fp32 summation order is 2e-6 … 5e-6.
+typedef __bf16 xt_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int xt_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t xt_bf16_rne(float x) {           // the bf16 nearest to x (ties to even), in the UPPER half of the word; finite x only
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__device__ __forceinline__ float xt_pack(float x) {                  // hi << 16 | lo as the bits of a float (what the LDS arrays are declared as)
+    const uint32_t hi = xt_bf16_rne(x);
+    const uint32_t lo = xt_bf16_rne(x - __uint_as_float(hi)) >> 16;
+    return __uint_as_float(hi | lo);
+}
+__device__ __forceinline__ float xt_unpack(float w) {
+    const uint32_t u = __float_as_uint(w);
+    return __uint_as_float(u & 0xFFFF0000u) + __uint_as_float(u << 16);
+}
+template <int MM> __device__ __forceinline__ float xt_act(float x) { return MM ? xt_pack(x) : x; }          // an activation as the matrix stages' LDS arrays hold it
+
+// A fragments of one convolution: 9 tap rows x (hi, lo) x 4 words per lane, packed by the caller (agents._mfma_operand_bf16)
+__device__ __forceinline__ void xt_load_wAb(const float* __restrict__ wc, int lane, xt_u4 (&ah)[9], xt_u4 (&al)[9]) {
+    const xt_u4* __restrict__ src = reinterpret_cast<const xt_u4*>(wc) + lane;
+#pragma unroll
+    for (int s = 0; s < 9; s++) { ah[s] = src[(2 * s) * 64]; al[s] = src[(2 * s + 1) * 64]; }
+}
+
+// one tap row: acc += A(kd, kh) . B, B = the seven channel words of the lane's cell at xt_smem[a .. a + 6] (+ a zero eighth slot)
+__device__ __forceinline__ xt_f4 xt_mm3(const xt_u4 ah, const xt_u4 al, const float* __restrict__ cell, xt_f4 acc) {
+    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(cell);
+    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6];
+    const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), w6 >> 16};
+    const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), w6 & 0xFFFFu};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
+    return acc;
 }
 
 // One 3x3x3 convolution of the 1-channel block on zero-padded grids [D + 2][H + 2][Wp] (Wp = W + 2 rounded up to an ODD number of words): a thread
@@ -152,7 +199,7 @@ __device__ __forceinline__ bool xt_tile_item(int k, int wv, int nw, int T, int* 
 #define XT_LAP(k) do { } while (0)
 #endif
 
-template <int BT, bool NET>
+template <int BT, bool NET, int MM>
 __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict__ head, int64_t stride, int n_envs, XtDims g,
                                                           const float* __restrict__ wt, float* __restrict__ out, int normalize, XnArgs na) {
     extern __shared__ __attribute__((aligned(16))) float xt_smem[];
@@ -185,7 +232,12 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     float* red = xt_smem + g.tail + 8;                // [nthr / 64][cols + 2][3]: every wave's column sums of the last stage
     for (int i = tid; i < 8 + (nthr >> 6) * (g.cols + 2) * 3; i += nthr) xt_smem[g.tail + i] = 0.f;
 
-    float wA[64];
+    float wA[MM ? 1 : 64];                               // matrix mode 0: the fp32 A operands of a convolution; mode 1: its bf16 fragments
+    xt_u4 wAh[MM ? 9 : 1], wAl[MM ? 9 : 1];
+    auto load_w = [&](int off_f32, int off_bf16) {
+        if constexpr (MM) xt_load_wAb(wt + off_bf16, lane, wAh, wAl);
+        else xt_load_wA(wt + off_f32, lane, wA);
+    };
     if constexpr (NET) {
         // ==== the net tower's SPARSE front end: P = align1(block(x)) of a net's 7 planes without ever forming them (agents.FusedNetTower) ====
         // x is 1 at the net's access points (plane 0; planes 1..6: the aliased "has a same-net axis neighbour" flag) and 0 elsewhere.  With S1 / S2 =
@@ -366,7 +418,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         // ---- the scatter: fixed-point sums of align1's taps in b's space (dy is dead), then P = background + sums
         int* accB = reinterpret_cast<int*>(bufB);
         for (int i = tid; i < nB; i += nthr) accB[i] = 0;
-        xt_load_wA(wt + XT_C1, lane, wA);                      // (the first matrix stage's operands: in flight under the scatter)
+        load_w(XT_C1, XT_C1B);                                 // (the first matrix stage's operands: in flight under the scatter)
         __syncthreads();
         XT_LAP(11);
         const float qmax = __int_as_float(s_cnt[2]);
@@ -415,7 +467,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         __syncthreads();
         {
             const float inv = qmax > 0.f ? bound * (1.f / 1073741824.f) : 0.f;
-            for (int i = tid; i < nB; i += nthr) bufB[i] = na.bg[i] + (float)accB[i] * inv;
+            for (int i = tid; i < nB; i += nthr) bufB[i] = xt_act<MM>(na.bg[i] + (float)accB[i] * inv);
         }
         __syncthreads();
     } else {
@@ -448,7 +500,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     XT_LAP(3);
     // the A operand of the 7-channel block's first convolution: 16 loads per lane, issued here so that the aligning convolution hides them
     // (it fetches nothing through the vector memory path; earlier, the 64 registers would squeeze the 1-channel stages)
-    xt_load_wA(wt + XT_C1, lane, wA);
+    load_w(XT_C1, XT_C1B);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
     // (consecutive lanes take consecutive ROWS of one column: their reads are an odd pitch apart.  Measured and dropped: a work item of HALF a cell —
@@ -475,7 +527,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int co = 0; co < 7; co++) bufB[i * 7 + co] = acc[co >> 1][co & 1];
+        for (int co = 0; co < 7; co++) bufB[i * 7 + co] = xt_act<MM>(acc[co >> 1][co & 1]);
     }
     __syncthreads();
     }       // (!NET)
@@ -499,7 +551,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         const int h = r2 < 0 ? oh + 1 + r / we1 : r2 >> 1, w = r2 < 0 ? r % we1 : ow + 1 + (r2 & 1);
         float* o = bufC1 + ((d * he1 + h) * we1 + w) * 7;
 #pragma unroll
-        for (int co = 0; co < 7; co++) o[co] = fmaxf(wt[XT_C1 + 4096 + co], 0.f);
+        for (int co = 0; co < 7; co++) o[co] = xt_act<MM>(fmaxf(wt[XT_C1 + 4096 + co], 0.f));
     }
     const int cbase = (int)(bufC1 - xt_smem);
 #ifdef XT_PHASE_TIMING
@@ -549,15 +601,19 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                     for (int kh = 0; kh < 3; kh++) {
                         const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
+                        if constexpr (MM) {
+                            acc = xt_mm3(wAh[kd * 3 + kh], wAl[kd * 3 + kh], xt_smem + a, acc);
+                        } else {
 #pragma unroll
-                        for (int ci = 0; ci < 7; ci++)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
+                            for (int ci = 0; ci < 7; ci++)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
+                        }
                     }
                 }
                 if (st) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = fmaxf(acc[i], 0.f);
+                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = xt_act<MM>(fmaxf(acc[i], 0.f));
                 }
 #pragma unroll
                 for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
@@ -568,7 +624,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     const unsigned long long xt_w1 = __builtin_readcyclecounter();
 #endif
     XT_LAP(9);
-    xt_load_wA(wt + XT_C2, lane, wA);                 // (before the barrier: a wave that is done fetches while the others finish)
+    load_w(XT_C2, XT_C2B);                            // (before the barrier: a wave that is done fetches while the others finish)
 #ifdef XT_PHASE_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XT_LAP(10);
@@ -617,7 +673,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                 const float* __restrict__ pb = (inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
                 float pv[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? pb[i] : 0.f;
+                for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? (MM ? xt_unpack(pb[i]) : pb[i]) : 0.f;
                 xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
                 for (int kd = 0; kd < 3; kd++) {
@@ -626,9 +682,13 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                     for (int kh = 0; kh < 3; kh++) {
                         const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
+                        if constexpr (MM) {
+                            acc = xt_mm3(wAh[kd * 3 + kh], wAl[kd * 3 + kh], xt_smem + a, acc);
+                        } else {
 #pragma unroll
-                        for (int ci = 0; ci < 7; ci++)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
+                            for (int ci = 0; ci < 7; ci++)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
+                        }
                     }
                 }
                 if (ov) {
@@ -823,9 +883,19 @@ __global__ void __launch_bounds__(128) xr_actor_kernel(const float* __restrict__
     if (j == 0) action[e] = besta;
 }
 
+// matrix mode of the towers' 7 -> 7-channel convolutions: 1 (default) = split-bf16 operands on v_mfma_f32_16x16x32_bf16 (three instructions per product, fp32
+// accumulation: see xt_mm3), 0 = fp32 operands on v_mfma_f32_16x16x4_f32 (XR_TOWER_FP32=1: the exact-fp32 form of rounds 4-5, kept for A/B and as the reference
+// of the split form's tolerance tests)
+static int xt_matrix_mode() {
+    static const int mm = [] { const char* v = getenv("XR_TOWER_FP32"); return (v && v[0] == '1') ? 0 : 1; }();
+    return mm;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t xr_agent_matrix_mode(void) { return xt_matrix_mode(); }
 
 int32_t xr_agent_obstacle_tower_weights(void) { return XT_TOTAL; }
 
@@ -861,15 +931,23 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     g.tail = (int)(nB + c1_alloc);
     const size_t lds = (size_t)(nB + c1_alloc + 8 + (threads / 64) * (g.cols + 2) * 3) * sizeof(float);
     if (lds > 160 * 1024) return XR_ERR_RANGE;
-    const void* fn = threads == 1024 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, false>)
-                   : threads == 256 ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<256, false>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<512, false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const XnArgs none{};
-    if (threads == 1024) hipLaunchKernelGGL((xr_ob_tower_kernel<1024, false>), dim3(n_envs), dim3(1024), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
-    else if (threads == 256) hipLaunchKernelGGL((xr_ob_tower_kernel<256, false>), dim3(n_envs), dim3(256), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
-    else hipLaunchKernelGGL((xr_ob_tower_kernel<512, false>), dim3(n_envs), dim3(512), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none);
-    return hipGetLastError() == hipSuccess ? XR_OK : XR_ERR_HIP;
+    const int mm = xt_matrix_mode();
+    hipError_t e = hipSuccess;
+#define XT_LAUNCH(BT, MM)                                                                                                                                   \
+    do {                                                                                                                                                    \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xr_ob_tower_kernel<BT, false, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        if (e == hipSuccess) {                                                                                                                              \
+            hipLaunchKernelGGL((xr_ob_tower_kernel<BT, false, MM>), dim3(n_envs), dim3(BT), lds, st, head_dev, head_stride, n_envs, g, weights_dev, out_dev, normalize, none); \
+            e = hipGetLastError();                                                                                                                          \
+        }                                                                                                                                                   \
+    } while (0)
+    if (threads == 1024) { if (mm) XT_LAUNCH(1024, 1); else XT_LAUNCH(1024, 0); }
+    else if (threads == 512) { if (mm) XT_LAUNCH(512, 1); else XT_LAUNCH(512, 0); }
+    else { if (mm) XT_LAUNCH(256, 1); else XT_LAUNCH(256, 0); }
+#undef XT_LAUNCH
+    return e == hipSuccess ? XR_OK : XR_ERR_HIP;
 }
 
 int32_t xr_agent_net_tower_weights(void) { return XN_TOTAL; }
@@ -899,13 +977,15 @@ hipError_t xr_launch_net_tower(const void* regions, const int32_t* net_csr, cons
     g.tail = (int)(nB + nC1);
     const size_t lds = (size_t)(nB + nC1 + 8 + 16 * (g.cols + 2) * 3) * sizeof(float);
     if (lds > 160 * 1024) { *status = XR_ERR_RANGE; return hipSuccess; }
-    const void* fn = reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, true>);
+    const int mm = xt_matrix_mode();
+    const void* fn = mm ? reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, true, 1>) : reinterpret_cast<const void*>(&xr_ob_tower_kernel<1024, true, 0>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     XnArgs na;
     na.regions = static_cast<const XrRegionDev*>(regions); na.net_csr = net_csr; na.ap_feat = ap_feat; na.pair_region = pair_region_dev; na.pair_net = pair_net_dev;
     na.bg = bg_dev; na.flags = flags_dev; na.n_regions = n_regions;
-    hipLaunchKernelGGL((xr_ob_tower_kernel<1024, true>), dim3(n_pairs), dim3(1024), lds, st, static_cast<const float*>(nullptr), (int64_t)0, n_pairs, g, weights_dev, out_dev, normalize, na);
+    if (mm) hipLaunchKernelGGL((xr_ob_tower_kernel<1024, true, 1>), dim3(n_pairs), dim3(1024), lds, st, static_cast<const float*>(nullptr), (int64_t)0, n_pairs, g, weights_dev, out_dev, normalize, na);
+    else hipLaunchKernelGGL((xr_ob_tower_kernel<1024, true, 0>), dim3(n_pairs), dim3(1024), lds, st, static_cast<const float*>(nullptr), (int64_t)0, n_pairs, g, weights_dev, out_dev, normalize, na);
     return hipGetLastError();
 }
 
