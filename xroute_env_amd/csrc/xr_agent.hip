@@ -52,7 +52,8 @@ constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padd
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3): [(kd, kh)][hi / lo][lane][4 words]
 constexpr int XT_C2B = XT_C1B + 4608;       // same       block(7).conv2
-constexpr int XT_TOTAL = XT_C2B + 4608;
+constexpr int XT_AL1B = XT_C2B + 4608;      // 10*2*64*4  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [(kd, kh group)][hi / lo][lane][4 words]
+constexpr int XT_TOTAL = XT_AL1B + 5120;
 // the NET tower (same 7-channel block + last convolution, its own weights in the XT_C1 .. XT_KV slots; XT_A1 .. XT_AL1 unused) has a sparse front end
 // behind them (agents.FusedNetTower.pack):
 constexpr int XN_A0 = XT_TOTAL;             // 27*8      block(7).conv1, input plane 0 (the access-point mask): [tap][co padded to 8]
@@ -142,7 +143,7 @@ __device__ __forceinline__ xt_f4 xt_mm3(const xt_u4 ah, const xt_u4 al, const fl
 // LDS cycles, profiles/r04_pt_tower_sq_counters.txt.)  Every cell's sum runs in the order (kd, kh, kw).  RES: out is the INPUT of the block (x) and
 // holds x at the cell: out = relu(conv + x), in place.  (A strip may hang over the end of its row: those reads hit the next row or the floats behind
 // the grid — inside the allocation — and feed only sums that are dropped.)
-template <int S, bool RES>
+template <int S, bool RES, bool PACK = false>      // PACK: the result is stored as hi << 16 | lo (matrix mode 1: the aligning convolution reads it as bf16 fragments)
 __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, const float* in, float* out, int D, int H, int W, int tid, int nthr) {
     const int Hp = H + 2, Wp = (W + 2) | 1, rows = D * H, nstrip = rows * ((W + S - 1) / S);
     float wk[27];
@@ -173,7 +174,7 @@ __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, c
         float* o = out + pi + (Hp + 1) * Wp + 1;
 #pragma unroll
         for (int j = 0; j < S; j++)
-            if (w0 + j < W) o[j] = fmaxf(RES ? acc[j] + o[j] : acc[j], 0.f);
+            if (w0 + j < W) { const float v_ = fmaxf(RES ? acc[j] + o[j] : acc[j], 0.f); o[j] = PACK ? xt_pack(v_) : v_; }
     }
 }
 
@@ -472,7 +473,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         __syncthreads();
     } else {
     const float* __restrict__ src = head + (int64_t)e * stride;
-    for (int i = tid; i < Np; i += nthr) { xpad[i] = 0.f; ypad[i] = 0.f; }
+    for (int i = tid; i < Np + 8; i += nthr) { xpad[i] = 0.f; if (i < Np) ypad[i] = 0.f; }      // (+ 8 zero words behind x: the matrix form of align1 reads one word past a row)
     __syncthreads();
     if (g.vec_load) {
         for (int i4 = tid; i4 < (N >> 2); i4 += nthr) {
@@ -494,8 +495,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     else xt_conv1_strips<3, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(2);
-    if (g.strip == 5) xt_conv1_strips<5, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
-    else xt_conv1_strips<3, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    const bool al1_mm = MM && g.sh == 1 && g.sw == 1;      // align1 on the matrix pipe too (matrix mode 1, unit strides in h and w)
+    if (al1_mm) {
+        if (g.strip == 5) xt_conv1_strips<5, true, MM != 0>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+        else xt_conv1_strips<3, true, MM != 0>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    } else {
+        if (g.strip == 5) xt_conv1_strips<5, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+        else xt_conv1_strips<3, true>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    }
     __syncthreads();
     XT_LAP(3);
     // the A operand of the 7-channel block's first convolution: 16 loads per lane, issued here so that the aligning convolution hides them
@@ -503,10 +510,53 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     load_w(XT_C1, XT_C1B);
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
+    if constexpr (MM != 0) {
+      if (al1_mm) {
+        // ---- align1 on v_mfma_f32_16x16x32_bf16 (split operands, like the block below).  Rows (dw, co): two output columns x 8 channel slots; columns: 16 cell
+        // pairs (hz, p) of one output slice; K = 32 = four kernel rows kh = 4 g + r (r = the lane's quarter) x eight input columns 2p - 1 .. 2p + 6 (c8 = dw + kw,
+        // weight 0 where kw is no tap or kh > 4): ten instructions per operand pair cover the 125 taps of 32 output cells — 30 x 17 cycles of the matrix pipe where
+        // the vector form spends 125 x 4 packed FMAs per cell (41 k of the tower's 120 k cycles).  A lane's B fragment is eight CONSECUTIVE words of a (packed by
+        // the block's second convolution); lanes whose kernel row does not exist read the zero words.
+        const xt_u4* __restrict__ wsrc = reinterpret_cast<const xt_u4*>(wt + XT_AL1B) + lane;
+        float bias[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) bias[i] = wt[XT_AL1 + 1000 + co0 + i];
+        const int ppr = (ow + 1) >> 1, npair = oh * ppr, T = (npair + 15) >> 4;
+        for (int tile = wv; tile < od * T; tile += nw) {
+            const int dz = tile / T, f = (tile - dz * T) * 16 + pn;
+            const bool lv = f < npair;
+            const int fc = lv ? f : npair - 1, hz = fc / ppr, p = fc - hz * ppr;
+            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll 1
+            for (int kd = 0; kd < 5; kd++) {
+                const int rbase = ((dz * g.sd + kd) * Hp + hz) * Wp + 2 * p;          // kernel row 0, input column 2p - 1 (the grid's halo is the padding)
+#pragma unroll
+                for (int gk = 0; gk < 2; gk++) {
+                    const int kh = 4 * gk + q;
+                    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(kh <= 4 ? xpad + rbase + kh * Wp : xt_smem + zidx);
+                    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6], w7 = pw[7];
+                    const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), __builtin_amdgcn_perm(w7, w6, 0x07060302u)};
+                    const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
+                    const xt_u4 ah = wsrc[((kd * 2 + gk) * 2) * 64], al = wsrc[((kd * 2 + gk) * 2 + 1) * 64];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
+                }
+            }
+            const int w = 2 * p + dwv;
+            if (lv && w < ow) {
+                float* o = bufB + ((dz * oh + hz) * ow + w) * 7 + co0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (co0 + i < 7) o[i] = xt_pack(acc[i]);
+            }
+        }
+      }
+    }
     // (consecutive lanes take consecutive ROWS of one column: their reads are an odd pitch apart.  Measured and dropped: a work item of HALF a cell —
     //  four of the eight channel slots, 80 chunks dealt evenly over 16 waves instead of 2.45 passes rounded up to 3: 47.6 k cycles against 32.9 k,
     //  the LDS read and the scalar weight load per tap do not shrink with the channels)
-    for (int q = tid; q < ncellB; q += nthr) {
+    for (int q = (MM != 0 && al1_mm) ? ncellB : tid; q < ncellB; q += nthr) {
         const int hz = q % oh, wz = (q / oh) % ow, dz = q / (ow * oh), i = (dz * oh + hz) * ow + wz;
         const float* ap = xpad + (dz * g.sd * Hp + hz * g.sh) * Wp + wz * g.sw;          // tap (0, 0, 0): the grid's halo is the convolution's padding
         xt_f2 acc[4];
