@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     XT_LAP(3);
     // the A operand of the 7-channel block's first convolution: 16 loads per lane, issued here so that the aligning convolution hides them
     // (it fetches nothing through the vector memory path; earlier, the 64 registers would squeeze the 1-channel stages)
-    load_w(XT_C1, XT_C1B);
+    if constexpr (MM == 0) load_w(XT_C1, XT_C1B);      // (matrix mode 1: after align1 — its six accumulators and fragments need the registers)
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
     if constexpr (MM != 0) {
@@ -521,34 +521,50 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         float bias[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_AL1 + 1000 + co0 + i];
-        const int ppr = (ow + 1) >> 1, npair = oh * ppr, T = (npair + 15) >> 4;
-        for (int tile = wv; tile < od * T; tile += nw) {
-            const int dz = tile / T, f = (tile - dz * T) * 16 + pn;
-            const bool lv = f < npair;
-            const int fc = lv ? f : npair - 1, hz = fc / ppr, p = fc - hz * ppr;
-            xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
-#pragma unroll 1
-            for (int kd = 0; kd < 5; kd++) {
-                const int rbase = ((dz * g.sd + kd) * Hp + hz) * Wp + 2 * p;          // kernel row 0, input column 2p - 1 (the grid's halo is the padding)
+        const int ppr = (ow + 1) >> 1, npair = oh * ppr, T = (npair + 15) >> 4, ntile = od * T;
+        // a wave takes its tiles (wv, wv + nw, ...) SIX at a time with the step loop outside: the fragments of a step are fetched once per wave and six
+        // tiles, and the six accumulators give the matrix pipe independent instructions (one tile at a time the 20 fetches per tile were the stage: 35 k cycles)
+        constexpr int TC = 6;
+        for (int t0 = wv; t0 < ntile; t0 += nw * TC) {
+            xt_f4 acc[TC];
+            int rb[TC];
+            bool ok[TC];
 #pragma unroll
-                for (int gk = 0; gk < 2; gk++) {
-                    const int kh = 4 * gk + q;
-                    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(kh <= 4 ? xpad + rbase + kh * Wp : xt_smem + zidx);
+            for (int j = 0; j < TC; j++) {
+                const int tile = min(t0 + j * nw, ntile - 1), dz = tile / T, f = (tile - dz * T) * 16 + pn;
+                ok[j] = f < npair;
+                const int fc = ok[j] ? f : npair - 1, hz = fc / ppr, p = fc - hz * ppr;
+                rb[j] = (dz * g.sd * Hp + hz) * Wp + 2 * p;                           // kernel row 0 of slice kd = 0, input column 2p - 1 (the grid's halo is the padding)
+                acc[j] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+            }
+#pragma unroll 1
+            for (int st = 0; st < 10; st++) {
+                const int kd = st >> 1, kh = 4 * (st & 1) + q;
+                const xt_u4 ah = wsrc[(st * 2) * 64], al = wsrc[(st * 2 + 1) * 64];
+                const int roff = (kd * Hp + kh) * Wp;
+#pragma unroll
+                for (int j = 0; j < TC; j++) {
+                    if (t0 + j * nw >= ntile) break;                                    // (wave-uniform)
+                    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(kh <= 4 ? xpad + rb[j] + roff : xt_smem + zidx);
                     const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6], w7 = pw[7];
                     const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), __builtin_amdgcn_perm(w7, w6, 0x07060302u)};
                     const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
-                    const xt_u4 ah = wsrc[((kd * 2 + gk) * 2) * 64], al = wsrc[((kd * 2 + gk) * 2 + 1) * 64];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
                 }
             }
-            const int w = 2 * p + dwv;
-            if (lv && w < ow) {
-                float* o = bufB + ((dz * oh + hz) * ow + w) * 7 + co0;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (co0 + i < 7) o[i] = xt_pack(acc[i]);
+            for (int j = 0; j < TC; j++) {
+                const int tile = t0 + j * nw;
+                if (tile >= ntile) break;
+                const int dz = tile / T, f = (tile - dz * T) * 16 + pn, hz = f / ppr, p = f - hz * ppr, w = 2 * p + dwv;
+                if (ok[j] && w < ow) {
+                    float* o = bufB + ((dz * oh + hz) * ow + w) * 7 + co0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (co0 + i < 7) o[i] = xt_pack(acc[j][i]);
+                }
             }
         }
       }
@@ -579,6 +595,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
         for (int co = 0; co < 7; co++) bufB[i * 7 + co] = xt_act<MM>(acc[co >> 1][co & 1]);
     }
+    if constexpr (MM != 0) load_w(XT_C1, XT_C1B);
     __syncthreads();
     }       // (!NET)
     XT_LAP(4);
