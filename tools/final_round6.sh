@@ -33,6 +33,7 @@ done
 cd $R; unset XR_BENCH_NO_FORK
 timeout 300 python bench.py --agent dqn --envs 1024 --steps 20 --warmup 3 > $OUT/agent_dqn_1024.json 2>/dev/null
 XR_NET_TOWER=0 timeout 300 python bench.py --agent ppo --envs 4096 --steps 20 --warmup 3 > $OUT/agent_ppo_4096_framework_net_tower.json 2>/dev/null
+XR_TOWER_FP32=1 timeout 300 python bench.py --agent ppo --envs 4096 --steps 20 --warmup 3 > $OUT/agent_ppo_4096_fp32_matrix_mode.json 2>/dev/null     # (the 7 -> 7 stages on v_mfma_f32_16x16x4_f32 instead of split bf16)
 for E in 4096 512; do
     timeout 300 python bench.py --global-envs $E --agent ppo --steps 20 --warmup 3 > $OUT/agent_ppo_${E}_per_rank.json 2>/dev/null
     timeout 300 python bench.py --global-envs $E --agent ppo --learner --steps 20 --warmup 3 > $OUT/agent_ppo_${E}_central_learner.json 2>/dev/null
@@ -52,7 +53,7 @@ for f in ("forced_rccl_env_only", "forced_rccl_config4_per_rank", "forced_rccl_c
         print(f, round(d["value"]), d["ms_per_step"], "gather_verified", d.get("gather_verified"), "ranks_seen", d.get("ranks_seen"), "parity", (d.get("parity") or {}).get("ok"), (d.get("actions_sha") or "")[:12])
     except Exception as ex:
         print(f, "FAILED", ex)
-for f in ("agent_dqn_4096", "agent_ppo_4096", "agent_ppo_4096_framework_net_tower", "agent_dqn_1024"):
+for f in ("agent_dqn_4096", "agent_ppo_4096", "agent_ppo_4096_framework_net_tower", "agent_ppo_4096_fp32_matrix_mode", "agent_dqn_1024"):
     try:
         d = json.loads(open("$OUT/" + f + ".json").read().strip().splitlines()[-1])
         print(f, round(d["value"]), d["ms_per_step"], {k: v for k, v in (d.get("training_cadence") or {}).items() if k != "what"}, (d.get("net_tower_roofline") or {}).get("ms_per_1024_nets"), (d.get("tower_roofline") or {}).get("ms_per_1024_envs"))

@@ -50,7 +50,7 @@ constexpr int XT_C1 = XT_AL1 + 1008;        // 16*64*4 + 8 block(7).conv1 as the
 constexpr int XT_C2 = XT_C1 + 4104;         // same       block(7).conv2
 constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padded to 8][kw]: the 12 weights a lane of the last stage needs are neighbours
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
-constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3): [(kd, kh)][hi / lo][lane][4 words]
+constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3b): [(kd, kh)][hi / lo][lane][4 words]
 constexpr int XT_C2B = XT_C1B + 4608;       // same       block(7).conv2
 constexpr int XT_AL1B = XT_C2B + 4608;      // 10*2*64*4  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [(kd, kh group)][hi / lo][lane][4 words]
 constexpr int XT_TOTAL = XT_AL1B + 5120;
@@ -124,16 +124,28 @@ __device__ __forceinline__ void xt_load_wAb(const float* __restrict__ wc, int la
     for (int s = 0; s < 9; s++) { ah[s] = src[(2 * s) * 64]; al[s] = src[(2 * s + 1) * 64]; }
 }
 
-// one tap row: acc += A(kd, kh) . B, B = the seven channel words of the lane's cell at xt_smem[a .. a + 6] (+ a zero eighth slot)
-__device__ __forceinline__ xt_f4 xt_mm3(const xt_u4 ah, const xt_u4 al, const float* __restrict__ cell, xt_f4 acc) {
+// the hi and lo B fragments of one cell: its seven channel words (+ a zero eighth slot)
+__device__ __forceinline__ void xt_bfrag(const float* __restrict__ cell, xt_u4& bh, xt_u4& bl) {
     const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(cell);
     const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6];
-    const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), w6 >> 16};
-    const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), w6 & 0xFFFFu};
+    bh = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), w6 >> 16};
+    bl = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), w6 & 0xFFFFu};
+}
+// the input-slice-major form of the two 7 -> 7 stages (a cell row's fragments built once for the up to three output slices it is a tap of) holds three
+// accumulators beside the 72 weight registers: the net variant fits its 128 registers (stages 24 k -> 18 k cycles), the obstacle variant spills all 72
+// (stage 79 k) and gains 1 k without the spill — it keeps the output-major form
+template <bool NET, int MM> constexpr bool xt_reuse_b() { return NET && MM != 0; }
+__device__ __forceinline__ xt_f4 xt_mm3b(const xt_u4 ah, const xt_u4 al, const xt_u4 bh, const xt_u4 bl, xt_f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
     return acc;
+}
+// one tap row: acc += A(kd, kh) . B, B = the seven channel words of the lane's cell at cell[0 .. 6] (+ a zero eighth slot)
+__device__ __forceinline__ xt_f4 xt_mm3(const xt_u4 ah, const xt_u4 al, const float* __restrict__ cell, xt_f4 acc) {
+    xt_u4 bh, bl;
+    xt_bfrag(cell, bh, bl);
+    return xt_mm3b(ah, al, bh, bl, acc);
 }
 
 // One 3x3x3 convolution of the 1-channel block on zero-padded grids [D + 2][H + 2][Wp] (Wp = W + 2 rounded up to an ODD number of words): a thread
@@ -653,6 +665,37 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const int w = 2 * p + dwv;
             const bool st = lv && w < wc;
             float* o = bufC1 + (h * we1 + w) * 7 + co0;
+            if constexpr (xt_reuse_b<NET, MM>()) {
+                // matrix mode 1, net variant: input-slice-major — the fragments of an input cell row (7 LDS reads + 8 permutes) are built ONCE and feed the up to three output
+                // slices it is a tap of (output-major they were built three times: the vector work of the stage, 13 k of its 24 k cycles)
+                xt_f4 acc3[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+                for (int dd = 0; dd < 3; dd++) {
+                    if (dd >= od) break;                              // (standard padding behind the data's slices) — wave-uniform
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) {
+                        __builtin_amdgcn_sched_barrier(0);            // (one cell row's fragments at a time: hoisting all nine rows' reads spills)
+                        xt_u4 bh, bl;
+                        xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            const int kd = dd - d + 1;
+                            if (kd < 0 || kd > 2 || !((dm >> d) & 1)) continue;       // (compile-time / wave-uniform)
+                            acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    if (!((dm >> d) & 1) || !st) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = xt_pack(fmaxf(acc3[d][i], 0.f));
+                }
+                continue;
+            }
 #pragma unroll 1
             for (int d = 0; d < 3; d++) {
                 if (!((dm >> d) & 1)) {                               // another wave's slice (wave-uniform)
@@ -668,7 +711,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                     for (int kh = 0; kh < 3; kh++) {
                         const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
-                        if constexpr (MM) {
+                        if constexpr (MM != 0) {
                             acc = xt_mm3(wAh[kd * 3 + kh], wAl[kd * 3 + kh], xt_smem + a, acc);
                         } else {
 #pragma unroll
@@ -727,6 +770,27 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const bool ov = lv && w < cols;
             const bool inhw = ov && h < oh && w < ow;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            constexpr bool RB = xt_reuse_b<NET, MM>();
+            xt_f4 acc3[RB ? 3 : 1];
+            if constexpr (RB) {                                       // matrix mode 1, net variant: input-slice-major, the fragments of a cell row built once (see the first stage)
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+                for (int dd = 0; dd < 3; dd++) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        xt_u4 bh, bl;
+                        xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            const int kd = dd - d + 1;
+                            if (kd < 0 || kd > 2 || !((dm >> d) & 1)) continue;
+                            acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                        }
+                    }
+                }
+            }
 #pragma unroll 1
             for (int d = 0; d < 3; d++) {
                 if (!((dm >> d) & 1)) {                               // another wave's slice (wave-uniform)
@@ -742,6 +806,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? (MM ? xt_unpack(pb[i]) : pb[i]) : 0.f;
                 xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
+                if constexpr (RB) {
+                    acc = d == 0 ? acc3[0] : d == 1 ? acc3[RB ? 1 : 0] : acc3[RB ? 2 : 0];
+                } else {
 #pragma unroll
                 for (int kd = 0; kd < 3; kd++) {
                     const int dd = d + kd - 1;
@@ -749,7 +816,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                     for (int kh = 0; kh < 3; kh++) {
                         const int a = kd == 0 ? am[kh] - ds[kh] : kd == 2 ? am[kh] + ds[kh] : am[kh];
-                        if constexpr (MM) {
+                        if constexpr (MM != 0) {
                             acc = xt_mm3(wAh[kd * 3 + kh], wAl[kd * 3 + kh], xt_smem + a, acc);
                         } else {
 #pragma unroll
@@ -757,6 +824,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(kd * 3 + kh) * 7 + ci], xt_smem[a + ci], acc, 0, 0, 0);
                         }
                     }
+                }
                 }
                 if (ov) {
                     const float wl[12] = {wk0[0], wk0[1], wk0[2], wk0[3], wk1[0], wk1[1], wk1[2], wk1[3], wk2[0], wk2[1], wk2[2], wk2[3]};
