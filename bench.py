@@ -43,6 +43,16 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 PACK_PATH = os.path.join(ROOT, "tests", "golden", "ispd18_test1_regions.npz")    # 256 regions extracted from the reference's ispd18_test1 LEF/DEF/guide
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / v_pk_fma_f32, 256 FLOP per clock and CU
+# How the towers multiply (csrc/xr_agent.hip, `xr_agent_matrix_mode`; XR_TOWER_FP32=1 selects 0).  Both are priced against the fp32 peak above: `achieved` counts the
+# ALGORITHMIC fp32 multiply-adds; mode 1 spends three bf16 matrix instructions (hi.hi + hi.lo + lo.hi of operands split into two bf16 halves, fp32 accumulate) on
+# each of them and agrees with the framework's fp32 convolutions to ~1e-5 (tests/test_agents.py hold 2e-4), mode 0 is a k-ordered fp32 fma chain.
+MATRIX_MODES = {0: "7 -> 7 convolutions on v_mfma_f32_16x16x4_f32",
+                1: "7 -> 7 convolutions and the aligning convolution on v_mfma_f32_16x16x32_bf16, split-bf16 operands x3, fp32 accumulate"}
+
+
+def matrix_mode():
+    from xroute_env_amd import _lib
+    return int(_lib.lib().xr_agent_matrix_mode())
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 STAGGER_SEED = 0x5EED5EED
 
@@ -1196,7 +1206,7 @@ def agent_leg(args, regions, dev, world):
         torch.cuda.synchronize(dev)
         tms = tev[0].elapsed_time(tev[1]) / 10
         fl = 2.0 * B * tower_macs((dims[2], dims[1], dims[0]))
-        tower_roof = {"kernel": "xr_ob_tower_kernel (7 -> 7 convolutions on v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": round(fl / (tms * 1e-3) / 1e12, 2),
+        tower_roof = {"kernel": "xr_ob_tower_kernel (%s)" % MATRIX_MODES[matrix_mode()], "matrix_mode": matrix_mode(), "bound": "mfma", "achieved": round(fl / (tms * 1e-3) / 1e12, 2),
                       "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (tms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
                       "avg_launch_ms": round(tms, 4), "ms_per_1024_envs": round(tms * 1024 / B, 4), "algorithmic_flops_per_launch": int(fl)}
     net_roof = None
@@ -1218,7 +1228,7 @@ def agent_leg(args, regions, dev, world):
             back = 1323 * 3 * ((oh + 1) * (ow + 1) + (oh + 2) * (ow + 2)) + 21 * 3 * (oh + 2) * (ow + 2)          # the matrix back end (what the kernel really multiplies)
             dense = 2 * 27 * 49 * D_ * H_ * W_ + 875 * 7 * od * oh * ow + back                                    # the framework path's multiply-adds per net
             npairs = int(reg_all.numel())
-            net_roof = {"kernel": "xr_ob_tower_kernel<NET> (sparse front end + the 7 -> 7 block on v_mfma_f32_16x16x4_f32)", "bound": "mfma",
+            net_roof = {"kernel": "xr_ob_tower_kernel<NET> (sparse front end; %s)" % MATRIX_MODES[matrix_mode()], "matrix_mode": matrix_mode(), "bound": "mfma",
                         "achieved": round(2.0 * npairs * back / (nms * 1e-3) / 1e12, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(2.0 * npairs * back / (nms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(nms, 4),
                         "net_pairs": npairs, "ms_per_1024_nets": round(nms * 1024 / max(npairs, 1), 4), "nets_per_s": round(npairs / (nms * 1e-3), 1),
@@ -1260,7 +1270,7 @@ def agent_leg(args, regions, dev, world):
             "net_cache_refill_ms": None if cadence is None else cadence.get("refill_ms"), "training_cadence": cadence,
             "net_vectors_by": {"fused_kernel": cache.fused_fills, "framework_convolutions": cache.framework_fills},
             "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
+            "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy (towers: split-bf16 x3 matrix products, fp32 accumulate; XR_TOWER_FP32=1 for fp32 ones)", "data": "synthetic",
             "config": {"workload": (f"{B} env slots over the design-derived ispd18_test1 region pack ({len(grouped.shapes)} grid shapes, fused tower for "
                                     f"{sum(t is not None for t in grouped.towers)} of them; XR-Maze {'v2 (the reference TCL knob values, this build semantics)' if args.maze_v2 else 'v1'}), full maze route per step, "
                                     if mixed else f"BASELINE config 3/4 shape: {B} ispd18_test1-sized regions, full maze route per step, ")
@@ -1518,7 +1528,7 @@ def agent_sharded(args, regions, dev, world, rank, first_env, B, strong, learner
                "value": round(total_real / elapsed_max, 1), "unit": "env-steps/s", "n_gpus": world if good else None, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed_max / n * 1e3, 4), "higher_is_better": True,
                "scaling": "strong" if strong else "weak", "vs_baseline": None,
-               "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy", "data": "synthetic",
+               "dtype": "u32 distances / i16 state / fp32 observation + fp32 policy (towers: split-bf16 x3 matrix products, fp32 accumulate; XR_TOWER_FP32=1 for fp32 ones)", "data": "synthetic",
                "config": {"workload": (f"BASELINE config 4 shape: a {Bg}-env batch, {B} per GPU, "
                                        + (f"over the design-derived ispd18_test1 region pack {os.path.basename(args.region_pack)} (XR-Maze {'v2: the reference TCL knob values, this build semantics' if v2 else 'v1'}), "
                                           if args.region_pack else "of ispd18_test1-sized regions (24x40x9, K~U[4,36]), ")

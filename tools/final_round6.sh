@@ -49,13 +49,13 @@ python3 - <<PY
 import json
 for f in ("forced_rccl_env_only", "forced_rccl_config4_per_rank", "forced_rccl_config4_central_learner", "forced_rccl_config5", "agent_ppo_4096_per_rank", "agent_ppo_4096_central_learner"):
     try:
-        d = json.loads(open("$OUT/" + f + ".json").read().strip().splitlines()[-1])
+        d = json.loads([l for l in open("$OUT/" + f + ".json").read().splitlines() if l.startswith("{")][-1])
         print(f, round(d["value"]), d["ms_per_step"], "gather_verified", d.get("gather_verified"), "ranks_seen", d.get("ranks_seen"), "parity", (d.get("parity") or {}).get("ok"), (d.get("actions_sha") or "")[:12])
     except Exception as ex:
         print(f, "FAILED", ex)
 for f in ("agent_dqn_4096", "agent_ppo_4096", "agent_ppo_4096_framework_net_tower", "agent_ppo_4096_fp32_matrix_mode", "agent_dqn_1024"):
     try:
-        d = json.loads(open("$OUT/" + f + ".json").read().strip().splitlines()[-1])
+        d = json.loads([l for l in open("$OUT/" + f + ".json").read().splitlines() if l.startswith("{")][-1])
         print(f, round(d["value"]), d["ms_per_step"], {k: v for k, v in (d.get("training_cadence") or {}).items() if k != "what"}, (d.get("net_tower_roofline") or {}).get("ms_per_1024_nets"), (d.get("tower_roofline") or {}).get("ms_per_1024_envs"))
     except Exception as ex:
         print(f, "FAILED", ex)
