@@ -41,6 +41,8 @@ def child(B, dims, out_path):
             print(f"  {n_:40s} {c:9.0f} cycles {100 * c / tot:5.1f}%")
         print(f"  {'total':40s} {tot:9.0f} cycles per env (thread 0)")
         print("  block(7) conv1, cycles of every wave's fill loop + tiles:", " ".join(f"{v / 1000:.1f}k" for v in out[:, 16:32].double().mean(0).tolist()))
+        print("  align1, cycles of every wave's tiles:", " ".join(f"{v / 1000:.1f}k" for v in out[:, 32:48].double().mean(0).tolist()))
+        print("  align1, then the next stage's operands arrive:", " ".join(f"{v / 1000:.1f}k" for v in out[:, 48:64].double().mean(0).tolist()))
         sub = out[:, 7:11].double().mean(0).tolist()
         print(f"  block(7) conv1, wave 0: fill loop {sub[0]:.0f}, its own tiles {sub[1]:.0f}, the next convolution's operands {sub[2]:.0f}, waiting at the barrier {sub[3]:.0f} cycles")
     print(json.dumps({"lib": os.environ.get("XR_LIB", "libxroute_hip.so"), "envs": B, "dims": dims, "ms_per_launch": round(ms, 4),

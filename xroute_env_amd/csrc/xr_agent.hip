@@ -52,7 +52,7 @@ constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padd
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3b): [(kd, kh)][hi / lo][lane][4 words]
 constexpr int XT_C2B = XT_C1B + 4608;       // same       block(7).conv2
-constexpr int XT_AL1B = XT_C2B + 4608;      // 10*2*64*4  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [(kd, kh group)][hi / lo][lane][4 words]
+constexpr int XT_AL1B = XT_C2B + 4608;      // 5*2*64*4 (+ as much unused)  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [kd][hi / lo][lane][4 words]
 constexpr int XT_TOTAL = XT_AL1B + 5120;
 // the NET tower (same 7-channel block + last convolution, its own weights in the XT_C1 .. XT_KV slots; XT_A1 .. XT_AL1 unused) has a sparse front end
 // behind them (agents.FusedNetTower.pack):
@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         if constexpr (MM) xt_load_wAb(wt + off_bf16, lane, wAh, wAl);
         else xt_load_wA(wt + off_f32, lane, wA);
     };
+#ifdef XT_PHASE_TIMING
+    unsigned long long xt_a0 = 0, xt_a1 = 0, xt_a2 = 0;         // every wave: align1's tiles / the next stage's operands arriving
+#endif
     if constexpr (NET) {
         // ==== the net tower's SPARSE front end: P = align1(block(x)) of a net's 7 planes without ever forming them (agents.FusedNetTower) ====
         // x is 1 at the net's access points (plane 0; planes 1..6: the aliased "has a same-net axis neighbour" flag) and 0 elsewhere.  With S1 / S2 =
@@ -522,21 +525,28 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     if constexpr (MM == 0) load_w(XT_C1, XT_C1B);      // (matrix mode 1: after align1 — its six accumulators and fragments need the registers)
     // ---- align1: 5x5x5, 1 -> 7 channels, stride (sd,sh,sw), padding 1 ------------------------------------------------------------
     const int ncellB = od * oh * ow;
+#ifdef XT_PHASE_TIMING
+    xt_a0 = __builtin_readcyclecounter();
+#endif
     if constexpr (MM != 0) {
       if (al1_mm) {
         // ---- align1 on v_mfma_f32_16x16x32_bf16 (split operands, like the block below).  Rows (dw, co): two output columns x 8 channel slots; columns: 16 cell
-        // pairs (hz, p) of one output slice; K = 32 = four kernel rows kh = 4 g + r (r = the lane's quarter) x eight input columns 2p - 1 .. 2p + 6 (c8 = dw + kw,
-        // weight 0 where kw is no tap or kh > 4): ten instructions per operand pair cover the 125 taps of 32 output cells — 30 x 17 cycles of the matrix pipe where
-        // the vector form spends 125 x 4 packed FMAs per cell (41 k of the tower's 120 k cycles).  A lane's B fragment is eight CONSECUTIVE words of a (packed by
-        // the block's second convolution); lanes whose kernel row does not exist read the zero words.
+        // pairs (hz, p) of one output slice; K = the 5 kernel rows x 6 input columns 2p - 1 .. 2p + 4 of ONE kd (c6 = dw + kw, weight 0 where kw is no tap): slot
+        // s = 6 kh + c6 (30 of 32; the lane's quarter holds s = 8 q .. 8 q + 7): FIVE instructions per operand pair cover the 125 taps of 32 output cells.
+        // (first form: four kernel rows x eight consecutive columns per instruction, ten steps — the eight reads were immediates off one address, but the stage is
+        // bound by what the lanes read from LDS and permute, 512 words per instruction and step: 30.0 k cycles; this form halves the steps.)
         const xt_u4* __restrict__ wsrc = reinterpret_cast<const xt_u4*>(wt + XT_AL1B) + lane;
         float bias[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_AL1 + 1000 + co0 + i];
+        int offs[8];                                                                    // the lane's eight slots: word offsets from (kernel row 0, column 2p - 1)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int sl = 8 * q + i, s2 = sl < 30 ? sl : 0; offs[i] = (s2 / 6) * Wp + s2 % 6; }
         const int ppr = (ow + 1) >> 1, npair = oh * ppr, T = (npair + 15) >> 4, ntile = od * T;
-        // a wave takes its tiles (wv, wv + nw, ...) SIX at a time with the step loop outside: the fragments of a step are fetched once per wave and six
-        // tiles, and the six accumulators give the matrix pipe independent instructions (one tile at a time the 20 fetches per tile were the stage: 35 k cycles)
-        constexpr int TC = 6;
+        // a wave takes its tiles (wv, wv + nw, ...) THREE at a time with the step loop outside: the fragments of a step are fetched once per wave and three
+        // tiles (a step ahead), the three accumulators give the matrix pipe independent instructions, and the 24 read addresses stay in registers over the steps (six
+        // tiles: 48 addresses, 212 B of scratch per lane)
+        constexpr int TC = 3;
         for (int t0 = wv; t0 < ntile; t0 += nw * TC) {
             xt_f4 acc[TC];
             int rb[TC];
@@ -549,22 +559,24 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                 rb[j] = (dz * g.sd * Hp + hz) * Wp + 2 * p;                           // kernel row 0 of slice kd = 0, input column 2p - 1 (the grid's halo is the padding)
                 acc[j] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
             }
+            xt_u4 ah = wsrc[0], al = wsrc[64];
 #pragma unroll 1
-            for (int st = 0; st < 10; st++) {
-                const int kd = st >> 1, kh = 4 * (st & 1) + q;
-                const xt_u4 ah = wsrc[(st * 2) * 64], al = wsrc[(st * 2 + 1) * 64];
-                const int roff = (kd * Hp + kh) * Wp;
+            for (int kd = 0; kd < 5; kd++) {
+                const int nx = min(kd + 1, 4);
+                const xt_u4 ahn = wsrc[(nx * 2) * 64], aln = wsrc[(nx * 2 + 1) * 64];
+                const uint32_t* __restrict__ slab = reinterpret_cast<const uint32_t*>(xpad) + kd * Hp * Wp;
 #pragma unroll
                 for (int j = 0; j < TC; j++) {
                     if (t0 + j * nw >= ntile) break;                                    // (wave-uniform)
-                    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(kh <= 4 ? xpad + rb[j] + roff : xt_smem + zidx);
-                    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6], w7 = pw[7];
+                    const uint32_t* __restrict__ pw = slab + rb[j];
+                    const uint32_t w0 = pw[offs[0]], w1 = pw[offs[1]], w2 = pw[offs[2]], w3 = pw[offs[3]], w4 = pw[offs[4]], w5 = pw[offs[5]], w6 = pw[offs[6]], w7 = pw[offs[7]];
                     const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), __builtin_amdgcn_perm(w7, w6, 0x07060302u)};
                     const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
                 }
+                ah = ahn; al = aln;
             }
 #pragma unroll
             for (int j = 0; j < TC; j++) {
@@ -607,7 +619,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
         for (int co = 0; co < 7; co++) bufB[i * 7 + co] = xt_act<MM>(acc[co >> 1][co & 1]);
     }
+#ifdef XT_PHASE_TIMING
+    xt_a1 = __builtin_readcyclecounter();
+#endif
     if constexpr (MM != 0) load_w(XT_C1, XT_C1B);
+#ifdef XT_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xt_a2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
     }       // (!NET)
     XT_LAP(4);
@@ -882,6 +901,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     XT_LAP(7);
     __syncthreads();                                   // (after wave 0 has written the row)
     if (lane == 0) out[(int64_t)e * 64 + 16 + wv] = (float)(xt_w1 - xt_w0);
+    if (lane == 0 && !NET) { out[(int64_t)e * 64 + 32 + wv] = (float)(xt_a1 - xt_a0); out[(int64_t)e * 64 + 48 + wv] = (float)(xt_a2 - xt_a1); }
     if (tid == 0) {
         for (int k = 0; k < 7; k++) out[(int64_t)e * 64 + k] = (float)(xt_lap[k + 1] - xt_lap[k]);
         out[(int64_t)e * 64 + 7] = (float)(xt_lap[8] - xt_lap[4]);          // conv 1 stage: the fill loop
