@@ -52,7 +52,7 @@ constexpr int XT_AL2 = XT_C2 + 4104;        // 3*64*8*3   align2: [d][h][ch padd
 constexpr int XT_KV = XT_AL2 + 4608;        // 64         bias + contribution of every cell the data cannot influence
 constexpr int XT_C1B = XT_KV + 64;          // 9*2*64*4   block(7).conv1 as bf16 A fragments of v_mfma_f32_16x16x32_bf16 (matrix mode 1, see xt_mm3b): [(kd, kh)][hi / lo][lane][4 words]
 constexpr int XT_C2B = XT_C1B + 4608;       // same       block(7).conv2
-constexpr int XT_AL1B = XT_C2B + 4608;      // 5*2*64*4 (+ as much unused)  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [kd][hi / lo][lane][4 words]
+constexpr int XT_AL1B = XT_C2B + 4608;      // 5*2*2*64*4  align1 as split-bf16 fragments (matrix mode 1, strides (sd, 1, 1)): [kd][g][kind][lane][4 words]
 constexpr int XT_TOTAL = XT_AL1B + 5120;
 // the NET tower (same 7-channel block + last convolution, its own weights in the XT_C1 .. XT_KV slots; XT_A1 .. XT_AL1 unused) has a sparse front end
 // behind them (agents.FusedNetTower.pack):
@@ -134,6 +134,10 @@ __device__ __forceinline__ void xt_bfrag(const float* __restrict__ cell, xt_u4& 
 // the input-slice-major form of the two 7 -> 7 stages (a cell row's fragments built once for the up to three output slices it is a tap of) holds three
 // accumulators beside the 72 weight registers: the net variant fits its 128 registers (stages 24 k -> 18 k cycles), the obstacle variant spills all 72
 // (stage 79 k) and gains 1 k without the spill — it keeps the output-major form
+template <int N> struct xt_ic { static constexpr int value = N; };
+#ifndef XT_AL1_TC
+#define XT_AL1_TC 4
+#endif
 template <bool NET, int MM> constexpr bool xt_reuse_b() { return NET && MM != 0; }
 __device__ __forceinline__ xt_f4 xt_mm3b(const xt_u4 ah, const xt_u4 al, const xt_u4 bh, const xt_u4 bl, xt_f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
@@ -155,6 +159,13 @@ __device__ __forceinline__ xt_f4 xt_mm3(const xt_u4 ah, const xt_u4 al, const fl
 // LDS cycles, profiles/r04_pt_tower_sq_counters.txt.)  Every cell's sum runs in the order (kd, kh, kw).  RES: out is the INPUT of the block (x) and
 // holds x at the cell: out = relu(conv + x), in place.  (A strip may hang over the end of its row: those reads hit the next row or the floats behind
 // the grid — inside the allocation — and feed only sums that are dropped.)
+// Division of a small non-negative index by a run-time extent (n * d < 2^32): one multiply-high with a reciprocal computed once per kernel — the compiler's
+// general u32 division is ~20 vector instructions, and the stages' index arithmetic (three per loaded voxel group, two per strip, four per tile) was a
+// quarter of the 1-channel block's instructions.
+struct XtFd { uint32_t m, d; };
+__device__ __forceinline__ XtFd xt_fd(int d) { return XtFd{d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u, (uint32_t)d}; }
+__device__ __forceinline__ int xt_q(int n, XtFd f) { return f.d > 1 ? (int)__umulhi((uint32_t)n, f.m) : n; }
+
 template <int S, bool RES, bool PACK = false>      // PACK: the result is stored as hi << 16 | lo (matrix mode 1: the aligning convolution reads it as bf16 fragments)
 __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, const float* in, float* out, int D, int H, int W, int tid, int nthr) {
     const int Hp = H + 2, Wp = (W + 2) | 1, rows = D * H, nstrip = rows * ((W + S - 1) / S);
@@ -162,8 +173,9 @@ __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, c
 #pragma unroll
     for (int k = 0; k < 27; k++) wk[k] = wgt[k];
     const float bias = wgt[27];
+    const XtFd frows = xt_fd(rows), fH = xt_fd(H);
     for (int i = tid; i < nstrip; i += nthr) {
-        const int sx = i / rows, r = i - sx * rows, h = r % H, d = r / H, w0 = sx * S;
+        const int sx = xt_q(i, frows), r = i - sx * rows, d = xt_q(r, fH), h = r - d * H, w0 = sx * S;
         const int pi = (d * Hp + h) * Wp + w0;                 // tap (0, 0, 0) of the strip's first cell
         float acc[S];
 #pragma unroll
@@ -488,10 +500,30 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         __syncthreads();
     } else {
     const float* __restrict__ src = head + (int64_t)e * stride;
+    // the env's plane is asked for BEFORE the buffers are zeroed (three 16-byte loads per thread cover 12 K voxels): the fill hides the fetch
+    constexpr int PF = 3;
+    xt_f4 pfv[PF];
+    const XtFd fW = xt_fd(W), fH = xt_fd(H);
+    if (g.vec_load) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int i4 = tid + k * nthr;
+            pfv[k] = i4 < (N >> 2) ? reinterpret_cast<const xt_f4*>(src)[i4] : xt_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     for (int i = tid; i < Np + 8; i += nthr) { xpad[i] = 0.f; if (i < Np) ypad[i] = 0.f; }      // (+ 8 zero words behind x: the matrix form of align1 reads one word past a row)
     __syncthreads();
     if (g.vec_load) {
-        for (int i4 = tid; i4 < (N >> 2); i4 += nthr) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int i4 = tid + k * nthr;
+            if (i4 < (N >> 2)) {
+                const int i = i4 << 2, r = xt_q(i, fW), w = i - r * W, d = xt_q(r, fH), h = r - d * H;
+                float* o = xpad + ((d + 1) * Hp + h + 1) * Wp + w + 1;
+                o[0] = pfv[k][0]; o[1] = pfv[k][1]; o[2] = pfv[k][2]; o[3] = pfv[k][3];
+            }
+        }
+        for (int i4 = tid + PF * nthr; i4 < (N >> 2); i4 += nthr) {
             const int i = i4 << 2, w = i % W, r = i / W, h = r % H, d = r / H;
             const xt_f4 v = reinterpret_cast<const xt_f4*>(src)[i4];
             float* o = xpad + ((d + 1) * Hp + h + 1) * Wp + w + 1;
@@ -530,59 +562,64 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #endif
     if constexpr (MM != 0) {
       if (al1_mm) {
-        // ---- align1 on v_mfma_f32_16x16x32_bf16 (split operands, like the block below).  Rows (dw, co): two output columns x 8 channel slots; columns: 16 cell
-        // pairs (hz, p) of one output slice; K = the 5 kernel rows x 6 input columns 2p - 1 .. 2p + 4 of ONE kd (c6 = dw + kw, weight 0 where kw is no tap): slot
-        // s = 6 kh + c6 (30 of 32; the lane's quarter holds s = 8 q .. 8 q + 7): FIVE instructions per operand pair cover the 125 taps of 32 output cells.
-        // (first form: four kernel rows x eight consecutive columns per instruction, ten steps — the eight reads were immediates off one address, but the stage is
-        // bound by what the lanes read from LDS and permute, 512 words per instruction and step: 30.0 k cycles; this form halves the steps.)
+        // ---- align1 on v_mfma_f32_16x16x32_bf16, split operands.  Rows (dw, co): two output columns x 8 channel slots; columns: 16 cell pairs (hz, p) of one
+        // output slice.  The B operand is the RAW packed word of an input cell (x_hi << 16 | x_lo as the block's second convolution stored it): K slot 2j is x_lo
+        // and 2j + 1 is x_hi of cell j, so an instruction covers 16 cells and the lanes permute nothing — fragment kind 0 holds w_hi on both halves
+        // (w_hi (x_hi + x_lo)), kind 1 holds w_lo on the x_hi half: two instructions per 16 cells for the same three products.  Cells c = 6 kh + c6: the 5 kernel rows
+        // x the 6 input columns 2p - 1 .. 2p + 4 of one kd (c6 = dw + kw; 30 of 32 cells, weight 0 elsewhere); step (kd, g): cells 16 g .. + 15, the lane's quarter
+        // holds cells 16 g + 4 q .. + 3 = two adjacent pairs of words.  Per 32 output cells and kd: 4 instructions, 4 two-word reads, no vector work beside addresses.
+        // (forms before, same products: [4 kernel rows x 8 columns] x 10 steps and [5 rows x 6 columns] x 5 steps with hi / lo fragments permuted out of the packed
+        // words — 8 reads + 8 v_perm per 3 instructions: 30.0 k / 29.3 k cycles, the vector form 32.9 k.)
         const xt_u4* __restrict__ wsrc = reinterpret_cast<const xt_u4*>(wt + XT_AL1B) + lane;
         float bias[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_AL1 + 1000 + co0 + i];
-        int offs[8];                                                                    // the lane's eight slots: word offsets from (kernel row 0, column 2p - 1)
+        int offs[4];                                                                    // the lane's pairs (g, half): word offset from (kernel row 0, column 2p - 1)
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const int sl = 8 * q + i, s2 = sl < 30 ? sl : 0; offs[i] = (s2 / 6) * Wp + s2 % 6; }
+        for (int i = 0; i < 4; i++) { const int c = 16 * (i >> 1) + 4 * q + 2 * (i & 1), c2 = c < 30 ? c : 0; offs[i] = (c2 / 6) * Wp + c2 % 6; }
         const int ppr = (ow + 1) >> 1, npair = oh * ppr, T = (npair + 15) >> 4, ntile = od * T;
-        // a wave takes its tiles (wv, wv + nw, ...) THREE at a time with the step loop outside: the fragments of a step are fetched once per wave and three
-        // tiles (a step ahead), the three accumulators give the matrix pipe independent instructions, and the 24 read addresses stay in registers over the steps (six
-        // tiles: 48 addresses, 212 B of scratch per lane)
-        constexpr int TC = 3;
-        for (int t0 = wv; t0 < ntile; t0 += nw * TC) {
-            xt_f4 acc[TC];
-            int rb[TC];
-            bool ok[TC];
+        const XtFd fT = xt_fd(T), fppr = xt_fd(ppr);
+        // a wave takes its tiles (wv, wv + nw, ...) up to SIX at a time with the step loop outside: the fragments of a step are fetched once per wave and round
+        // (a step ahead: six tiles of work cover the fetch), and the tiles of a round have no branch between them — their reads and matrix instructions interleave
+        // (with a wave-uniform `break` per tile the tiles ran one after the other, each waiting for its own LDS reads: a wave alone took 13 k cycles for five tiles)
+        auto al1_round = [&](auto nt_c, const int t0) {
+            constexpr int NT = decltype(nt_c)::value;
+            xt_f4 acc[NT];
+            int rb[NT];
+            bool ok[NT];
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
-                const int tile = min(t0 + j * nw, ntile - 1), dz = tile / T, f = (tile - dz * T) * 16 + pn;
+            for (int j = 0; j < NT; j++) {
+                const int tile = t0 + j * nw, dz = xt_q(tile, fT), f = (tile - dz * T) * 16 + pn;
                 ok[j] = f < npair;
-                const int fc = ok[j] ? f : npair - 1, hz = fc / ppr, p = fc - hz * ppr;
+                const int fc = ok[j] ? f : npair - 1, hz = xt_q(fc, fppr), p = fc - hz * ppr;
                 rb[j] = (dz * g.sd * Hp + hz) * Wp + 2 * p;                           // kernel row 0 of slice kd = 0, input column 2p - 1 (the grid's halo is the padding)
                 acc[j] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
             }
-            xt_u4 ah = wsrc[0], al = wsrc[64];
+            xt_u4 a00 = wsrc[0], a01 = wsrc[64], a10 = wsrc[128], a11 = wsrc[192];
 #pragma unroll 1
             for (int kd = 0; kd < 5; kd++) {
-                const int nx = min(kd + 1, 4);
-                const xt_u4 ahn = wsrc[(nx * 2) * 64], aln = wsrc[(nx * 2 + 1) * 64];
+                const xt_u4* __restrict__ wn = wsrc + min(kd + 1, 4) * 256;
+                const xt_u4 n00 = wn[0], n01 = wn[64], n10 = wn[128], n11 = wn[192];
                 const uint32_t* __restrict__ slab = reinterpret_cast<const uint32_t*>(xpad) + kd * Hp * Wp;
 #pragma unroll
-                for (int j = 0; j < TC; j++) {
-                    if (t0 + j * nw >= ntile) break;                                    // (wave-uniform)
-                    const uint32_t* __restrict__ pw = slab + rb[j];
-                    const uint32_t w0 = pw[offs[0]], w1 = pw[offs[1]], w2 = pw[offs[2]], w3 = pw[offs[3]], w4 = pw[offs[4]], w5 = pw[offs[5]], w6 = pw[offs[6]], w7 = pw[offs[7]];
-                    const xt_u4 bh = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), __builtin_amdgcn_perm(w7, w6, 0x07060302u)};
-                    const xt_u4 bl = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, al), __builtin_bit_cast(xt_bf8, bh), acc[j], 0, 0, 0);
+                for (int gk = 0; gk < 2; gk++) {                                        // cells 16 gk .. + 15: the round's reads, then its instructions
+                    xt_u4 b[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const uint32_t* __restrict__ pw = slab + rb[j];
+                        b[j] = xt_u4{pw[offs[2 * gk]], pw[offs[2 * gk] + 1], pw[offs[2 * gk + 1]], pw[offs[2 * gk + 1] + 1]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, gk ? a10 : a00), __builtin_bit_cast(xt_bf8, b[j]), acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, gk ? a11 : a01), __builtin_bit_cast(xt_bf8, b[j]), acc[j], 0, 0, 0);
                 }
-                ah = ahn; al = aln;
+                a00 = n00; a01 = n01; a10 = n10; a11 = n11;
             }
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
+            for (int j = 0; j < NT; j++) {
                 const int tile = t0 + j * nw;
-                if (tile >= ntile) break;
-                const int dz = tile / T, f = (tile - dz * T) * 16 + pn, hz = f / ppr, p = f - hz * ppr, w = 2 * p + dwv;
+                const int dz = xt_q(tile, fT), f = (tile - dz * T) * 16 + pn, hz = xt_q(f, fppr), p = f - hz * ppr, w = 2 * p + dwv;
                 if (ok[j] && w < ow) {
                     float* o = bufB + ((dz * oh + hz) * ow + w) * 7 + co0;
 #pragma unroll
@@ -590,6 +627,16 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                         if (co0 + i < 7) o[i] = xt_pack(acc[j][i]);
                 }
             }
+        };
+        constexpr int TC = XT_AL1_TC;
+        for (int t0 = wv; t0 < ntile; t0 += nw * TC) {
+            const int nt = min(TC, (ntile - t0 + nw - 1) / nw);                         // (wave-uniform)
+            if (nt >= 6) al1_round(xt_ic<(TC >= 6 ? 6 : 1)>{}, t0);
+            else if (nt == 5) al1_round(xt_ic<(TC >= 5 ? 5 : 1)>{}, t0);
+            else if (nt == 4) al1_round(xt_ic<(TC >= 4 ? 4 : 1)>{}, t0);
+            else if (nt == 3) al1_round(xt_ic<(TC >= 3 ? 3 : 1)>{}, t0);
+            else if (nt == 2) al1_round(xt_ic<(TC >= 2 ? 2 : 1)>{}, t0);
+            else al1_round(xt_ic<1>{}, t0);
         }
       }
     }
@@ -665,10 +712,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C1 + 4096 + co0 + i];
         const int hc = oh + 1, wc = ow + 1, ppr = (wc + 1) >> 1, npair = hc * ppr, T = (npair + 15) >> 4;
         const int slice = oh * ow * 7;
+        const XtFd fppr = xt_fd(ppr);
         for (int item = 0, t = 0, dm = 0; xt_tile_item(item, wv, nw, T, &t, &dm); item++) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
-            const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
+            const int fc = lv ? f : npair - 1, h = xt_q(fc, fppr), p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)ow;
             // the three kh tap rows of this lane in slice 0: float index of channel 0 (the channels of a cell are neighbours: immediate offsets),
@@ -771,10 +819,11 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         for (int i = 0; i < 4; i++) bias[i] = wt[XT_C2 + 4096 + co0 + i];
         const int ppr = (cols + 1) >> 1, npair = (oh + 2) * ppr, T = (npair + 15) >> 4;
         const int slice = he1 * we1 * 7;
+        const XtFd fppr = xt_fd(ppr);
         for (int item = 0, t = 0, dm = 0; xt_tile_item(item, wv, nw, T, &t, &dm); item++) {
             const int f = t * 16 + pn;
             const bool lv = f < npair;
-            const int fc = lv ? f : npair - 1, h = fc / ppr, p = fc - h * ppr;
+            const int fc = lv ? f : npair - 1, h = xt_q(fc, fppr), p = fc - h * ppr;
             const int col = 2 * p + q - 1;
             const bool cv = lv && (unsigned)col < (unsigned)we1;
             const int base0 = cbase + (h * we1 + col) * 7;
