@@ -83,5 +83,6 @@ timeout 300 python tools/tower_probe.py 4096 9 40 24 2>&1 | grep -v amdgpu > $OU
 timeout 600 make -C xroute_env_amd/csrc ttiming > /dev/null 2>&1
 XR_LIB=libxroute_hip_ttiming.so XT_PHASES=1 timeout 300 python tools/net_tower_probe.py 1024 2>&1 | grep -v amdgpu > $OUT/net_tower_phases.txt; cat $OUT/net_tower_phases.txt
 XR_TOWER_LIBS=libxroute_hip_ttiming.so XT_PHASES=1 timeout 300 python tools/tower_probe.py 1024 9 40 24 2>&1 | grep -v amdgpu > $OUT/tower_phases.txt; tail -14 $OUT/tower_phases.txt
+timeout 900 bash tools/pmc_tower.sh ${TAG}_tower_sq > $OUT/tower_sq_counters.txt 2>&1; cp $R/gpurun_out/${TAG}_tower_sq/summary.txt $OUT/tower_sq_counters.txt 2>/dev/null; rm -rf $R/gpurun_out/${TAG}_tower_sq; tail -8 $OUT/tower_sq_counters.txt
 timeout 900 python tools/soak.py 2>&1 | grep -v amdgpu | tail -8 > $OUT/parity_soak.txt; cat $OUT/parity_soak.txt
 rm -rf $R/gpurun_out/${TAG}_sq $R/gpurun_out/${TAG}_c5 2>/dev/null; du -sh $R/gpurun_out; ls $OUT | head -80
