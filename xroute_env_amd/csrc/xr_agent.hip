@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const int w = 2 * p + dwv;
             const bool st = lv && w < wc;
             float* o = bufC1 + (h * we1 + w) * 7 + co0;
-            if constexpr (xt_reuse_b<NET, MM>()) {
+            if constexpr (MM != 0) {
                 // matrix mode 1, net variant: input-slice-major — the fragments of an input cell row (7 LDS reads + 8 permutes) are built ONCE and feed the up to three output
                 // slices it is a tap of (output-major they were built three times: the vector work of the stage, 13 k of its 24 k cycles)
                 xt_f4 acc3[3];
