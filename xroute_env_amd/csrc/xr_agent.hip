@@ -131,9 +131,10 @@ __device__ __forceinline__ void xt_bfrag(const float* __restrict__ cell, xt_u4& 
     bh = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), w6 >> 16};
     bl = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), w6 & 0xFFFFu};
 }
-// the input-slice-major form of the two 7 -> 7 stages (a cell row's fragments built once for the up to three output slices it is a tap of) holds three
-// accumulators beside the 72 weight registers: the net variant fits its 128 registers (stages 24 k -> 18 k cycles), the obstacle variant spills all 72
-// (stage 79 k) and gains 1 k without the spill — it keeps the output-major form
+// the input-slice-major form of the 7 -> 7 stages (a cell row's fragments built once for the up to three output slices it is a tap of) holds three accumulators
+// beside the 72 weight registers: stages 24 k -> 18 k cycles.  The first stage takes it in both variants; the second only in the net variant — in the obstacle
+// variant its epilogue's registers on top spill all 72 weights (stage 79 k), and with 768 threads (no spill) the epilogue's align2 weights can no longer be asked
+// for ahead of a slice's matrix instructions (31 k)
 template <int N> struct xt_ic { static constexpr int value = N; };
 #ifndef XT_AL1_TC
 #define XT_AL1_TC 4
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const bool st = lv && w < wc;
             float* o = bufC1 + (h * we1 + w) * 7 + co0;
             if constexpr (MM != 0) {
-                // matrix mode 1, net variant: input-slice-major — the fragments of an input cell row (7 LDS reads + 8 permutes) are built ONCE and feed the up to three output
+                // matrix mode 1: input-slice-major — the fragments of an input cell row (7 LDS reads + 8 permutes) are built ONCE and feed the up to three output
                 // slices it is a tap of (output-major they were built three times: the vector work of the stage, 13 k of its 24 k cycles)
                 xt_f4 acc3[3];
 #pragma unroll
