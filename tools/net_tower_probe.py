@@ -44,5 +44,7 @@ else:
     with torch.no_grad():
         ref = agents.normalize(rep.encode_nets(batch.net_planes(reg[:256], net[:256])[:, :7 * N].reshape(-1, 7, Z, Y, X)))
     print("max abs err vs framework path (256 nets):", float((out[:256] - ref).abs().max()))
-print(json.dumps({"lib": os.environ.get("XR_LIB", "libxroute_hip.so"), "regions": n_regions, "net_pairs": int(reg.numel()), "ms_per_launch": round(ms, 4),
+import hashlib
+out_sha = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]          # (fixed-point scatters: the same bits whatever the order of the adds — equal across builds that only re-deal the work)
+print(json.dumps({"lib": os.environ.get("XR_LIB", "libxroute_hip.so"), "regions": n_regions, "net_pairs": int(reg.numel()), "ms_per_launch": round(ms, 4), "out_sha": out_sha,
                   "ms_per_1024_nets": round(ms * 1024 / reg.numel(), 4), "fallbacks": tower.fallbacks}))
