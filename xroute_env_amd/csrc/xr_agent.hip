@@ -96,8 +96,8 @@ __device__ __forceinline__ void xt_load_wA(const float* __restrict__ wc, int lan
 // lo x lo term is <= 2^-16 of the product).  One instruction takes K = 32 = the four input columns x eight channel slots of one (kd, kh) tap row — what the fp32
 // form (K = 4) needs seven instructions for, at 32 cycles each against ~17 — so a tap row costs 3 x 17 instead of 7 x 32 cycles of the matrix pipe.  Lane l holds, for
 // BOTH operands, the k-values of its quarter q = l >> 4 in the same order, so the sum over k does not care how the hardware numbers them; C / D are laid out like
-// the fp32 form's: the epilogues are shared.  Activations live in LDS as ONE word per value, hi << 16 | lo (same footprint as fp32): a lane reads its cell's seven
-// channel words as before and two byte permutes per word pair make the hi and the lo fragment.  Measured against the fp32 form on the reference fixtures (CPU
+// the fp32 form's.  Activations live in LDS as 16 + 16 bits per value (same footprint as fp32), a 7-channel cell in the order its readers want (xt_bfrag below): a lane
+// reads its cell's seven words as before and they ARE the hi and the lo fragment, up to a shift and a mask of the seventh.  Measured against the fp32 form on the reference fixtures (CPU
 // emulation first, tests/test_agents.py): normalised vectors within 1.1e-5 — the noise of a different fp32 summation order is 2e-6 … 5e-6.
 typedef __bf16 xt_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int xt_u4 __attribute__((ext_vector_type(4)));
@@ -106,16 +106,11 @@ __device__ __forceinline__ uint32_t xt_bf16_rne(float x) {           // the bf16
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
 }
-__device__ __forceinline__ float xt_pack(float x) {                  // hi << 16 | lo as the bits of a float (what the LDS arrays are declared as)
+__device__ __forceinline__ float xt_pack(float x) {                  // hi << 16 | lo as the bits of a float: a value of the 1-channel grid (align1's raw B operand)
     const uint32_t hi = xt_bf16_rne(x);
     const uint32_t lo = xt_bf16_rne(x - __uint_as_float(hi)) >> 16;
     return __uint_as_float(hi | lo);
 }
-__device__ __forceinline__ float xt_unpack(float w) {
-    const uint32_t u = __float_as_uint(w);
-    return __uint_as_float(u & 0xFFFF0000u) + __uint_as_float(u << 16);
-}
-template <int MM> __device__ __forceinline__ float xt_act(float x) { return MM ? xt_pack(x) : x; }          // an activation as the matrix stages' LDS arrays hold it
 
 // A fragments of one convolution: 9 tap rows x (hi, lo) x 4 words per lane, packed by the caller (agents._mfma_operand_bf16)
 __device__ __forceinline__ void xt_load_wAb(const float* __restrict__ wc, int lane, xt_u4 (&ah)[9], xt_u4 (&al)[9]) {
@@ -124,12 +119,40 @@ __device__ __forceinline__ void xt_load_wAb(const float* __restrict__ wc, int la
     for (int s = 0; s < 9; s++) { ah[s] = src[(2 * s) * 64]; al[s] = src[(2 * s + 1) * 64]; }
 }
 
-// the hi and lo B fragments of one cell: its seven channel words (+ a zero eighth slot)
+// A 7-channel CELL of the matrix stages' LDS arrays (matrix mode 1), seven words, laid out for the reader: words 0..2 = the hi halves of the channel pairs
+// (0,1) (2,3) (4,5) (even channel in the low 16 bits), words 3..5 = their lo halves, word 6 = channel 6 as hi << 16 | lo.  The hi and lo B fragments of a cell
+// are then its words {0, 1, 2, w6 >> 16} and {3, 4, 5, w6 & 0xFFFF}: seven reads and TWO vector instructions (one word hi << 16 | lo per channel took six
+// byte permutes on top: a cell is written once and read as a fragment ~30 times, and the 7 -> 7 stages are bound by the building of their fragments).
 __device__ __forceinline__ void xt_bfrag(const float* __restrict__ cell, xt_u4& bh, xt_u4& bl) {
     const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(cell);
     const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5], w6 = pw[6];
-    bh = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u), w6 >> 16};
-    bl = xt_u4{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u), w6 & 0xFFFFu};
+    bh = xt_u4{w0, w1, w2, w6 >> 16};
+    bl = xt_u4{w3, w4, w5, w6 & 0xFFFFu};
+}
+// the writer's side: `half` 0 = channels 0..3 (v0..v3) -> words 0, 1, 3, 4;  half 1 = channels 4..6 (v0..v2) -> words 2, 5, 6.  (A lane of the matrix stages'
+// epilogues holds one half of a cell.)
+__device__ __forceinline__ void xt_store_half(float* __restrict__ cell, const int half, const float v0, const float v1, const float v2, const float v3) {
+    uint32_t* __restrict__ pw = reinterpret_cast<uint32_t*>(cell);
+    const uint32_t h0 = xt_bf16_rne(v0), h1 = xt_bf16_rne(v1), h2 = xt_bf16_rne(v2), h3 = xt_bf16_rne(v3);
+    const uint32_t l0 = xt_bf16_rne(v0 - __uint_as_float(h0)), l1 = xt_bf16_rne(v1 - __uint_as_float(h1));
+    const uint32_t l2 = xt_bf16_rne(v2 - __uint_as_float(h2)), l3 = xt_bf16_rne(v3 - __uint_as_float(h3));
+    pw[2 * half] = (h0 >> 16) | h1;
+    pw[3 + 2 * half] = (l0 >> 16) | l1;
+    pw[half ? 6 : 1] = half ? (h2 | (l2 >> 16)) : ((h2 >> 16) | h3);
+    if (!half) pw[4] = (l2 >> 16) | l3;
+}
+__device__ __forceinline__ void xt_store_cell(float* __restrict__ cell, const float (&v)[7]) {
+    xt_store_half(cell, 0, v[0], v[1], v[2], v[3]);
+    xt_store_half(cell, 1, v[4], v[5], v[6], 0.f);
+}
+// ... and the values back (the residual of the block's second convolution): the half's channels as floats, hi + lo
+__device__ __forceinline__ void xt_load_half(const float* __restrict__ cell, const int half, float (&v)[4]) {
+    const uint32_t* __restrict__ pw = reinterpret_cast<const uint32_t*>(cell);
+    const uint32_t a = pw[2 * half], c = pw[3 + 2 * half], b = pw[half ? 6 : 1], d = pw[half ? 6 : 4];
+    v[0] = __uint_as_float(a << 16) + __uint_as_float(c << 16);
+    v[1] = __uint_as_float(a & 0xFFFF0000u) + __uint_as_float(c & 0xFFFF0000u);
+    v[2] = half ? __uint_as_float(b & 0xFFFF0000u) + __uint_as_float(b << 16) : __uint_as_float(b << 16) + __uint_as_float(d << 16);
+    v[3] = half ? 0.f : __uint_as_float(b & 0xFFFF0000u) + __uint_as_float(d & 0xFFFF0000u);
 }
 // the input-slice-major form of the 7 -> 7 stages (a cell row's fragments built once for the up to three output slices it is a tap of) holds three accumulators
 // beside the 72 weight registers: stages 24 k -> 18 k cycles.  The first stage takes it in both variants; the second only in the net variant — in the obstacle
@@ -496,7 +519,16 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         __syncthreads();
         {
             const float inv = qmax > 0.f ? bound * (1.f / 1073741824.f) : 0.f;
-            for (int i = tid; i < nB; i += nthr) bufB[i] = xt_act<MM>(na.bg[i] + (float)accB[i] * inv);
+            if constexpr (MM != 0) {
+                for (int c = tid; c * 7 < nB; c += nthr) {                                // (a thread reads its cell's seven sums, then writes the cell's seven words over them)
+                    float v[7];
+#pragma unroll
+                    for (int k = 0; k < 7; k++) v[k] = na.bg[c * 7 + k] + (float)accB[c * 7 + k] * inv;
+                    xt_store_cell(bufB + c * 7, v);
+                }
+            } else {
+                for (int i = tid; i < nB; i += nthr) bufB[i] = na.bg[i] + (float)accB[i] * inv;
+            }
         }
         __syncthreads();
     } else {
@@ -621,12 +653,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             for (int j = 0; j < NT; j++) {
                 const int tile = t0 + j * nw;
                 const int dz = xt_q(tile, fT), f = (tile - dz * T) * 16 + pn, hz = xt_q(f, fppr), p = f - hz * ppr, w = 2 * p + dwv;
-                if (ok[j] && w < ow) {
-                    float* o = bufB + ((dz * oh + hz) * ow + w) * 7 + co0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (co0 + i < 7) o[i] = xt_pack(acc[j][i]);
-                }
+                if (ok[j] && w < ow) xt_store_half(bufB + ((dz * oh + hz) * ow + w) * 7, co0 >> 2, acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
             }
         };
         constexpr int TC = XT_AL1_TC;
@@ -664,8 +691,13 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                 }
             }
         }
+        if constexpr (MM != 0) {
+            const float v[7] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0]};
+            xt_store_cell(bufB + i * 7, v);
+        } else {
 #pragma unroll
-        for (int co = 0; co < 7; co++) bufB[i * 7 + co] = xt_act<MM>(acc[co >> 1][co & 1]);
+            for (int co = 0; co < 7; co++) bufB[i * 7 + co] = acc[co >> 1][co & 1];
+        }
     }
 #ifdef XT_PHASE_TIMING
     xt_a1 = __builtin_readcyclecounter();
@@ -696,8 +728,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
         const int d = i / nfr, r = i - d * nfr, r2 = r - 2 * we1;
         const int h = r2 < 0 ? oh + 1 + r / we1 : r2 >> 1, w = r2 < 0 ? r % we1 : ow + 1 + (r2 & 1);
         float* o = bufC1 + ((d * he1 + h) * we1 + w) * 7;
+        float v[7];
 #pragma unroll
-        for (int co = 0; co < 7; co++) o[co] = xt_act<MM>(fmaxf(wt[XT_C1 + 4096 + co], 0.f));
+        for (int co = 0; co < 7; co++) v[co] = fmaxf(wt[XT_C1 + 4096 + co], 0.f);
+        if constexpr (MM != 0) xt_store_cell(o, v);
+        else {
+#pragma unroll
+            for (int co = 0; co < 7; co++) o[co] = v[co];
+        }
     }
     const int cbase = (int)(bufC1 - xt_smem);
 #ifdef XT_PHASE_TIMING
@@ -758,9 +796,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
                     if (!((dm >> d) & 1) || !st) continue;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = xt_pack(fmaxf(acc3[d][i], 0.f));
+                    xt_store_half(o - co0 + d * he1 * we1 * 7, co0 >> 2, fmaxf(acc3[d][0], 0.f), fmaxf(acc3[d][1], 0.f), fmaxf(acc3[d][2], 0.f), fmaxf(acc3[d][3], 0.f));
                 }
                 continue;
             }
@@ -791,7 +827,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                 if (st) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = xt_act<MM>(fmaxf(acc[i], 0.f));
+                        if (co0 + i < 7) o[d * he1 * we1 * 7 + i] = fmaxf(acc[i], 0.f);          // (fp32 mode: matrix mode 1 left above)
                 }
 #pragma unroll
                 for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
@@ -870,10 +906,14 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
                 // what the epilogue needs, fetched before the instructions run: the residual of the lane's four cells and their 12 align2 weights
                 const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
                 const xt_f4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2];          // [channel co0 .. co0 + 3][kw]
-                const float* __restrict__ pb = (inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
                 float pv[4];
+                if constexpr (MM != 0) {
+                    xt_load_half((inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 : xt_smem + zidx, co0 >> 2, pv);
+                } else {
+                    const float* __restrict__ pb = (inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 + co0 : xt_smem + zidx;
 #pragma unroll
-                for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? (MM ? xt_unpack(pb[i]) : pb[i]) : 0.f;
+                    for (int i = 0; i < 4; i++) pv[i] = co0 + i < 7 ? pb[i] : 0.f;
+                }
                 xt_f4 acc = {bias[0], bias[1], bias[2], bias[3]};
                 if constexpr (RB) {
                     acc = d == 0 ? acc3[0] : d == 1 ? acc3[RB ? 1 : 0] : acc3[RB ? 2 : 0];
