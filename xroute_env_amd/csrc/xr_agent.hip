@@ -163,6 +163,7 @@ template <int N> struct xt_ic { static constexpr int value = N; };
 #define XT_AL1_TC 4
 #endif
 template <bool NET, int MM> constexpr bool xt_reuse_b() { return NET && MM != 0; }
+template <bool NET, int MM, int BT> constexpr bool xt_reuse_b2() { return MM != 0 && (NET || BT <= 768); }      // the second stage: see the launcher's thread count
 __device__ __forceinline__ xt_f4 xt_mm3b(const xt_u4 ah, const xt_u4 al, const xt_u4 bh, const xt_u4 bl, xt_f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bh), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xt_bf8, ah), __builtin_bit_cast(xt_bf8, bl), acc, 0, 0, 0);
@@ -875,8 +876,50 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             const bool ov = lv && w < cols;
             const bool inhw = ov && h < oh && w < ow;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            constexpr bool RB = xt_reuse_b<NET, MM>();
+            constexpr bool RB = xt_reuse_b2<NET, MM, BT>();
+            constexpr bool PRE = RB && !NET;                          // (768 threads: 170 registers — room to ask for all three slices' epilogue operands up front)
             xt_f4 acc3[RB ? 3 : 1];
+            if constexpr (PRE) {
+                xt_f4 wkp[3][3];
+                float pvp[3][4];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    if (!((dm >> d) & 1)) continue;
+                    const xt_f4* __restrict__ wk = reinterpret_cast<const xt_f4*>(wt + XT_AL2 + ((d * 64 + h) * 8 + co0) * 3);
+                    wkp[d][0] = wk[0]; wkp[d][1] = wk[1]; wkp[d][2] = wk[2];
+                    xt_load_half((inhw && d < od) ? bufB + ((d * oh + h) * ow + w) * 7 : xt_smem + zidx, co0 >> 2, pvp[d]);
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+                for (int dd = 0; dd < 3; dd++) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; kh++) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        xt_u4 bh, bl;
+                        xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            const int kd = dd - d + 1;
+                            if (kd < 0 || kd > 2 || !((dm >> d) & 1)) continue;
+                            acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    if (!((dm >> d) & 1) || !ov) continue;
+                    const float wl[12] = {wkp[d][0][0], wkp[d][0][1], wkp[d][0][2], wkp[d][0][3], wkp[d][1][0], wkp[d][1][1], wkp[d][1][2], wkp[d][1][3],
+                                          wkp[d][2][0], wkp[d][2][1], wkp[d][2][2], wkp[d][2][3]};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (co0 + i < 7) {
+                            const float c = fmaxf(acc3[d][i] + pvp[d][i], 0.f);
+                            s0 += wl[i * 3 + 0] * c; s1 += wl[i * 3 + 1] * c; s2 += wl[i * 3 + 2] * c;
+                        }
+                    }
+                }
+            } else {
             if constexpr (RB) {                                       // matrix mode 1, net variant: input-slice-major, the fragments of a cell row built once (see the first stage)
 #pragma unroll
                 for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
@@ -948,6 +991,7 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
 #pragma unroll
                 for (int kh = 0; kh < 3; kh++) am[kh] += ds[kh];
             }
+            }       // (!PRE)
             s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);     // channels 0-3 + channels 4-6 of the same cells
             // the tile's pairs lie in rows h0 .. h1: one row at a time, so that the lanes of a pass own distinct columns
             const int h0 = (t * 16) / ppr, h1 = min(t * 16 + 15, npair - 1) / ppr;
@@ -1161,7 +1205,10 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     if (g.od > 3 || g.oh + 3 > 64 || g.ow + 3 > 64) return XR_ERR_RANGE;
     g.cols = g.ow + 2;
     const int64_t N = (int64_t)D * H * W, nB = 7LL * g.od * g.oh * g.ow, nC1 = 21LL * (g.oh + 3) * (g.ow + 3);
-    static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : 1024; return (t == 256 || t == 512 || t == 1024) ? t : 1024; }();      // (1024: 0.83 against 0.93 ms per agent step)
+    // threads per workgroup (one workgroup per CU either way: LDS): matrix mode 1 runs 768 — three waves per SIMD have 170 registers each, what the second 7 -> 7
+    // stage needs to build every fragment once (three accumulators + the three slices' epilogue operands asked for up front): 0.155 against 0.163 ms per 1024 envs;
+    // the fp32 mode keeps 1024 (0.83 against 0.93 ms per agent step, round 5).  XR_TOWER_THREADS overrides (A/B).
+    static const int threads = [] { const char* v = getenv("XR_TOWER_THREADS"); const int t = v ? atoi(v) : (xt_matrix_mode() ? 768 : 1024); return (t == 256 || t == 512 || t == 768 || t == 1024) ? t : 1024; }();
     const int64_t Np = (int64_t)(D + 2) * (H + 2) * ((W + 2) | 1);
     g.y_in_b = Np <= nB;
     const int64_t c1_alloc = nC1 > (g.y_in_b ? Np : 2 * Np) ? nC1 : (g.y_in_b ? Np : 2 * Np);      // floats behind b: the first activation of the 7-channel block, or
@@ -1189,6 +1236,7 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
         }                                                                                                                                                   \
     } while (0)
     if (threads == 1024) { if (mm) XT_LAUNCH(1024, 1); else XT_LAUNCH(1024, 0); }
+    else if (threads == 768) { if (mm) XT_LAUNCH(768, 1); else XT_LAUNCH(768, 0); }
     else if (threads == 512) { if (mm) XT_LAUNCH(512, 1); else XT_LAUNCH(512, 0); }
     else { if (mm) XT_LAUNCH(256, 1); else XT_LAUNCH(256, 0); }
 #undef XT_LAUNCH
