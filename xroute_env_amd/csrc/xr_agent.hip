@@ -37,7 +37,7 @@ struct XtDims {
     int od, oh, ow;       // its output
     int cols;             // columns of the last stage: ow + 2
     int y_in_b;           // the 1-channel block's intermediate lives in b's LDS space (else behind x in the first activation's space, which then grows)
-    int strip;            // cells per thread of the 1-channel convolutions: 3 or 5, whichever takes fewer instructions over all passes
+    int strip;            // cells per thread of the 1-channel convolutions: 3, 5 or 4 (the packed form), whichever takes fewer instructions over all passes
     int vec_load;         // rows of x are multiples of 16 bytes at 16-byte aligned addresses: four cells per load
     int tail;             // floats of b + the first activation's allocation: behind them 8 zero words and the waves' column sums [nw][cols + 2][3]
 };
@@ -223,6 +223,39 @@ __device__ __forceinline__ void xt_conv1_strips(const float* __restrict__ wgt, c
         float* o = out + pi + (Hp + 1) * Wp + 1;
 #pragma unroll
         for (int j = 0; j < S; j++)
+            if (w0 + j < W) { const float v_ = fmaxf(RES ? acc[j] + o[j] : acc[j], 0.f); o[j] = PACK ? xt_pack(v_) : v_; }
+    }
+}
+
+// The same, four cells per thread as TWO packed sums (v_pk_fma_f32): a tap row's pairs (v0 v1) (v1 v2) (v2 v3) (v3 v4) (v4 v5) are five two-word LDS reads —
+// a read lands in an aligned register pair, so the pairs cost no moves — and feed six packed FMAs with the weight on both halves (scalar pairs): 11
+// instructions per tap row and four cells where the strips of three take 3 reads + 9 FMAs for three.  Same order of the sums (kd, kh, kw): same bits.
+template <bool RES, bool PACK>
+__device__ __forceinline__ void xt_conv1_pk4(const float* __restrict__ wgt, const float* in, float* out, int D, int H, int W, int tid, int nthr) {
+    const int Hp = H + 2, Wp = (W + 2) | 1, rows = D * H, nstrip = rows * ((W + 3) >> 2);
+    xt_f2 wk[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) wk[k] = xt_f2{wgt[k], wgt[k]};
+    const float bias = wgt[27];
+    const XtFd frows = xt_fd(rows), fH = xt_fd(H);
+    for (int i = tid; i < nstrip; i += nthr) {
+        const int sx = xt_q(i, frows), r = i - sx * rows, d = xt_q(r, fH), h = r - d * H, w0 = sx * 4;
+        const int pi = (d * Hp + h) * Wp + w0;                 // tap (0, 0, 0) of the strip's first cell
+        xt_f2 a01 = {bias, bias}, a23 = {bias, bias};
+#pragma unroll
+        for (int kd = 0; kd < 3; kd++)
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                const float* row = in + pi + (kd * Hp + kh) * Wp;
+                const xt_f2 p01 = {row[0], row[1]}, p12 = {row[1], row[2]}, p23 = {row[2], row[3]}, p34 = {row[3], row[4]}, p45 = {row[4], row[5]};
+                const int k = (kd * 3 + kh) * 3;
+                a01 += wk[k] * p01; a01 += wk[k + 1] * p12; a01 += wk[k + 2] * p23;
+                a23 += wk[k] * p23; a23 += wk[k + 1] * p34; a23 += wk[k + 2] * p45;
+            }
+        float* o = out + pi + (Hp + 1) * Wp + 1;
+        const float acc[4] = {a01[0], a01[1], a23[0], a23[1]};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
             if (w0 + j < W) { const float v_ = fmaxf(RES ? acc[j] + o[j] : acc[j], 0.f); o[j] = PACK ? xt_pack(v_) : v_; }
     }
 }
@@ -572,12 +605,16 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
     __syncthreads();
     XT_LAP(1);
     // ---- ResidualBlock(1): y = relu(conv3(x) + b1), then a = relu(conv3(y) + b2 + x) over x ------------------------------------------------
-    if (g.strip == 5) xt_conv1_strips<5, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
+    if (g.strip == 4) xt_conv1_pk4<false, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
+    else if (g.strip == 5) xt_conv1_strips<5, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     else xt_conv1_strips<3, false>(wt + XT_A1, xpad, ypad, D, H, W, tid, nthr);
     __syncthreads();
     XT_LAP(2);
     const bool al1_mm = MM && g.sh == 1 && g.sw == 1;      // align1 on the matrix pipe too (matrix mode 1, unit strides in h and w)
-    if (al1_mm) {
+    if (g.strip == 4) {
+        if (al1_mm) xt_conv1_pk4<true, MM != 0>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+        else xt_conv1_pk4<true, false>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
+    } else if (al1_mm) {
         if (g.strip == 5) xt_conv1_strips<5, true, MM != 0>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
         else xt_conv1_strips<3, true, MM != 0>(wt + XT_A2, ypad, xpad, D, H, W, tid, nthr);
     } else {
@@ -1213,10 +1250,12 @@ int32_t xr_agent_obstacle_tower(const float* head_dev, int64_t head_stride, int3
     g.y_in_b = Np <= nB;
     const int64_t c1_alloc = nC1 > (g.y_in_b ? Np : 2 * Np) ? nC1 : (g.y_in_b ? Np : 2 * Np);      // floats behind b: the first activation of the 7-channel block, or
                                                                                                // the 1-channel block's grids where they need more (narrow regions)
-    {   // cells per thread of the 1-channel convolutions: 9 (S + 2) reads + 27 S FMAs + ~25 index instructions per strip, times the passes
-        auto cost = [&](int S) { const int64_t strips = (int64_t)D * H * ((W + S - 1) / S); return ((strips + threads - 1) / threads) * (36 * S + 43); };
-        g.strip = cost(5) < cost(3) ? 5 : 3;
-        if (const char* v = getenv("XR_TOWER_STRIP")) { const int S = atoi(v); if (S == 3 || S == 5) g.strip = S; }      // (A/B)
+    {   // cells per thread of the 1-channel convolutions: 9 (S + 2) reads + 27 S FMAs + ~25 index instructions per strip, times the passes; 4 = the packed form
+        // (xt_conv1_pk4: 9 x 11 instructions + the same overhead, measured 1.14 x the cost of a strip of three per pass)
+        auto passes = [&](int S) { const int64_t strips = (int64_t)D * H * ((W + S - 1) / S); return (strips + threads - 1) / threads; };
+        const int64_t c3 = passes(3) * (36 * 3 + 43), c4 = passes(4) * 172, c5 = passes(5) * (36 * 5 + 43);
+        g.strip = c4 <= c3 && c4 <= c5 ? 4 : c5 < c3 ? 5 : 3;
+        if (const char* v = getenv("XR_TOWER_STRIP")) { const int S = atoi(v); if (S == 3 || S == 4 || S == 5) g.strip = S; }      // (A/B)
     }
     g.vec_load = (W % 4 == 0) && (head_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(head_dev) % 16 == 0);
     if (nB < 1024 * 3 || head_stride < N) return XR_ERR_RANGE;
