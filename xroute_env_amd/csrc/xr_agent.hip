@@ -811,30 +811,36 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             if constexpr (MM != 0) {
                 // matrix mode 1: input-slice-major — the fragments of an input cell row (7 LDS reads + 8 permutes) are built ONCE and feed the up to three output
                 // slices it is a tap of (output-major they were built three times: the vector work of the stage, 13 k of its 24 k cycles)
-                xt_f4 acc3[3];
+                // The slices of the item (dm: 7 = all three, 5 / 2 = the shared group of a partial round) are a COMPILE-TIME constant of the body: tested at run time
+                // (wave-uniform) every triple of matrix instructions sat in its own basic block behind a branch — 27 branches per item, nothing scheduled across them.
+                auto body = [&](auto dm_c) {
+                    constexpr int DM = decltype(dm_c)::value;
+                    xt_f4 acc3[3];
 #pragma unroll
-                for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+                    for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                for (int dd = 0; dd < 3; dd++) {
-                    if (dd >= od) break;                              // (standard padding behind the data's slices) — wave-uniform
+                    for (int dd = 0; dd < 3; dd++) {
+                        if (dd >= od) break;                              // (standard padding behind the data's slices) — wave-uniform
 #pragma unroll
-                    for (int kh = 0; kh < 3; kh++) {
-                        __builtin_amdgcn_sched_barrier(0);            // (one cell row's fragments at a time: hoisting all nine rows' reads spills)
-                        xt_u4 bh, bl;
-                        xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
+                        for (int kh = 0; kh < 3; kh++) {
+                            __builtin_amdgcn_sched_barrier(0);            // (one cell row's fragments at a time: hoisting all nine rows' reads spills)
+                            xt_u4 bh, bl;
+                            xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
 #pragma unroll
-                        for (int d = 0; d < 3; d++) {
-                            const int kd = dd - d + 1;
-                            if (kd < 0 || kd > 2 || !((dm >> d) & 1)) continue;       // (compile-time / wave-uniform)
-                            acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                            for (int d = 0; d < 3; d++) {
+                                const int kd = dd - d + 1;
+                                if (kd < 0 || kd > 2 || !((DM >> d) & 1)) continue;       // (compile time)
+                                acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    if (!((dm >> d) & 1) || !st) continue;
-                    xt_store_half(o - co0 + d * he1 * we1 * 7, co0 >> 2, fmaxf(acc3[d][0], 0.f), fmaxf(acc3[d][1], 0.f), fmaxf(acc3[d][2], 0.f), fmaxf(acc3[d][3], 0.f));
-                }
+                    for (int d = 0; d < 3; d++) {
+                        if (!((DM >> d) & 1) || !st) continue;
+                        xt_store_half(o - co0 + d * he1 * we1 * 7, co0 >> 2, fmaxf(acc3[d][0], 0.f), fmaxf(acc3[d][1], 0.f), fmaxf(acc3[d][2], 0.f), fmaxf(acc3[d][3], 0.f));
+                    }
+                };
+                if (dm == 7) body(xt_ic<7>{}); else if (dm == 5) body(xt_ic<5>{}); else body(xt_ic<2>{});          // (xt_tile_item deals 7, 5 and 2 only)
                 continue;
             }
 #pragma unroll 1
@@ -959,21 +965,25 @@ __global__ void __launch_bounds__(BT) xr_ob_tower_kernel(const float* __restrict
             if constexpr (RB) {                                       // matrix mode 1, net variant: input-slice-major, the fragments of a cell row built once (see the first stage)
 #pragma unroll
                 for (int d = 0; d < 3; d++) acc3[d] = xt_f4{bias[0], bias[1], bias[2], bias[3]};
+                auto body = [&](auto dm_c) {                              // (the item's slices as a compile-time constant: see the first stage)
+                    constexpr int DM = decltype(dm_c)::value;
 #pragma unroll
-                for (int dd = 0; dd < 3; dd++) {
+                    for (int dd = 0; dd < 3; dd++) {
 #pragma unroll
-                    for (int kh = 0; kh < 3; kh++) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        xt_u4 bh, bl;
-                        xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
+                        for (int kh = 0; kh < 3; kh++) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            xt_u4 bh, bl;
+                            xt_bfrag(xt_smem + am[kh] + dd * ds[kh], bh, bl);
 #pragma unroll
-                        for (int d = 0; d < 3; d++) {
-                            const int kd = dd - d + 1;
-                            if (kd < 0 || kd > 2 || !((dm >> d) & 1)) continue;
-                            acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                            for (int d = 0; d < 3; d++) {
+                                const int kd = dd - d + 1;
+                                if (kd < 0 || kd > 2 || !((DM >> d) & 1)) continue;
+                                acc3[d] = xt_mm3b(wAh[kd * 3 + kh], wAl[kd * 3 + kh], bh, bl, acc3[d]);
+                            }
                         }
                     }
-                }
+                };
+                if (dm == 7) body(xt_ic<7>{}); else if (dm == 5) body(xt_ic<5>{}); else body(xt_ic<2>{});
             }
 #pragma unroll 1
             for (int d = 0; d < 3; d++) {
